@@ -1,0 +1,135 @@
+"""Normative fixed-point resampler (numpy).  TEST INFRASTRUCTURE -- see ``oracle/__init__.py``.
+
+Why fixed point: ``north_star`` asks for bit-exact resample indices under a fixed seed,
+but a floating-point prefix sum rounds differently for every scan tree, and libm ``exp``
+differs from the GPU's by an ulp.  So the *definition* of the resampler is integer:
+
+1. ``x_i = logw_i - max_j logw_j``                         (one IEEE fp32 subtract)
+2. ``e_i = detexp(x_i)``                                   (fp32 mul/add only, fixed order)
+3. ``q_i = floor(e_i * 2**24)`` as u64, ``Q = sum q_i``    (integer => order independent)
+4. ``cdf_i = q_0 + ... + q_i``                             (inclusive integer scan)
+5. systematic (one uniform ``u`` per trajectory), ``U = floor(u * 2**24)``::
+
+       p_k = (k*Q + ((U*Q) >> 24)) // M_out        k = 0 .. M_out-1
+
+   multinomial (one uniform per output particle)::
+
+       p_k = (U_k * Q) >> 24
+
+6. ``index_k = #{i : cdf_i <= p_k}``  (first ``i`` whose inclusive CDF exceeds ``p_k``)
+
+Every quantity fits u64 for ``M <= 65536`` (``Q <= 2**40``, ``U*Q < 2**64``,
+``k*Q < 2**56``).  Upstream torchfilter resamples with
+``Categorical(logits=logw).sample((M,))`` (multinomial, torch global RNG; SURVEY.md
+A.2) which cannot be reproduced bit-for-bit by anything; mode ``"multinomial"`` here is
+the same distribution driven by explicit uniforms, ``"systematic"`` is the low-variance
+scheme ``north_star`` asks for.
+"""
+import numpy as np
+
+_F = np.float32
+LOG2E = _F(1.4426950408889634)
+# Taylor coefficients of 2**f = exp(f ln 2), degree 6, highest first.
+_POLY = [
+    _F(0.00015403530393381608),
+    _F(0.0013333558146428443),
+    _F(0.009618129107628477),
+    _F(0.05550410866482158),
+    _F(0.2402265069591007),
+    _F(0.6931471805599453),
+    _F(1.0),
+]
+FIX_BITS = 24
+MAX_PARTICLES = 1 << 16
+
+
+def detexp(x: np.ndarray) -> np.ndarray:
+    """Deterministic fp32 ``exp`` for ``x <= 0``: separate (un-fused) multiplies and adds
+    in a fixed order, so numpy and the HIP kernel agree bit for bit."""
+    x = np.asarray(x, dtype=_F)
+    with np.errstate(invalid="ignore", over="ignore"):
+        t = (x * LOG2E).astype(_F)
+        t = np.maximum(t, _F(-126.0)).astype(_F)  # also maps -inf -> -126 (=> q == 0)
+        n = np.rint(t).astype(_F)  # round-half-even, like v_rndne_f32
+        f = (t - n).astype(_F)
+        p = np.full_like(f, _POLY[0])
+        for c in _POLY[1:]:
+            p = (p * f).astype(_F)
+            p = (p + c).astype(_F)
+        scale = ((n.astype(np.int32) + 127) << 23).astype(np.int32).view(_F)
+        return (p * scale).astype(_F)
+
+
+def quantise(logw: np.ndarray):
+    """``(N, M)`` fp32 log-weights -> (``q`` u64 ``(N, M)``, fp32 ``e`` ``(N, M)``, max ``(N,)``)."""
+    logw = np.asarray(logw, dtype=_F)
+    m = logw.max(axis=1, keepdims=True)
+    e = detexp((logw - m).astype(_F))
+    q = np.floor(e.astype(np.float64) * float(1 << FIX_BITS)).astype(np.uint64)
+    return q, e, m[:, 0]
+
+
+def _fix_uniform(u) -> np.ndarray:
+    u = np.asarray(u, dtype=_F)
+    assert np.all((u >= 0) & (u < 1)), "uniforms must lie in [0, 1)"
+    return np.floor(u.astype(np.float64) * float(1 << FIX_BITS)).astype(np.uint64)
+
+
+def resample_indices(logw: np.ndarray, u: np.ndarray, mode: str, num_out: int = None) -> np.ndarray:
+    """Resampling ancestor indices, ``(N, num_out)`` int32.
+
+    ``mode="systematic"``: ``u`` has shape ``(N,)``; ``mode="multinomial"``: ``(N, num_out)``.
+    """
+    logw = np.asarray(logw, dtype=_F)
+    N, M = logw.shape
+    num_out = M if num_out is None else int(num_out)
+    assert 1 <= M <= MAX_PARTICLES and 1 <= num_out <= MAX_PARTICLES
+    q, _, _ = quantise(logw)
+    cdf = np.cumsum(q, axis=1, dtype=np.uint64)
+    Q = cdf[:, -1]
+    U = _fix_uniform(u)
+    sh = np.uint64(FIX_BITS)
+    if mode == "systematic":
+        assert U.shape == (N,)
+        R = (U * Q) >> sh
+        k = np.arange(num_out, dtype=np.uint64)[None, :]
+        p = (k * Q[:, None] + R[:, None]) // np.uint64(num_out)
+    elif mode == "multinomial":
+        assert U.shape == (N, num_out)
+        p = (U * Q[:, None]) >> sh
+    else:
+        raise ValueError(mode)
+    idx = np.empty((N, num_out), dtype=np.int32)
+    for n in range(N):
+        idx[n] = np.searchsorted(cdf[n], p[n], side="right")
+    assert idx.max(initial=0) < M
+    return idx
+
+
+def reweight_resample(loglik, logw, states, u, mode: str, num_out: int = None):
+    """What kernel K1 (``mmf_pf_reweight_resample``) computes, restated on the CPU.
+
+    Follows the post-measurement half of upstream ``ParticleFilter.forward`` (SURVEY.md
+    A.2 / section 3.2): ``logw += loglik``; normalise; weighted-mean estimate; then, when
+    ``mode != "none"``, resample ancestors, gather states and reset log-weights to
+    ``-log(num_out)``.
+
+    Returns ``(estimate (N,d), states_out, logw_out, indices or None)``.
+    """
+    loglik = np.asarray(loglik, dtype=_F)
+    logw = np.asarray(logw, dtype=_F)
+    states = np.asarray(states, dtype=_F)
+    N, M, d = states.shape
+    tot = (logw + loglik).astype(_F)
+    _, e, m = quantise(tot)
+    S = e.astype(np.float64).sum(axis=1)
+    w = e.astype(np.float64) / S[:, None]
+    estimate = (w[:, :, None] * states.astype(np.float64)).sum(axis=1).astype(_F)
+    if mode == "none":
+        logw_out = ((tot - m[:, None]).astype(np.float64) - np.log(S)[:, None]).astype(_F)
+        return estimate, states.copy(), logw_out, None
+    num_out = M if num_out is None else int(num_out)
+    idx = resample_indices(tot, u, mode, num_out)
+    states_out = np.take_along_axis(states, idx[:, :, None].astype(np.int64), axis=1)
+    logw_out = np.full((N, num_out), -np.log(_F(num_out)), dtype=_F)
+    return estimate, states_out, logw_out, idx

@@ -1,0 +1,194 @@
+"""Particle filter and (virtual-sensor) EKF recursions -- torchfilter.filters restated.
+
+Follows the upstream step order recorded in SURVEY.md A.2 / 3.2 / 3.3 and the
+reference's use of the classes: ``ParticleFilter(dynamics_model=, measurement_model=,
+num_particles=)`` with a public mutable ``num_particles`` (``door_models/pf.py:18-27``);
+``VirtualSensorExtendedKalmanFilter(dynamics_model=, virtual_sensor_model=)`` whose
+belief is read back as ``_belief_covariance`` (``base_models/crossmodal_kf.py:180``).
+Every random draw is an explicit tensor from ``self.noise`` (a ``NoiseSource``).
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import resample as _rs
+from ..fp.utils import SliceWrapper
+from . import base
+
+
+class ParticleFilter(base.Filter):
+    def __init__(
+        self,
+        *,
+        dynamics_model: base.DynamicsModel,
+        measurement_model: base.ParticleFilterMeasurementModel,
+        num_particles: int = 100,
+        resample: bool = None,
+        resample_mode: str = "systematic",
+        estimation_method: str = "weighted_average",
+    ):
+        super().__init__(state_dim=dynamics_model.state_dim)
+        assert measurement_model.state_dim == self.state_dim
+        self.dynamics_model = dynamics_model
+        self.measurement_model = measurement_model
+        self.num_particles = num_particles
+        self.resample = resample  # None => resample iff not self.training
+        assert resample_mode in ("systematic", "multinomial")
+        self.resample_mode = resample_mode
+        assert estimation_method in ("weighted_average", "argmax")
+        self.estimation_method = estimation_method
+        self.noise = base.NoiseSource(0)
+        self.particle_states: torch.Tensor = None  # (N, M, d)
+        self.particle_log_weights: torch.Tensor = None  # (N, M)
+        self.last_resample_indices = None
+        self._initialized = False
+
+    def initialize_beliefs(self, *, mean, covariance):
+        N, d = mean.shape
+        assert d == self.state_dim and covariance.shape == (N, d, d)
+        M = self.num_particles
+        eps = self.noise.gaussian((N, M, d), like=mean)
+        L = torch.linalg.cholesky(covariance)
+        self.particle_states = mean[:, None, :] + torch.einsum("nij,nmj->nmi", L, eps)
+        self.particle_log_weights = mean.new_full((N, M), -math.log(M))
+        self._initialized = True
+
+    def forward(self, *, observations, controls):
+        assert self._initialized, "initialize_beliefs() first"
+        N, M, d = self.particle_states.shape
+        do_resample = (not self.training) if self.resample is None else self.resample
+        assert do_resample or self.num_particles == M, (
+            "particle-count adaptation without resampling is not restated"
+        )
+
+        # propagate: same control for each of a trajectory's M particles
+        flat = self.particle_states.reshape(N * M, d)
+        rep_controls = SliceWrapper(controls).map(
+            lambda t: torch.repeat_interleave(t, repeats=M, dim=0)
+        )
+        pred, tril = self.dynamics_model(initial_states=flat, controls=rep_controls)
+        eps = self.noise.gaussian((N, M, d), like=pred).reshape(N * M, d)
+        self.particle_states = (pred + torch.einsum("rij,rj->ri", tril, eps)).reshape(N, M, d)
+
+        # reweight + normalise
+        loglik = self.measurement_model(states=self.particle_states, observations=observations)
+        assert loglik.shape == (N, M)
+        logw = self.particle_log_weights + loglik
+        logw = logw - torch.logsumexp(logw, dim=1, keepdim=True)
+        self.particle_log_weights = logw
+
+        if self.estimation_method == "weighted_average":
+            estimate = torch.sum(torch.exp(logw)[:, :, None] * self.particle_states, dim=1)
+        else:
+            best = torch.argmax(logw, dim=1)
+            estimate = self.particle_states[torch.arange(N), best]
+
+        if do_resample:
+            self._resample()
+        return estimate
+
+    def _resample(self):
+        N, M, d = self.particle_states.shape
+        Mo = self.num_particles
+        like = self.particle_log_weights
+        if self.resample_mode == "systematic":
+            u = self.noise.uniform((N,), like=like)
+        else:
+            u = self.noise.uniform((N, Mo), like=like)
+        idx = _rs.resample_indices(
+            like.detach().cpu().numpy(), u.detach().cpu().numpy(), self.resample_mode, Mo
+        )
+        idx_t = torch.from_numpy(idx.astype(np.int64)).to(like.device)
+        self.last_resample_indices = idx_t
+        self.particle_states = torch.gather(
+            self.particle_states, 1, idx_t[:, :, None].expand(N, Mo, d)
+        )
+        self.particle_log_weights = like.new_full((N, Mo), -math.log(Mo))
+
+
+class _IdentityMeasurementModel(base.KalmanFilterMeasurementModel):
+    """``C = I``: the virtual sensor already speaks state space."""
+
+    def __init__(self, *, state_dim: int):
+        super().__init__(state_dim=state_dim, observation_dim=state_dim)
+        self.scale_tril = None
+
+    def forward(self, *, states):
+        return states, self.scale_tril
+
+    def jacobian(self, *, states):
+        N, d = states.shape
+        return torch.eye(d, dtype=states.dtype, device=states.device)[None].expand(N, d, d)
+
+
+class ExtendedKalmanFilter(base.Filter):
+    """predict ``S- = A S A^T + L L^T`` / correct ``K = S- C^T (C S- C^T + R)^-1``,
+    ``S = (I - K C) S-`` -- no Joseph form, no symmetrisation."""
+
+    def __init__(self, *, dynamics_model, measurement_model):
+        super().__init__(state_dim=dynamics_model.state_dim)
+        self.dynamics_model = dynamics_model
+        self.measurement_model = measurement_model
+        self._belief_mean = None
+        self._belief_covariance = None
+        self._initialized = False
+
+    @property
+    def belief_mean(self):
+        return self._belief_mean
+
+    @belief_mean.setter
+    def belief_mean(self, v):
+        self._belief_mean = v
+
+    @property
+    def belief_covariance(self):
+        return self._belief_covariance
+
+    @belief_covariance.setter
+    def belief_covariance(self, v):
+        self._belief_covariance = v
+
+    def initialize_beliefs(self, *, mean, covariance):
+        N, d = mean.shape
+        assert d == self.state_dim and covariance.shape == (N, d, d)
+        self._belief_mean = mean
+        self._belief_covariance = covariance
+        self._initialized = True
+
+    def forward(self, *, observations, controls):
+        assert self._initialized, "initialize_beliefs() first"
+        self._predict_step(controls=controls)
+        self._update_step(observations=observations)
+        return self._belief_mean
+
+    def _predict_step(self, *, controls):
+        mu, Sigma = self._belief_mean, self._belief_covariance
+        mu_pred, L = self.dynamics_model(initial_states=mu, controls=controls)
+        A = self.dynamics_model.jacobian(initial_states=mu, controls=controls)
+        self._belief_mean = mu_pred
+        self._belief_covariance = A @ Sigma @ A.transpose(-1, -2) + L @ L.transpose(-1, -2)
+
+    def _update_step(self, *, observations):
+        mu, Sigma = self._belief_mean, self._belief_covariance
+        y_hat, Rtril = self.measurement_model(states=mu)
+        C = self.measurement_model.jacobian(states=mu)
+        R = Rtril @ Rtril.transpose(-1, -2)
+        S = C @ Sigma @ C.transpose(-1, -2) + R
+        K = Sigma @ C.transpose(-1, -2) @ torch.inverse(S)
+        self._belief_mean = mu + (K @ (observations - y_hat)[:, :, None]).squeeze(-1)
+        eye = torch.eye(K.shape[-1], dtype=K.dtype, device=K.device)
+        self._belief_covariance = (eye - K @ C) @ Sigma
+
+
+class VirtualSensorExtendedKalmanFilter(ExtendedKalmanFilter):
+    def __init__(self, *, dynamics_model, virtual_sensor_model):
+        ident = _IdentityMeasurementModel(state_dim=dynamics_model.state_dim)
+        super().__init__(dynamics_model=dynamics_model, measurement_model=ident)
+        self.virtual_sensor_model = virtual_sensor_model
+
+    def forward(self, *, observations, controls):
+        z, Rtril = self.virtual_sensor_model(observations=observations)
+        self.measurement_model.scale_tril = Rtril
+        return super().forward(observations=z, controls=controls)

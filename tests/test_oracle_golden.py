@@ -1,0 +1,73 @@
+"""The oracle's crossmodal layer vs. vectors produced by the REFERENCE's own classes.
+
+``tests/golden/{door,push}.npz`` were written by ``oracle/capture_golden.py`` running
+``/root/reference/crossmodal`` (rows R1-R12 of SURVEY.md section 8a, both tasks, N in {1,4},
+M in {1,8}, masks and blackout on/off); ``eval.npz`` by the reference's ``run_eval`` (H1).
+Nothing here reads ``/root/reference``.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import evalmetrics, golden_cases as gc, models as om
+
+_PARAMS = [
+    (case, tname, n, m)
+    for case in gc.CASES for tname in case.tasks for (n, m) in case.shapes
+]
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return {t: np.load(os.path.join(golden_dir, f"{t}.npz")) for t in ("door", "push")}
+
+
+def test_inputs_are_reproducible(golden):
+    for tname, task in om.TASKS.items():
+        inp = gc.make_inputs(task)
+        for k, v in inp.items():
+            np.testing.assert_array_equal(golden[tname][f"input/{k}"], v)
+
+
+@pytest.mark.parametrize("case,tname,n,m", _PARAMS,
+                         ids=[gc.case_key(c, t, n, m) for c, t, n, m in _PARAMS])
+def test_oracle_matches_reference_vectors(golden, case, tname, n, m):
+    torch.manual_seed(0)
+    torch.set_num_threads(2)
+    task = om.TASKS[tname]
+    z = golden[tname]
+    inp = {k[len("input/"):]: z[k] for k in z.files if k.startswith("input/")}
+    out = gc.run_case(case, case.make(task), task, inp, n, m)
+    prefix = gc.case_key(case, tname, n, m) + "/"
+    expected = {k[len(prefix):]: z[k] for k in z.files if k.startswith(prefix)}
+    assert set(out) == set(expected) and expected
+    for k, want in expected.items():
+        got = out[k]
+        assert got.shape == want.shape, k
+        np.testing.assert_array_equal(np.isneginf(got), np.isneginf(want))
+        fin = np.isfinite(want)
+        scale = max(1.0, float(np.abs(want[fin]).max()))
+        np.testing.assert_allclose(got[fin], want[fin], rtol=2e-4, atol=2e-5 * scale, err_msg=k)
+
+
+def test_eval_rmse_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "eval.npz"))
+    for tname in ("door", "push"):
+        res = evalmetrics.task_rmse(tname, z[f"{tname}/pred"], z[f"{tname}/true"][1:])
+        for k, v in res.items():
+            np.testing.assert_allclose(np.asarray(v), z[f"{tname}/{k}"], rtol=1e-6)
+
+
+def test_parameter_counts_match_reference():
+    # SURVEY.md B.3, counted on the reference's classes
+    want = dict(DoorKalmanFilter=717299, DoorCrossmodalKalmanFilter=1431084,
+                DoorMeasurementCrossmodalKalmanFilter=1380191, DoorParticleFilter=667808,
+                DoorCrossmodalParticleFilter=1309883, DoorUnimodalKalmanFilter=834830,
+                DoorMeasurementUnimodalKalmanFilter=783937, DoorUnimodalParticleFilter=697249,
+                PushKalmanFilter=195937, PushCrossmodalKalmanFilter=909292,
+                PushParticleFilter=667616, PushCrossmodalParticleFilter=1292987,
+                PushUnimodalKalmanFilter=313168, PushUnimodalParticleFilter=696993)
+    for name, count in want.items():
+        assert sum(p.numel() for p in om.build(name).parameters()) == count, name
