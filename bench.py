@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Benchmark of the filter hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload door_pf|push_pf|door_ekf]
+
+A *step* is one filter time step over one batch: for the particle-filter workloads the
+per-trajectory encoders (CNNs, control / observation MLPs, modality weights), the fused
+per-particle dynamics + measurement networks (K2) and reweight + resample (K1) for N x M
+particles.  The default workload is the one BASELINE.json's metric is quoted on: the door
+crossmodal particle filter with 4096 particles (batch 256 trajectories per GPU, weak
+scaling: rank r owns its own 256 trajectories; the only collective is the all-gather of
+per-sequence squared errors, ``multimodalfilter_amd/distributed.py``).
+
+Inputs (observations, controls, pre-drawn noise) are resident in HBM when the timed region
+starts; the timed region is ``forward_loop`` over exactly K steps, bracketed by barrier +
+``torch.cuda.synchronize()``; the time is the max over ranks.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
+
+WORKLOADS = {
+    "door_pf": dict(task="door", cls="DoorCrossmodalParticleFilter", kind="pf", batch=256, particles=4096,
+                    desc="door crossmodal particle filter, 4096 particles, batch 256 per GPU"),
+    "push_pf": dict(task="push", cls="PushCrossmodalParticleFilter", kind="pf", batch=256, particles=4096,
+                    desc="push crossmodal particle filter, 4096 particles, batch 256 per GPU"),
+    "door_ekf": dict(task="door", cls="DoorCrossmodalKalmanFilter", kind="ekf", batch=1024, particles=1,
+                     desc="door crossmodal EKF, batch 1024 trajectories per GPU"),
+}
+
+
+def build_filter(wl, device, seed=0):
+    import multimodalfilter_amd as mmf
+
+    torch.manual_seed(seed)
+    f = mmf.model_types(wl["task"])[wl["cls"]]()
+    f.to(device).eval()
+    return f
+
+
+def to_device(traj, device):
+    return {k: v.to(device) for k, v in traj.items()}
+
+
+def make_inputs(wl, steps, batch, seed, device, state_dim):
+    from multimodalfilter_amd import synthetic
+
+    traj = synthetic.make_trajectories(state_dim=state_dim, T=steps, N=batch, seed=seed)
+    return traj, to_device(traj, device)
+
+
+def run_pf(f, traj_dev, noise_dev, M, mode="systematic"):
+    """initialize at states[0] / 0.1 I (eval_helpers.py:125-131), then K steps."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import evaluation
+
+    eps0, eps, us = noise_dev
+    f.num_particles = M
+    f.resample_mode = mode
+    f.noise = mmf.ReplayNoise([eps0] + list(eps), list(us))
+    return evaluation.run_filter(f, traj_dev)
+
+
+def cpu_baseline_pf(wl, engine_filter, state_dim, cores, sample_batch=32, sample_steps=8, warm=1):
+    """The oracle (pure torch, fp32, CPU) on a bounded sample of the same workload, with the
+    engine run on the identical sample (same weights, observations, noise) for parity."""
+    from multimodalfilter_amd import synthetic
+    import multimodalfilter_amd as mmf
+    from oracle import models as om
+    from oracle.tf.base import ReplayNoise as OReplay
+
+    M = wl["particles"]
+    T = sample_steps + warm
+    torch.set_num_threads(cores)
+    traj = synthetic.make_trajectories(state_dim=state_dim, T=T, N=sample_batch, seed=4242)
+    eps0, eps, us = synthetic.draw_filter_noise(T=T, N=sample_batch, M=M, state_dim=state_dim, seed=4243)
+    oracle = om.build(wl["cls"])
+    oracle.load_state_dict({k: v.detach().cpu() for k, v in engine_filter.state_dict().items()})
+    oracle.eval()
+    oracle.num_particles = M
+    oracle.noise = OReplay([eps0] + eps, us)
+    obs = synthetic.observations_of(traj)
+    d = state_dim
+    cov = (torch.eye(d) * 0.1)[None].expand(sample_batch, d, d)
+    ests = []
+    with torch.no_grad():
+        oracle.initialize_beliefs(mean=traj["states"][0], covariance=cov)
+        for t in range(1, warm + 1):
+            ests.append(oracle(observations={k: v[t] for k, v in obs.items()}, controls=traj["controls"][t]))
+        t0 = time.perf_counter()
+        for t in range(warm + 1, T + 1):
+            ests.append(oracle(observations={k: v[t] for k, v in obs.items()}, controls=traj["controls"][t]))
+        dt = time.perf_counter() - t0
+    cpu_rate = sample_batch * M * sample_steps / dt
+    want = torch.stack(ests)
+
+    dev = next(engine_filter.parameters()).device
+    got = run_pf(engine_filter, to_device(traj, dev),
+                 (eps0.to(dev), [e.to(dev) for e in eps], [u.to(dev) for u in us]), M).cpu()
+    scale = max(1.0, float(want.abs().max()))
+    parity = {
+        "max_rel_err_posterior_mean": float((got - want).abs().max()) / scale,
+        "rmse_engine": [float(x) for x in ((got - traj["states"][1:]) ** 2).mean((0, 1)).sqrt()],
+        "rmse_oracle": [float(x) for x in ((want - traj["states"][1:]) ** 2).mean((0, 1)).sqrt()],
+    }
+    return {"value": cpu_rate, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle PF (oracle/), {wl['cls']}, batch {sample_batch} x {M} particles x "
+                      f"{sample_steps} steps after {warm} warm-up, {dt:.1f} s"}, parity
+
+
+def cpu_baseline_ekf(wl, engine_filter, state_dim, cores, sample_batch=256, sample_steps=6, warm=1):
+    from multimodalfilter_amd import evaluation, synthetic
+    from oracle import models as om
+
+    T = sample_steps + warm
+    torch.set_num_threads(cores)
+    traj = synthetic.make_trajectories(state_dim=state_dim, T=T, N=sample_batch, seed=4242)
+    oracle = om.build(wl["cls"])
+    oracle.load_state_dict({k: v.detach().cpu() for k, v in engine_filter.state_dict().items()})
+    oracle.eval()
+    obs = synthetic.observations_of(traj)
+    d = state_dim
+    cov = (torch.eye(d) * 0.1)[None].expand(sample_batch, d, d)
+    ests = []
+    with torch.no_grad():
+        oracle.initialize_beliefs(mean=traj["states"][0], covariance=cov)
+        for t in range(1, warm + 1):
+            ests.append(oracle(observations={k: v[t] for k, v in obs.items()}, controls=traj["controls"][t]))
+        t0 = time.perf_counter()
+        for t in range(warm + 1, T + 1):
+            ests.append(oracle(observations={k: v[t] for k, v in obs.items()}, controls=traj["controls"][t]))
+        dt = time.perf_counter() - t0
+    want = torch.stack(ests)
+    dev = next(engine_filter.parameters()).device
+    got = evaluation.run_filter(engine_filter, to_device(traj, dev)).cpu()
+    scale = max(1.0, float(want.abs().max()))
+    parity = {"max_rel_err_posterior_mean": float((got - want).abs().max()) / scale}
+    return {"value": sample_batch * sample_steps / dt, "unit": "trajectory-steps/s", "cores": cores,
+            "kind": "port",
+            "sample": f"oracle EKF (oracle/), {wl['cls']}, batch {sample_batch} x {sample_steps} steps "
+                      f"after {warm} warm-up, {dt:.1f} s"}, parity
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--workload", default="door_pf", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU")
+    ap.add_argument("--particles", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    args = ap.parse_args()
+
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import _abi, distributed, engine, evaluation, synthetic
+
+    _abi.load()  # fail loudly before touching the GPU if the HIP library is missing
+    rank, world, local = distributed.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["batch"] = args.batch
+    if args.particles:
+        wl["particles"] = args.particles
+    K, W, B, M = args.steps, args.warmup, wl["batch"], wl["particles"]
+    spec = mmf.door_models._ns.task if wl["task"] == "door" else mmf.push_models._ns.task
+    d = spec.state_dim
+
+    f = build_filter(wl, device)
+    # rank-private trajectories (weak scaling): seed 20201025 + config id + rank
+    traj_w_cpu, traj_w = make_inputs(wl, W, B, 20201025 + 1000 * rank + 1, device, d)
+    traj_cpu, traj = make_inputs(wl, K, B, 20201025 + 1000 * rank + 2, device, d)
+
+    if wl["kind"] == "pf":
+        f.num_particles = M
+        # non-degenerate weights (ESS/M ~ 0.25): flat log-likelihoods would make resampling trivial
+        cal_states = traj["states"][0][:, None, :] + 0.3 * torch.randn((B, 256, d), device=device)
+        synthetic.calibrate_measurement_heads(
+            f, {k: traj[k][0] for k in ("image", "gripper_pos", "gripper_sensors")}, cal_states)
+        noise_w = synthetic.draw_filter_noise(T=W, N=B, M=M, state_dim=d, seed=77 + rank)
+        noise = synthetic.draw_filter_noise(T=K, N=B, M=M, state_dim=d, seed=78 + rank)
+        mv = lambda nz: (nz[0].to(device), [e.to(device) for e in nz[1]], [u.to(device) for u in nz[2]])
+        noise_w, noise = mv(noise_w), mv(noise)
+        run = lambda tr, nz: run_pf(f, tr, nz, M)
+    else:
+        noise_w = noise = None
+        run = lambda tr, nz: evaluation.run_filter(f, tr)
+
+    # ---- warm-up (untimed): W steps
+    if W > 0:
+        run(traj_w, noise_w)
+    torch.cuda.synchronize()
+
+    # ---- timed region: exactly K steps
+    timer = None if args.no_kernel_timers else engine.KernelTimer()
+    engine.set_kernel_timer(timer)
+    distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pred = run(traj, noise)
+    mse_local = evaluation.per_trajectory_mse(pred, traj["states"][1:], start=min(30, K // 2))
+    mse_all = distributed.all_gather_rows(mse_local)  # RCCL all-gather of per-sequence errors
+    torch.cuda.synchronize()
+    distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    engine.set_kernel_timer(None)
+    elapsed = distributed.max_over_ranks(elapsed, device)
+
+    units_per_step = B * M * world if wl["kind"] == "pf" else B * world
+    value = units_per_step * K / elapsed
+    rmse = evaluation.raw_rmse(mse_all)
+
+    if rank != 0:
+        return
+    out = {
+        "metric": "filter steps/sec (batch x particles)" if wl["kind"] == "pf" else "filter steps/sec (trajectories)",
+        "value": value,
+        "unit": "particle-steps/s" if wl["kind"] == "pf" else "trajectory-steps/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl["desc"], "filter": wl["cls"], "batch_per_gpu": B, "particles": M,
+                   "global_batch": B * world, "state_dim": d, "resample": "systematic",
+                   "parallelism": f"trajectory-sharded x{world}"},
+        "posterior_rmse_vs_truth": [float(x) for x in rmse],
+    }
+
+    if timer is not None:
+        ks = timer.summary()
+        out["kernels"] = {k: {kk: (round(vv, 6) if isinstance(vv, float) else vv) for kk, vv in v.items()}
+                          for k, v in ks.items()}
+        if wl["kind"] == "pf" and "particle_net_measure" in ks:
+            dom = ks["particle_net_measure"]
+            ach = dom["flops_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "particle_net_kernel<measure>", "bound": "mfma",
+                               "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None}
+            k1 = ks.get("pf_reweight_resample")
+            if k1:
+                gbs = k1["bytes_per_launch"] / (k1["avg_ms"] * 1e-3) / 1e9
+                out["roofline_k1"] = {"kernel": "pf_reweight_resample_kernel", "bound": "hbm",
+                                      "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": gbs / HBM_PEAK_GBS, "traffic": None}
+    if "roofline" not in out:
+        out["roofline"] = None
+
+    if world == 1 and not args.no_cpu_baseline:
+        cores = os.cpu_count() or 1
+        if wl["kind"] == "pf":
+            base, parity = cpu_baseline_pf(wl, f, d, cores)
+        else:
+            base, parity = cpu_baseline_ekf(wl, f, d, cores)
+        out["cpu_baseline"] = base
+        out["parity_vs_oracle"] = parity
+        out["speedup_vs_cpu_baseline"] = value / base["value"]
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,176 @@
+/*
+ * mmf.h -- C ABI of libmmf_hip.so, the MI355X (gfx950) filter hot path.
+ *
+ * Drop-in boundary for brentyi/multimodalfilter's batched filter recursions.  The
+ * reference is pure Python; the interface each entry point replaces is the sequence of
+ * stock torch ops at the cited lines (reference paths are relative to
+ * /root/reference/).  The reference-side binding is a ctypes
+ * stub; multimodalfilter_amd/_abi.py is that stub in this repo.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer valid on the current HIP device unless marked
+ *     "host"; arrays are contiguous fp32 unless stated; N = trajectories, M = particles
+ *     per trajectory, d = state_dim (1..4), rows R = N*M
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work
+ *   - return value: 0 on success, a hipError_t (>0) from the runtime, or a negative
+ *     MMF_E* code for argument errors; no allocation, no global state, re-entrant per
+ *     stream; the caller owns every buffer
+ *   - nothing here has a CPU fallback: without a GPU the launch fails with a hipError_t
+ */
+#ifndef MMF_H
+#define MMF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMF_ABI_VERSION 1
+
+#define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
+#define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
+
+#define MMF_UNITS 64         /* hidden width of every per-particle layer (layers.py: units=64) */
+#define MMF_MAX_RES 3        /* residual blocks after the join layer (LDS: 3 -> 149.5 KiB) */
+#define MMF_MAX_STATE_DIM 4
+
+int mmf_version(void);
+
+/* ---------------------------------------------------------------- K1: reweight + resample
+ * Replaces the post-measurement half of torchfilter.ParticleFilter.forward (external
+ * dependency; call sites crossmodal/eval_helpers.py:139-142):
+ *     logw += loglik; logw -= logsumexp(logw); estimate = sum exp(logw) x;
+ *     indices ~ resample(logw); states = gather(states, indices); logw = -log(M_out)
+ * as ONE kernel, one workgroup per trajectory: wave-shuffle max/sum reductions, an
+ * integer (fixed-point, 2^-24 of the row max) CDF built by an LDS-staged block scan, then
+ * systematic (mode 1) or multinomial (mode 2) selection by binary search in LDS.  The
+ * integer CDF makes the indices independent of the scan order: bit-exact against
+ * oracle/resample.py.
+ *
+ *  loglik      (N, M)          measurement log-likelihoods
+ *  logw_in     (N, M)          current log-weights
+ *  states_in   (N, M, d)
+ *  u           mode 1: (N) uniforms in [0,1); mode 2: (N, M_out); mode 0: ignored (may be null)
+ *  estimate    (N, d)          weighted-mean state estimate (always written)
+ *  states_out  (N, M_out, d)   mode 1/2: resampled particles; must NOT alias states_in.
+ *                              mode 0: may be null or alias states_in (no copy when it does)
+ *  logw_out    (N, M_out)      mode 0: normalised log-weights (may alias logw_in);
+ *                              mode 1/2: -log(M_out) (may alias logw_in when M_out == M)
+ *  indices_out (N, M_out) int32 ancestor indices, or null
+ *  mode        0 none, 1 systematic, 2 multinomial
+ * Limits: d <= 4; M, M_out <= 65536; modes 1/2 keep the 8-byte CDF in LDS: M <= 16384.
+ */
+int mmf_pf_reweight_resample(const float* loglik, const float* logw_in, const float* states_in,
+                             const float* u, float* estimate, float* states_out,
+                             float* logw_out, int32_t* indices_out, int N, int M, int M_out,
+                             int d, int mode, void* stream);
+
+/* Dynamic LDS bytes K1 will request for (M, mode) -- for occupancy planning / tests. */
+size_t mmf_pf_reweight_resample_lds_bytes(int M, int mode);
+
+/* ---------------------------------------------------------------- K2: per-particle networks
+ * The reference evaluates its dynamics and measurement MLPs as ~20 stock nn.Linear launches
+ * over R = N*M rows, materialising (R, 64) activations after every layer and repeating the
+ * control / observation features per particle (crossmodal/door_models/dynamics.py:102-134,
+ * door_models/pf.py:63-107, push mirrors).  Both networks share one shape:
+ *
+ *   enc  : Linear(d -> 64), ReLU, ResLinear(64)                (layers.py:11-24)
+ *   join : Linear(64*(1+k) -> 64) on cat(per-trajectory features, enc)  [+ ReLU for the
+ *          measurement model]; the per-trajectory half is hoisted: the caller passes
+ *          traj_bias (N, 64) = W[:, traj cols] @ traj_features + b
+ *   res  : n_res x ResLinear(64)                               (3 dynamics, 2 measurement)
+ *   head : Linear(64 -> n_out)                                 (d+1 dynamics, 1 measurement)
+ *
+ * The kernels keep every activation in registers: a wave owns 64 particles as the N
+ * (lane) dimension of v_mfma_f32_32x32x2_f32 tiles, the accumulator tile of one layer is
+ * the B operand of the next with no data movement, and a network's weights (<= 149 KiB,
+ * fragment-ordered by mmf_pack_particle_net) live in LDS for the whole launch.
+ */
+typedef struct MmfParticleNetDesc {
+  int32_t d_in;             /* state_dim: 1..4                                            */
+  int32_t n_res;            /* residual blocks after the join layer: 0..MMF_MAX_RES       */
+  int32_t relu_after_join;  /* 0 dynamics (dynamics.py:29-35), 1 measurement (pf.py:54-55) */
+  int32_t n_out;            /* head width: 1..MMF_MAX_STATE_DIM+1                         */
+  int32_t join_in;          /* row length of w_join (128, 192 or 256)                     */
+  int32_t join_state_off;   /* first column of the state-feature block inside w_join      */
+  const float* w_in;        /* (64, d_in)   enc Linear                                    */
+  const float* b_in;        /* (64)                                                       */
+  const float* w_enc[2];    /* (64, 64) x2  enc ResLinear block1, block2                  */
+  const float* b_enc[2];    /* (64) x2                                                    */
+  const float* w_join;      /* (64, join_in); only columns [off, off+64) are packed       */
+  const float* w_res[2 * MMF_MAX_RES]; /* (64,64): block1, block2 of each residual block  */
+  const float* b_res[2 * MMF_MAX_RES];
+  const float* w_head;      /* (n_out, 64)                                                */
+  const float* b_head;      /* (n_out)                                                    */
+} MmfParticleNetDesc;       /* host struct holding device pointers (torch Linear layout)  */
+
+/* Number of floats of a packed network blob with `n_res` residual blocks. */
+size_t mmf_particle_net_floats(int n_res);
+
+/* Re-order a network's weights into MFMA-fragment order (device -> device). */
+int mmf_pack_particle_net(const MmfParticleNetDesc* desc /* host */, float* packed, void* stream);
+
+/* x' = x + dir(x) * sigmoid(gate(x)) + L eps      (dynamics.py:102-134 + the reparameterised
+ * MultivariateNormal(loc, scale_tril).rsample() of torchfilter's PF step)
+ *  packed      blob from mmf_pack_particle_net (n_out must be d+1)
+ *  states_in   (N*M, d)
+ *  traj_bias   (N, 64)      hoisted control half of shared_layers[0] (+ its bias)
+ *  noise       (N*M, d) standard normal, or null (EKF predict / open-loop rollouts)
+ *  scale_tril  (d, d) row-major lower-triangular, shared by all rows (ignored if noise null)
+ *  states_out  (N*M, d)     may alias states_in
+ */
+int mmf_pf_dynamics(const float* packed, int n_res, const float* states_in,
+                    const float* traj_bias, const float* noise, const float* scale_tril,
+                    float* states_out, int N, int M, int d, void* stream);
+
+/* One modality's log-likelihood and its crossmodal combination
+ * (pf.py:63-107 + base_models/crossmodal_pf.py:106-139):
+ *      ll = net(x) + (modality_logw ? modality_logw[n * logw_stride] : 0)
+ *      combine 0: loglik = ll          combine 1: loglik = log(exp(loglik) + exp(ll))
+ * Calling it once per enabled modality with combine = 0, 1, 1, ... gives
+ * logsumexp_k(log beta_k + ll_k).
+ *  states (N*M, d); traj_bias (N, 64); loglik (N*M) in/out
+ */
+int mmf_pf_measure(const float* packed, int n_res, const float* states, const float* traj_bias,
+                   const float* modality_logw, int logw_stride, float* loglik, int combine,
+                   int N, int M, int d, void* stream);
+
+/* Forward-mode Jacobian of the dynamics network (replaces torchfilter's default autograd
+ * DynamicsModel.jacobian: batch replicated d times + one autograd.grad):
+ *  states_in (N, d), traj_bias (N, 64) -> states_out (N, d), jac (N, d, d), jac[n][i][j] = d x'_i / d x_j
+ */
+int mmf_dynamics_jacobian(const float* packed, int n_res, const float* states_in,
+                          const float* traj_bias, float* states_out, float* jac, int N, int d,
+                          void* stream);
+
+/* ---------------------------------------------------------------- K3: EKF algebra + fusion
+ * Replaces torchfilter's EKF predict/update (A S A^T + L L^T; K = S-(S- + R)^-1;
+ * mu = mu- + K(z - mu-); S = (I-K)S-) for K sub-filters and the reference's
+ * fusion of their beliefs: crossmodal (base_models/crossmodal_kf.py:153-167 via
+ * utility.py:4-11) or unimodal information form (base_models/unimodal_kf.py:204-242).
+ * One trajectory per lane, all d x d algebra in registers.
+ *
+ *  A        (K, N, d, d)  dynamics Jacobians
+ *  mu_pred  (K, N, d)     predicted means
+ *  q_tril   (K, d, d)     dynamics noise scale_tril per sub-filter (Q = L L^T)
+ *  z        (K, N, d)     virtual-sensor observations
+ *  r_tril   (K, N, d, d)  virtual-sensor scale matrices (R = T T^T; need not be triangular)
+ *  fuse_w   (K, N, d)     crossmodal weights (fusion 1) or null
+ *  mu       (K, N, d)     out: corrected sub-filter means
+ *  Sigma    (K, N, d, d)  in: previous covariances; out: corrected covariances
+ *  mu_f     (N, d), Sigma_f (N, d, d)  fused belief (fusion != 0), else may be null
+ *  fusion   0 none, 1 crossmodal, 2 unimodal
+ *  feedback 0: sub-filters keep their own beliefs (the reference's effective behaviour,
+ *           SURVEY.md appendix C Q1); 1: fused belief is written back into every sub-filter
+ */
+int mmf_ekf_step(const float* A, const float* mu_pred, const float* q_tril, const float* z,
+                 const float* r_tril, const float* fuse_w, float* mu, float* Sigma,
+                 float* mu_f, float* Sigma_f, int N, int d, int K, int fusion, int feedback,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMF_H */

@@ -1,0 +1,151 @@
+"""ctypes binding of ``libmmf_hip.so`` (the C ABI declared in ``include/mmf.h``).
+
+This is the thin layer the product path goes through: tensors stay ``torch.Tensor`` (device
+memory + stream plumbing), the arithmetic is the hand-written HIP behind these entry
+points.  There is deliberately no fallback: if the library is missing, or a launch fails,
+the call raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_float, c_int, c_int32, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmf_hip.so")
+
+MMF_UNITS = 64
+MMF_MAX_RES = 3
+MMF_MAX_STATE_DIM = 4
+ABI_VERSION = 1
+
+_FP = c_void_p  # device pointers travel as integers
+
+
+class MmfParticleNetDesc(Structure):
+    _fields_ = [
+        ("d_in", c_int32), ("n_res", c_int32), ("relu_after_join", c_int32), ("n_out", c_int32),
+        ("join_in", c_int32), ("join_state_off", c_int32),
+        ("w_in", _FP), ("b_in", _FP),
+        ("w_enc", _FP * 2), ("b_enc", _FP * 2),
+        ("w_join", _FP),
+        ("w_res", _FP * (2 * MMF_MAX_RES)), ("b_res", _FP * (2 * MMF_MAX_RES)),
+        ("w_head", _FP), ("b_head", _FP),
+    ]
+
+
+SIGNATURES = {
+    "mmf_version": (c_int, []),
+    "mmf_pf_reweight_resample": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP,
+                                         c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmf_pf_reweight_resample_lds_bytes": (c_size_t, [c_int, c_int]),
+    "mmf_particle_net_floats": (c_size_t, [c_int]),
+    "mmf_pack_particle_net": (c_int, [POINTER(MmfParticleNetDesc), _FP, c_void_p]),
+    "mmf_pf_dynamics": (c_int, [_FP, c_int, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
+    "mmf_pf_measure": (c_int, [_FP, c_int, _FP, _FP, _FP, c_int, _FP, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmf_dynamics_jacobian": (c_int, [_FP, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
+    "mmf_ekf_step": (c_int, [_FP] * 10 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+class MmfError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MmfError(
+                f"{LIB_PATH} is missing: build it with `python -m multimodalfilter_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        got = lib.mmf_version()
+        if got != ABI_VERSION:
+            raise MmfError(f"ABI mismatch: library {got}, binding {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def _check(code: int, what: str):
+    if code != 0:
+        kind = "argument error" if code < 0 else "hipError_t"
+        raise MmfError(f"{what} failed: {kind} {code}")
+
+
+def ptr(t: torch.Tensor, *, dtype=torch.float32):
+    """Device pointer of a contiguous CUDA/HIP tensor (``None`` -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MmfError("libmmf_hip works on device memory only (got a CPU tensor); no CPU fallback")
+    if t.dtype != dtype:
+        raise MmfError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise MmfError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream_of(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+# ------------------------------------------------------------------ typed wrappers
+def pf_reweight_resample(loglik, logw_in, states_in, u, estimate, states_out, logw_out,
+                         indices_out, mode: int):
+    N, M, d = states_in.shape
+    M_out = logw_out.shape[1]
+    assert loglik.shape == (N, M) and logw_in.shape == (N, M) and estimate.shape == (N, d)
+    with torch.cuda.device(states_in.device):
+        _check(load().mmf_pf_reweight_resample(
+            ptr(loglik), ptr(logw_in), ptr(states_in), ptr(u), ptr(estimate), ptr(states_out),
+            ptr(logw_out), ptr(indices_out, dtype=torch.int32), N, M, M_out, d, mode,
+            stream_of(states_in)), "mmf_pf_reweight_resample")
+
+
+def particle_net_floats(n_res: int) -> int:
+    return int(load().mmf_particle_net_floats(n_res))
+
+
+def pack_particle_net(desc: MmfParticleNetDesc, packed: torch.Tensor):
+    with torch.cuda.device(packed.device):
+        _check(load().mmf_pack_particle_net(ctypes.byref(desc), ptr(packed), stream_of(packed)),
+               "mmf_pack_particle_net")
+
+
+def pf_dynamics(packed, n_res, states_in, traj_bias, noise, scale_tril, states_out, N, M, d):
+    with torch.cuda.device(states_in.device):
+        _check(load().mmf_pf_dynamics(ptr(packed), n_res, ptr(states_in), ptr(traj_bias), ptr(noise),
+                                      ptr(scale_tril), ptr(states_out), N, M, d,
+                                      stream_of(states_in)), "mmf_pf_dynamics")
+
+
+def pf_measure(packed, n_res, states, traj_bias, modality_logw, logw_stride, loglik, combine, N, M, d):
+    with torch.cuda.device(states.device):
+        _check(load().mmf_pf_measure(ptr(packed), n_res, ptr(states), ptr(traj_bias),
+                                     ptr(modality_logw), logw_stride, ptr(loglik), int(combine),
+                                     N, M, d, stream_of(states)), "mmf_pf_measure")
+
+
+def dynamics_jacobian(packed, n_res, states_in, traj_bias, states_out, jac, N, d):
+    with torch.cuda.device(states_in.device):
+        _check(load().mmf_dynamics_jacobian(ptr(packed), n_res, ptr(states_in), ptr(traj_bias),
+                                            ptr(states_out), ptr(jac), N, d,
+                                            stream_of(states_in)), "mmf_dynamics_jacobian")
+
+
+def ekf_step(A, mu_pred, q_tril, z, r_tril, fuse_w, mu, Sigma, mu_f, Sigma_f, fusion: int,
+             feedback: int):
+    K, N, d = mu_pred.shape
+    with torch.cuda.device(mu_pred.device):
+        _check(load().mmf_ekf_step(ptr(A), ptr(mu_pred), ptr(q_tril), ptr(z), ptr(r_tril),
+                                   ptr(fuse_w), ptr(mu), ptr(Sigma), ptr(mu_f), ptr(Sigma_f),
+                                   N, d, K, fusion, feedback, stream_of(mu_pred)), "mmf_ekf_step")

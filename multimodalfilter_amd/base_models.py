@@ -1,0 +1,391 @@
+"""Multimodal fusion classes -- the API of ``/root/reference/crossmodal/base_models`` with the
+fusion arithmetic in HIP.
+
+* ``CrossmodalParticleFilterMeasurementModel`` (``base_models/crossmodal_pf.py:33-141``):
+  ``logsumexp_k(log beta_k + ll_k)`` is folded into the epilogue of the measurement kernel
+  (``mmf_pf_measure`` with ``combine``), so no ``(N, M, K)`` tensor is ever materialised.
+* ``CrossmodalKalmanFilter`` (``base_models/crossmodal_kf.py:39-240``) and
+  ``UnimodalKalmanFilter`` (``base_models/unimodal_kf.py:118-270``): all sub-filters'
+  predict / correct steps *and* the fusion of their beliefs are ONE ``mmf_ekf_step`` launch.
+* ``CrossmodalVirtualSensorModel`` / ``UnimodalVirtualSensorModel``
+  (``crossmodal_kf.py:243-359``, ``unimodal_kf.py:13-115``): per-trajectory (N rows) and
+  off the per-particle path; evaluated with device-side torch ops.
+
+Reference quirks that change numbers are preserved and flag-gated.
+"""
+import abc
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _abi, base, filters
+from .engine import require_device
+from .utils import tree_index, tree_leading_shape, tree_map
+
+
+def _check_mask(mask, n):
+    assert isinstance(mask, list)
+    assert len(mask) == n
+    for x in mask:
+        assert type(x) == bool
+
+
+class _EnabledModels:
+    @property
+    def enabled_models(self) -> List[bool]:
+        return self._enabled_models
+
+    @enabled_models.setter
+    def enabled_models(self, enabled_models: List[bool]) -> None:
+        _check_mask(enabled_models, self._num_models())
+        self._enabled_models = enabled_models
+
+
+def weighted_average(predictions: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+    """``base_models/utility.py:4-11``."""
+    assert predictions.shape == weights.shape
+    weights = weights / (torch.sum(weights, dim=0) + 1e-9)
+    return torch.sum(weights * predictions, dim=0)
+
+
+# ===================================================================== particle filter side
+class CrossmodalWeightModel(nn.Module, abc.ABC):
+    """``forward(*, observations) -> (N, modality_count)`` log-weights."""
+
+    def __init__(self, modality_count: int):
+        super().__init__()
+        self.modality_count = modality_count
+
+    @abc.abstractmethod
+    def forward(self, *, observations) -> torch.Tensor:
+        ...
+
+
+class CrossmodalParticleFilterMeasurementModel(base.ParticleFilterMeasurementModel, _EnabledModels):
+    def __init__(self, *, measurement_models: List[base.ParticleFilterMeasurementModel],
+                 crossmodal_weight_model: Optional[CrossmodalWeightModel], state_dim: int):
+        super().__init__(state_dim=state_dim)
+        self.measurement_models = nn.ModuleList(measurement_models)
+        self.crossmodal_weight_model = crossmodal_weight_model
+        self._enabled_models: List[bool] = [True for _ in self.measurement_models]
+
+    def _num_models(self):
+        return len(self.measurement_models)
+
+    def _fusable(self) -> bool:
+        return all(hasattr(m, "forward_encoded") for m in self.measurement_models)
+
+    def encode_observations(self, observations):
+        """Everything that depends on the observation only: each unimodal model's hoisted
+        join-layer bias and the modality log-weights."""
+        ctx = {}
+        for i, m in enumerate(self.measurement_models):
+            if self._enabled_models[i]:
+                for k, v in m.encode_observations(observations).items():
+                    ctx[f"m{i}.{k}"] = v
+        if self.crossmodal_weight_model is not None:
+            ctx["modality_log_weights"] = self.crossmodal_weight_model(
+                observations=observations).to(torch.float32).contiguous()
+        return ctx
+
+    def forward_encoded(self, states: torch.Tensor, ctx) -> torch.Tensor:
+        N, M, _ = states.shape
+        loglik = torch.empty((N, M), dtype=torch.float32, device=states.device)
+        beta = ctx.get("modality_log_weights")
+        K = self._num_models()
+        first = True
+        for i, m in enumerate(self.measurement_models):
+            if not self._enabled_models[i]:
+                continue
+            sub = {k[len(f"m{i}."):]: v for k, v in ctx.items() if k.startswith(f"m{i}.")}
+            m.forward_encoded(states, sub, loglik=loglik, combine=not first,
+                              modality_logw=None if beta is None else beta.view(-1)[i:],
+                              logw_stride=K)
+            first = False
+        assert not first, "no measurement model enabled"
+        return loglik
+
+    def forward(self, *, states, observations):
+        N, M, _state_dim = states.shape
+        if self._fusable():
+            with torch.no_grad():
+                return self.forward_encoded(states.contiguous(), self.encode_observations(observations))
+        # user-supplied unimodal models: stock formulation (crossmodal_pf.py:106-139)
+        ll = torch.stack(
+            [m(states=states, observations=observations)
+             for i, m in enumerate(self.measurement_models) if self._enabled_models[i]], dim=2)
+        assert ll.shape == (N, M, np.sum(self._enabled_models))
+        if self.crossmodal_weight_model is not None:
+            beta = self.crossmodal_weight_model(observations=observations)[:, self._enabled_models]
+            assert beta.shape == (N, np.sum(self._enabled_models))
+            ll = ll + beta[:, None, :]
+        return torch.logsumexp(ll, dim=2)
+
+
+# ===================================================================== Kalman filter side
+class CrossmodalKalmanFilterWeightModel(nn.Module, abc.ABC):
+    """``forward(*, observations) -> (modality_count, N, state_dim)`` weights."""
+
+    def __init__(self, modality_count: int, state_dim: int):
+        super().__init__()
+        self.modality_count = modality_count
+        self.state_dim = state_dim
+
+    @abc.abstractmethod
+    def forward(self, *, observations) -> torch.Tensor:
+        ...
+
+
+class _FusedKalmanFilters(base.Filter, _EnabledModels):
+    """Shared machinery: K virtual-sensor EKFs stepped and fused by one K3 launch."""
+
+    def __init__(self, *, filter_models: List[filters.VirtualSensorExtendedKalmanFilter],
+                 state_dim: int):
+        super().__init__(state_dim=state_dim)
+        self.filter_models = nn.ModuleList(filter_models)
+        self._enabled_models: List[bool] = [True for _ in self.filter_models]
+        self.weighted_covariances = None
+
+    def _num_models(self):
+        return len(self.filter_models)
+
+    @property
+    def state_covariance_estimate(self):
+        return self.weighted_covariances
+
+    def initialize_beliefs(self, *, mean: torch.Tensor, covariance: torch.Tensor):
+        N = mean.shape[0]
+        assert mean.shape == (N, self.state_dim)
+        assert covariance.shape == (N, self.state_dim, self.state_dim)
+        for model in self.filter_models:
+            model.initialize_beliefs(mean=mean, covariance=covariance)
+
+    def _live(self):
+        return [f for i, f in enumerate(self.filter_models) if self._enabled_models[i]]
+
+    def _encode_loop_inputs(self, observations, controls):
+        """Belief-independent work for a whole ``forward_loop``: virtual sensors, control
+        encoders (and, in subclasses, fusion weights) over all ``T*N`` rows."""
+        T, N = tree_leading_shape(controls)[:2]
+        flat = lambda t: t.reshape((T * N,) + tuple(t.shape[2:]))
+        obs_f, ctrl_f = tree_map(observations, flat), tree_map(controls, flat)
+        pre = {"sensor": [], "ctrl": []}
+        for f in self.filter_models:
+            pre["sensor"].append(f.virtual_sensor_model(observations=obs_f))
+            pre["ctrl"].append(f.dynamics_model.encode_controls(ctrl_f)
+                               if hasattr(f.dynamics_model, "predict_with_jacobian") else None)
+        return pre, obs_f
+
+    def _fused_step(self, observations, controls, *, fusion: int, fuse_w, feedback: int, pre=None):
+        """Run every enabled sub-filter's predict + correct and the fusion in one launch.
+        Returns ``(mu_fused, Sigma_fused)`` (``None`` for ``fusion == 0``)."""
+        live_idx = [i for i, on in enumerate(self._enabled_models) if on]
+        live = [self.filter_models[i] for i in live_idx]
+        A, mu_pred, L, z, r = [], [], [], [], []
+        for i, f in zip(live_idx, live):
+            assert f._initialized, "Kalman filter not initialized!"
+            sens = pre["sensor"][i] if pre is not None else f.virtual_sensor_model(observations=observations)
+            mp, Ak, Lk = f._predict_pieces(controls, pre["ctrl"][i] if pre is not None else None)
+            A.append(Ak); mu_pred.append(mp); L.append(Lk)
+            z.append(sens[0].to(torch.float32)); r.append(sens[1].to(torch.float32))
+        K = len(live)
+        N, d = mu_pred[0].shape
+        dev = mu_pred[0].device
+        mu = torch.empty((K, N, d), dtype=torch.float32, device=dev)
+        Sigma = torch.stack([f._belief_covariance for f in live]).contiguous()
+        mu_f = Sigma_f = None
+        if fusion:
+            mu_f = torch.empty((N, d), dtype=torch.float32, device=dev)
+            Sigma_f = torch.empty((N, d, d), dtype=torch.float32, device=dev)
+        _abi.ekf_step(torch.stack(A).contiguous(), torch.stack(mu_pred).contiguous(),
+                      torch.stack(L).contiguous(), torch.stack(z).contiguous(),
+                      torch.stack(r).contiguous(),
+                      None if fuse_w is None else fuse_w.to(torch.float32).contiguous(),
+                      mu, Sigma, mu_f, Sigma_f, fusion=fusion, feedback=feedback)
+        for k, f in enumerate(live):
+            f._belief_mean, f._belief_covariance = mu[k], Sigma[k]
+        return mu_f, Sigma_f, mu, Sigma
+
+    def forward_loop(self, *, observations, controls):
+        T, N = tree_leading_shape(controls)[:2]
+        with torch.no_grad():
+            pre_all, obs_f = self._encode_loop_inputs(observations, controls)
+            extra_all = self._encode_loop_extra(obs_f)
+        out = []
+        for t in range(T):
+            sl = slice(t * N, (t + 1) * N)
+            pre = {"sensor": [(s[0][sl], s[1][sl]) for s in pre_all["sensor"]],
+                   "ctrl": [None if c is None else {k: v[sl] for k, v in c.items()} for c in pre_all["ctrl"]]}
+            extra = None if extra_all is None else self._slice_extra(extra_all, t, N)
+            out.append(self._forward_pre(tree_index(observations, t), tree_index(controls, t), pre, extra))
+        return torch.stack(out, dim=0)
+
+    def _encode_loop_extra(self, obs_flat):
+        return None
+
+    def _slice_extra(self, extra, t, N):
+        return extra
+
+
+class CrossmodalKalmanFilter(_FusedKalmanFilters):
+    """Learned-weight fusion of unimodal EKFs (``base_models/crossmodal_kf.py:39-240``):
+    ``mu = sum_k w_k mu_k / (sum_k w_k + 1e-9)``, ``Sigma = sum_k (w_k w_k^T) (.) Sigma_k``.
+
+    ``feedback``: the reference assigns the fused belief to ``f.states_prev`` /
+    ``f.states_covariance_prev`` (``:147-149``) while its sub-filters keep their belief in
+    ``_belief_mean`` / ``_belief_covariance`` (``:180``), so that write never reaches them
+    (SURVEY.md appendix C, Q1).  ``"none"`` (default) reproduces this; ``"belief"`` does the
+    write-back the code intends.
+    """
+
+    def __init__(self, *, filter_models, crossmodal_weight_model: CrossmodalKalmanFilterWeightModel,
+                 state_dim: int, feedback: str = "none"):
+        super().__init__(filter_models=filter_models, state_dim=state_dim)
+        self.crossmodal_weight_model = crossmodal_weight_model
+        assert feedback in ("none", "belief")
+        self.feedback = feedback
+
+    def _state_weights(self, observations, N, device, raw=None):
+        on = self._enabled_models
+        if np.sum(on) < len(on):
+            w = torch.tensor(on, dtype=torch.float32, device=device)
+            w = w[:, None, None].repeat(1, N, self.state_dim)
+        else:
+            w = raw if raw is not None else self.crossmodal_weight_model(observations=observations)
+        w = w[on]
+        assert w.shape == (np.sum(on), N, self.state_dim)
+        return w
+
+    def _encode_loop_extra(self, obs_flat):
+        # Q3: the reference's weight model mixes batch and feature axes, so it must see
+        # exactly the per-step batch; it is therefore evaluated per step, not over T*N rows.
+        return None
+
+    def _forward_pre(self, observations, controls, pre, extra):
+        N = tree_leading_shape(controls)[0]
+        with torch.no_grad():
+            dev = self.filter_models[0]._belief_mean.device
+            w = self._state_weights(observations, N, dev)
+            fb = 1 if self.feedback == "belief" else 0
+            mu_f, Sigma_f, _, _ = self._fused_step(observations, controls, fusion=1, fuse_w=w,
+                                                   feedback=fb, pre=pre)
+            self.weighted_covariances = Sigma_f
+            for f in self.filter_models:  # inert attributes, exactly as the reference sets them
+                f.states_prev = mu_f
+                f.states_covariance_prev = Sigma_f
+        return mu_f
+
+    def forward(self, *, observations, controls):
+        N, _ = controls.shape
+        return self._forward_pre(observations, controls, None, None)
+
+    # kept for API parity with the reference (``crossmodal_kf.py:153-186``)
+    def calculate_weighted_states(self, state_weights, unimodal_states, unimodal_covariances):
+        model_dim, N, state_dim = state_weights.shape
+        assert state_dim == self.state_dim
+        mu = weighted_average(unimodal_states, state_weights)
+        cw = state_weights.unsqueeze(-1).repeat((1, 1, 1, self.state_dim))
+        cw = cw * cw.transpose(-1, -2)
+        return mu, torch.sum(cw * unimodal_covariances, 0)
+
+    def calculate_unimodal_states(self, observations, controls):
+        _, _, mu, Sigma = self._fused_step(observations, controls, fusion=0, fuse_w=None, feedback=0)
+        return mu, Sigma
+
+    def measurement_initialize_beliefs(self, observations):
+        """``crossmodal_kf.py:208-240`` (per trajectory, off the hot path)."""
+        on = self._enabled_models
+        outs = [f.virtual_sensor_model(observations=observations)
+                for i, f in enumerate(self.filter_models) if on[i]]
+        means = torch.stack([x[0] for x in outs])
+        trils = torch.stack([x[1] for x in outs])
+        covs = trils @ trils.transpose(-1, -2)
+        w = self.crossmodal_weight_model(observations=observations)[on]
+        mu = weighted_average(means, w)
+        mult = torch.prod(torch.prod(w, dim=-1), dim=0).unsqueeze(-1).unsqueeze(-1)
+        self.initialize_beliefs(mean=mu, covariance=mult * torch.sum(covs, dim=0))
+
+
+class UnimodalKalmanFilter(_FusedKalmanFilters):
+    """Information-form fusion (``base_models/unimodal_kf.py:118-270``):
+    ``Sigma = (sum_k (Sigma_k + 1e-9)^-1 + 1e-9)^-1``, ``mu = Sigma sum_k P_k mu_k``.
+    As in the reference the fused belief is returned but never fed back (Q6)."""
+
+    def __init__(self, *, filter_models, state_dim: int):
+        super().__init__(filter_models=filter_models, state_dim=state_dim)
+
+    def _forward_pre(self, observations, controls, pre, extra):
+        with torch.no_grad():
+            if np.sum(self._enabled_models) == 1:
+                _, _, mu, _ = self._fused_step(observations, controls, fusion=0, fuse_w=None,
+                                               feedback=0, pre=pre)
+                return mu[0]
+            mu_f, _, _, _ = self._fused_step(observations, controls, fusion=2, fuse_w=None,
+                                             feedback=0, pre=pre)
+        return mu_f
+
+    def forward(self, *, observations, controls):
+        return self._forward_pre(observations, controls, None, None)
+
+
+# ===================================================================== fused virtual sensors
+class CrossmodalVirtualSensorModel(base.VirtualSensorModel, _EnabledModels):
+    """``base_models/crossmodal_kf.py:243-359``: fuse K virtual sensors *before* one EKF;
+    ``Sigma = (prod_k prod_i w_ki) sum_k Sigma_k``; returns a Cholesky factor."""
+
+    def __init__(self, *, virtual_sensor_model: List[base.VirtualSensorModel],
+                 crossmodal_weight_model: CrossmodalKalmanFilterWeightModel, state_dim: int):
+        super().__init__(state_dim=state_dim)
+        self.virtual_sensor_model = nn.ModuleList(virtual_sensor_model)
+        self.crossmodal_weight_model = crossmodal_weight_model
+        self._enabled_models: List[bool] = [True for _ in self.virtual_sensor_model]
+
+    def _num_models(self):
+        return len(self.virtual_sensor_model)
+
+    def forward(self, *, observations):
+        on = self._enabled_models
+        outs = [m(observations=observations) for i, m in enumerate(self.virtual_sensor_model) if on[i]]
+        means = torch.stack([x[0] for x in outs])
+        trils = torch.stack([x[1] for x in outs])
+        covs = trils @ trils.transpose(-1, -2)
+        N = means.shape[1]
+        if np.sum(on) < len(on):
+            w = torch.tensor(on, dtype=torch.float32, device=means.device)
+            w = w[:, None, None].repeat(1, N, self.state_dim)
+        else:
+            w = self.crossmodal_weight_model(observations=observations)
+        w = w[on]
+        assert w.shape == (np.sum(on), N, self.state_dim)
+        mu = weighted_average(means, w)
+        mult = torch.prod(torch.prod(w, dim=-1), dim=0).unsqueeze(-1).unsqueeze(-1)
+        assert mult.shape == (N, 1, 1)
+        return mu, torch.linalg.cholesky(mult * torch.sum(covs, dim=0))
+
+
+class UnimodalVirtualSensorModel(base.VirtualSensorModel, _EnabledModels):
+    """``base_models/unimodal_kf.py:13-115`` including its quirk Q5 (element-wise
+    ``1 / (scale_tril + 1e-9)`` used as "precision"; a covariance returned where a
+    scale-tril is expected)."""
+
+    def __init__(self, *, virtual_sensor_model: List[base.VirtualSensorModel], state_dim: int):
+        super().__init__(state_dim=state_dim)
+        self.virtual_sensor_model = nn.ModuleList(virtual_sensor_model)
+        self._enabled_models: List[bool] = [True for _ in self.virtual_sensor_model]
+
+    def _num_models(self):
+        return len(self.virtual_sensor_model)
+
+    def forward(self, *, observations):
+        on = self._enabled_models
+        outs = [m(observations=observations) for i, m in enumerate(self.virtual_sensor_model) if on[i]]
+        means = torch.stack([x[0] for x in outs])
+        trils = torch.stack([x[1] for x in outs])
+        if np.sum(on) == 1:
+            return means[0], (trils @ trils.transpose(-1, -2))[0]
+        prec = 1.0 / (trils + 1e-9)
+        w = torch.diagonal(prec, dim1=-2, dim2=-1)
+        assert w.shape == means.shape
+        return weighted_average(means, w), torch.inverse(torch.sum(prec, dim=0) + 1e-9)

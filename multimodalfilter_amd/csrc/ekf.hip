@@ -1,0 +1,285 @@
+// K3: batched small-matrix EKF predict/correct for K sub-filters + crossmodal / unimodal
+// fusion of their beliefs, one trajectory per lane, all d x d algebra in registers.
+//
+// Replaces torchfilter's ExtendedKalmanFilter._predict_step / _update_step specialised to the
+// virtual-sensor case C = I (external dependency of the reference) and
+//   /root/reference/crossmodal/base_models/crossmodal_kf.py:153-167  (crossmodal fusion)
+//   /root/reference/crossmodal/base_models/utility.py:4-11           (weighted_average)
+//   /root/reference/crossmodal/base_models/unimodal_kf.py:204-242    (information-form fusion)
+// HBM bytes per trajectory-step (K=2, d=3): 2*(A 36 + mu- 12 + z 12 + T 36 + w 12 + Sigma 36 r/w 72
+// + mu 12) + fused 48 = 432 B for ~1.5 kFLOP: launch-latency-bound in isolation.
+#include "mmf_common.h"
+
+namespace {
+
+template <int D>
+struct Mat {
+  float a[D][D];
+};
+
+template <int D>
+__device__ __forceinline__ Mat<D> load_mat(const float* p) {
+  Mat<D> m;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) m.a[i][j] = p[i * D + j];
+  return m;
+}
+
+template <int D>
+__device__ __forceinline__ void store_mat(float* p, const Mat<D>& m) {
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) p[i * D + j] = m.a[i][j];
+}
+
+template <int D>
+__device__ __forceinline__ Mat<D> matmul(const Mat<D>& x, const Mat<D>& y) {
+  Mat<D> r;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) s += x.a[i][k] * y.a[k][j];
+      r.a[i][j] = s;
+    }
+  return r;
+}
+
+template <int D>
+__device__ __forceinline__ Mat<D> matmul_nt(const Mat<D>& x, const Mat<D>& y) {  // x y^T
+  Mat<D> r;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) s += x.a[i][k] * y.a[j][k];
+      r.a[i][j] = s;
+    }
+  return r;
+}
+
+// Gauss-Jordan with partial pivoting (the pivot order LU-based torch.inverse uses); row
+// swaps are branch-free selects so every index stays compile-time and the matrix stays in
+// registers.
+template <int D>
+__device__ __forceinline__ Mat<D> inverse(Mat<D> m) {
+  Mat<D> inv;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) inv.a[i][j] = (i == j) ? 1.f : 0.f;
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+#pragma unroll
+    for (int r = c + 1; r < D; ++r) {
+      const bool sw = fabsf(m.a[r][c]) > fabsf(m.a[c][c]);
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const float t0 = m.a[c][j], t1 = m.a[r][j];
+        m.a[c][j] = sw ? t1 : t0;
+        m.a[r][j] = sw ? t0 : t1;
+        const float u0 = inv.a[c][j], u1 = inv.a[r][j];
+        inv.a[c][j] = sw ? u1 : u0;
+        inv.a[r][j] = sw ? u0 : u1;
+      }
+    }
+    const float piv = 1.0f / m.a[c][c];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      m.a[c][j] *= piv;
+      inv.a[c][j] *= piv;
+    }
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      if (r == c) continue;
+      const float f = m.a[r][c];
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        m.a[r][j] -= f * m.a[c][j];
+        inv.a[r][j] -= f * inv.a[c][j];
+      }
+    }
+  }
+  return inv;
+}
+
+constexpr int kMaxK = 4;
+
+template <int D>
+__global__ __launch_bounds__(256) void ekf_step_kernel(
+    const float* __restrict__ A, const float* __restrict__ mu_pred, const float* __restrict__ q_tril,
+    const float* __restrict__ z, const float* __restrict__ r_tril, const float* __restrict__ fuse_w,
+    float* __restrict__ mu, float* __restrict__ Sigma, float* __restrict__ mu_f,
+    float* __restrict__ Sigma_f, int N, int K, int fusion, int feedback) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+
+  float mus[kMaxK][D];
+  Mat<D> Ss[kMaxK];
+#pragma unroll
+  for (int k = 0; k < kMaxK; ++k) {
+    if (k >= K) break;
+    const size_t row = static_cast<size_t>(k) * N + n;
+    const Mat<D> Ak = load_mat<D>(A + row * D * D);
+    const Mat<D> S0 = load_mat<D>(Sigma + row * D * D);
+    const Mat<D> L = load_mat<D>(q_tril + static_cast<size_t>(k) * D * D);
+    const Mat<D> T = load_mat<D>(r_tril + row * D * D);
+    // predict: S- = A S A^T + L L^T
+    const Mat<D> AS = matmul<D>(Ak, S0);
+    Mat<D> Sp = matmul_nt<D>(AS, Ak);
+    const Mat<D> Q = matmul_nt<D>(L, L);
+    const Mat<D> Rm = matmul_nt<D>(T, T);
+    Mat<D> Sinn;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        Sp.a[i][j] += Q.a[i][j];
+        Sinn.a[i][j] = Sp.a[i][j] + Rm.a[i][j];
+      }
+    // correct (C = I): K = S- (S- + R)^-1; mu = mu- + K (z - mu-); S = (I - K) S-
+    const Mat<D> G = matmul<D>(Sp, inverse<D>(Sinn));
+    float mp[D], innov[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      mp[i] = mu_pred[row * D + i];
+      innov[i] = z[row * D + i] - mp[i];
+    }
+    Mat<D> ImG;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        s += G.a[i][j] * innov[j];
+        ImG.a[i][j] = ((i == j) ? 1.f : 0.f) - G.a[i][j];
+      }
+      mus[k][i] = mp[i] + s;
+    }
+    Ss[k] = matmul<D>(ImG, Sp);
+  }
+
+  float mf[D];
+  Mat<D> Sf;
+  if (fusion == 1) {
+    // mu_f = sum_k (w_k / (sum_k w_k + 1e-9)) mu_k ; Sigma_f = sum_k (w_k w_k^T) (.) Sigma_k
+    float w[kMaxK][D], wsum[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) wsum[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k) {
+      if (k >= K) break;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        w[k][i] = fuse_w[(static_cast<size_t>(k) * N + n) * D + i];
+        wsum[i] += w[k][i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      mf[i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < D; ++j) Sf.a[i][j] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k) {
+      if (k >= K) break;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        mf[i] += (w[k][i] / (wsum[i] + 1e-9f)) * mus[k][i];
+#pragma unroll
+        for (int j = 0; j < D; ++j) Sf.a[i][j] += (w[k][i] * w[k][j]) * Ss[k].a[i][j];
+      }
+    }
+  } else if (fusion == 2) {
+    // P_k = (Sigma_k + 1e-9)^-1 ; Sigma_f = (sum_k P_k + 1e-9)^-1 ; mu_f = Sigma_f sum_k P_k mu_k
+    Mat<D> Psum;
+    float info[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      info[i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < D; ++j) Psum.a[i][j] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k) {
+      if (k >= K) break;
+      Mat<D> t = Ss[k];
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) t.a[i][j] += 1e-9f;
+      const Mat<D> P = inverse<D>(t);
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          s += P.a[i][j] * mus[k][j];
+          Psum.a[i][j] += P.a[i][j];
+        }
+        info[i] += s;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) Psum.a[i][j] += 1e-9f;
+    Sf = inverse<D>(Psum);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < D; ++j) s += Sf.a[i][j] * info[j];
+      mf[i] = s;
+    }
+  }
+
+  if (fusion != 0) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) mu_f[static_cast<size_t>(n) * D + i] = mf[i];
+    store_mat<D>(Sigma_f + static_cast<size_t>(n) * D * D, Sf);
+  }
+#pragma unroll
+  for (int k = 0; k < kMaxK; ++k) {
+    if (k >= K) break;
+    const size_t row = static_cast<size_t>(k) * N + n;
+    const bool fb = fusion != 0 && feedback != 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) mu[row * D + i] = fb ? mf[i] : mus[k][i];
+    store_mat<D>(Sigma + row * D * D, fb ? Sf : Ss[k]);
+  }
+}
+
+}  // namespace
+
+extern "C" int mmf_ekf_step(const float* A, const float* mu_pred, const float* q_tril,
+                            const float* z, const float* r_tril, const float* fuse_w, float* mu,
+                            float* Sigma, float* mu_f, float* Sigma_f, int N, int d, int K,
+                            int fusion, int feedback, void* stream) {
+  if (!A || !mu_pred || !q_tril || !z || !r_tril || !mu || !Sigma) return MMF_EINVAL;
+  if (N < 0 || d < 1 || d > MMF_MAX_STATE_DIM || K < 1 || K > kMaxK) return MMF_EINVAL;
+  if (fusion < 0 || fusion > 2 || (fusion == 1 && !fuse_w)) return MMF_EINVAL;
+  if (fusion != 0 && (!mu_f || !Sigma_f)) return MMF_EINVAL;
+  if (N == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int block = 256, grid = (N + block - 1) / block;
+#define MMF_K3(D)                                                                               \
+  case D:                                                                                       \
+    ekf_step_kernel<D><<<grid, block, 0, s>>>(A, mu_pred, q_tril, z, r_tril, fuse_w, mu, Sigma,  \
+                                              mu_f, Sigma_f, N, K, fusion, feedback);            \
+    break;
+  switch (d) {
+    MMF_K3(1) MMF_K3(2) MMF_K3(3) MMF_K3(4)
+  }
+#undef MMF_K3
+  MMF_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,479 @@
+// K2 / K5: the per-particle networks (dynamics, measurement, forward-mode Jacobian) as
+// register-resident chains of v_mfma_f32_32x32x2_f32 tiles.
+//
+// Replaces the reference's op-per-layer evaluation over R = N*M rows:
+//   /root/reference/crossmodal/door_models/dynamics.py:102-134 (push_models/dynamics.py:34-64)
+//   /root/reference/crossmodal/door_models/pf.py:63-107        (push_models/pf.py:65-109)
+//   /root/reference/crossmodal/base_models/crossmodal_pf.py:106-139 (modality logsumexp)
+// and torchfilter's default autograd DynamicsModel.jacobian.
+//
+// Mapping.  A wave owns 32*CT particles; a particle is a COLUMN (lane & 31) of every MFMA
+// tile, the 64 hidden features are the rows.  For Y = W X (W: 64x64, X: 64 x particles)
+//   A operand = W fragment  : lane (i, h) holds W[32t + i][kmap(s, h)]      (from LDS)
+//   B operand = X           : lane (j, h) holds X[kmap(s, h)][j]            (a register)
+//   C/D       = Y tile t    : lane (j, h), reg r holds Y[32t + (r&3) + 8(r>>2) + 4h][j]
+// Choosing kmap(s, h) = 32(s>>4) + ((s&15)&3) + 8((s&15)>>2) + 4h makes register (s & 15) of
+// output tile (s >> 4) of one layer *be* the B operand of k-step s of the next layer: the whole
+// network runs without moving an activation between lanes, LDS or HBM.  Weights are packed in
+// that fragment order once (mmf_pack_particle_net) and a launch keeps one network's blob
+// (<= 149.5 KiB) in LDS; each lane fetches four k-steps of A with one ds_read_b128.
+//
+// Roofline: 2 FLOP/MAC * {37,312 dynamics | 28,928 measurement} MAC per particle against
+// ~32 B of HBM traffic => compute bound on the f32 MFMA peak (157.3 TFLOP/s); DESIGN.md.
+#include "mmf_common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kUnits = MMF_UNITS;
+constexpr int kW0Cols = 8;                    // first layer padded to K = 8 (state dims, 1, zeros)
+constexpr int kHeadRows = MMF_MAX_STATE_DIM + 1;
+constexpr int kLayerFloats = kUnits * kUnits;
+constexpr int kThreads = 512;                 // 8 waves = 2 per SIMD, one workgroup per CU (LDS)
+constexpr int kWavesPerBlock = kThreads / MMF_WAVE;
+
+__host__ __device__ constexpr int num_layers(int n_res) { return 3 + 2 * n_res; }
+__host__ __device__ constexpr int off_w0() { return 0; }
+__host__ __device__ constexpr int off_layers() { return kUnits * kW0Cols; }
+__host__ __device__ constexpr int off_bias(int n_res) { return off_layers() + num_layers(n_res) * kLayerFloats; }
+__host__ __device__ constexpr int off_whead(int n_res) { return off_bias(n_res) + num_layers(n_res) * kUnits; }
+__host__ __device__ constexpr int off_bhead(int n_res) { return off_whead(n_res) + kHeadRows * kUnits; }
+__host__ __device__ constexpr int blob_floats(int n_res) { return off_bhead(n_res) + 8; }
+
+// feature row held by accumulator register r of a 32-row tile, for lane half h
+__host__ __device__ constexpr int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ------------------------------------------------------------------------------ packing
+__global__ void pack_particle_net_kernel(MmfParticleNetDesc d, float* __restrict__ out) {
+  const int total = blob_floats(d.n_res);
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (q < off_layers()) {
+      const int row = q / kW0Cols, k = q % kW0Cols;
+      if (k < d.d_in) v = d.w_in[row * d.d_in + k];
+      else if (k == d.d_in) v = d.b_in[row];
+    } else if (q < off_bias(d.n_res)) {
+      const int rel = q - off_layers();
+      const int l = rel / kLayerFloats, e = rel % kLayerFloats;
+      const int ks = e & 3, lane = (e >> 2) & 63, s4 = (e >> 8) & 7, t = e >> 11;
+      const int s = 4 * s4 + ks, h = lane >> 5, i = lane & 31;
+      const int k = 32 * (s >> 4) + rowmap(s & 15, h);
+      const int row = 32 * t + i;
+      const float* W;
+      int stride = kUnits, coff = 0;
+      if (l < 2) W = d.w_enc[l];
+      else if (l == 2) { W = d.w_join; stride = d.join_in; coff = d.join_state_off; }
+      else W = d.w_res[l - 3];
+      v = W[row * stride + coff + k];
+    } else if (q < off_whead(d.n_res)) {
+      const int rel = q - off_bias(d.n_res);
+      const int l = rel / kUnits, row = rel % kUnits;
+      if (l < 2) v = d.b_enc[l][row];
+      else if (l > 2) v = d.b_res[l - 3][row];  // join bias travels in traj_bias
+    } else if (q < off_bhead(d.n_res)) {
+      const int rel = q - off_whead(d.n_res);
+      const int o = rel / kUnits, k = rel % kUnits;
+      if (o < d.n_out) v = d.w_head[o * kUnits + k];
+    } else {
+      const int o = q - off_bhead(d.n_res);
+      if (o < d.n_out) v = d.b_head[o];
+    }
+    out[q] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------ layer pieces
+template <int CT>
+struct Act {  // one 64-feature activation for 32*CT particles: [row tile][col tile]
+  f32x16 v[2][CT];
+};
+
+// quad broadcast of lane (l & ~3) -- the primal column of a Jacobian group
+__device__ __forceinline__ float quad_first(float x) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x00, 0xf, 0xf, true));
+}
+
+template <int CT>
+__device__ __forceinline__ void mfma_layer(const float* __restrict__ Wl, const Act<CT>& in,
+                                           Act<CT>& acc, int lane) {
+  // The blob in LDS is loop-invariant across tiles; without a compiler barrier LICM hoists
+  // every layer's fragment reads out of the tile loop (hundreds of VGPRs -> scratch spills).
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(Wl + ((t * 8 + s4) * 64 + lane) * 4);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int s = s4 * 4 + ks;
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+          acc.v[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], in.v[s >> 4][c][s & 15],
+                                                             acc.v[t][c], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// acc (+)= bias (LDS, natural order).  `scale` zeroes the bias on Jacobian tangent columns.
+template <int CT, bool ADD>
+__device__ __forceinline__ void add_bias(const float* __restrict__ bl, Act<CT>& acc, int h, float scale) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bl + 32 * t + 8 * g + 4 * h);
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (ADD) acc.v[t][c][4 * g + e] += b[e] * scale;
+          else acc.v[t][c][4 * g + e] = b[e] * scale;
+        }
+    }
+}
+
+template <int CT, bool JAC>
+__device__ __forceinline__ void relu(Act<CT>& a, bool primal) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = a.v[t][c][r];
+        if (JAC) {
+          // tangent columns follow the primal's mask (sub-gradient 0 at 0, as autograd)
+          const float pv = quad_first(v);
+          a.v[t][c][r] = primal ? fmaxf(v, 0.f) : (pv > 0.f ? v : 0.f);
+        } else {
+          a.v[t][c][r] = fmaxf(v, 0.f);
+        }
+      }
+}
+
+// y = relu(W2 relu(W1 x + b1) + b2 + x), in place in x, h as scratch (resblocks.Linear)
+template <int CT, bool JAC>
+__device__ __forceinline__ void res_block(const float* __restrict__ lds, int n_res, int l1,
+                                          Act<CT>& x, Act<CT>& hbuf, int lane, bool primal) {
+  const int h = lane >> 5;
+  const float bs = (JAC && !primal) ? 0.f : 1.f;
+  add_bias<CT, false>(lds + off_bias(n_res) + l1 * kUnits, hbuf, h, bs);
+  mfma_layer<CT>(lds + off_layers() + l1 * kLayerFloats, x, hbuf, lane);
+  relu<CT, JAC>(hbuf, primal);
+  add_bias<CT, true>(lds + off_bias(n_res) + (l1 + 1) * kUnits, x, h, bs);
+  mfma_layer<CT>(lds + off_layers() + (l1 + 1) * kLayerFloats, hbuf, x, lane);
+  relu<CT, JAC>(x, primal);
+}
+
+enum Kind { kDynamics = 0, kMeasure = 1, kJacobian = 2 };
+
+struct NetArgs {
+  const float* packed;
+  const float* states_in;   // (R, D)            [jacobian: (N, D)]
+  const float* traj_bias;   // (N, 64)
+  const float* noise;       // (R, D) or null
+  const float* scale_tril;  // (D, D) or null
+  const float* mod_logw;    // (N * stride) or null
+  float* states_out;        // (R, D)
+  float* loglik;            // (R)
+  float* jac;               // (N, D, D)
+  int R;                    // rows (columns of the tiles); jacobian: 4 * N
+  int M;                    // particles per trajectory (row -> trajectory = row / M)
+  int logw_stride;
+  int combine;
+};
+
+template <int D, int NRES, int KIND, int CT>
+__global__ __launch_bounds__(kThreads, 2) void particle_net_kernel(NetArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr bool JAC = KIND == kJacobian;
+  constexpr int NOUT = (KIND == kMeasure) ? 1 : D + 1;
+  constexpr int TILE = 32 * CT;
+  static_assert(!JAC || D <= 3, "jacobian groups are 4 columns: primal + up to 3 tangents");
+
+  // stage this network's fragment-ordered weights in LDS once per workgroup
+  {
+    const float4* src = reinterpret_cast<const float4*>(a.packed);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = threadIdx.x; i < blob_floats(NRES) / 4; i += kThreads) dst[i] = src[i];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int wave_global = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  const int waves_total = gridDim.x * kWavesPerBlock;
+  const int ntiles = (a.R + TILE - 1) / TILE;
+
+  for (int tile = wave_global; tile < ntiles; tile += waves_total) {
+    const int base = tile * TILE;
+    // column -> row / trajectory bookkeeping for the CT columns this lane feeds
+    int col_row[CT], col_traj[CT];
+    bool col_primal[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      int row = base + 32 * c + j;
+      row = row < a.R ? row : a.R - 1;
+      col_row[c] = row;
+      col_traj[c] = JAC ? (row >> 2) : (row / a.M);
+      col_primal[c] = JAC ? ((row & 3) == 0) : true;
+    }
+    const bool primal = col_primal[0];  // same for every c: 32 is a multiple of 4
+
+    // ---- encoder layer 0: relu(W0 [x; 1]) as (kW0Cols / 2) k-steps
+    Act<CT> X, H;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X.v[t][c][r] = 0.f;
+    constexpr int KS0 = (D + 2) / 2;
+#pragma unroll
+    for (int s = 0; s < KS0; ++s) {
+      const int comp = 2 * s + h;
+      float b[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        float v;
+        if (JAC) {
+          const int role = col_row[c] & 3;
+          if (role == 0) v = comp < D ? a.states_in[col_traj[c] * D + comp] : (comp == D ? 1.f : 0.f);
+          else v = (comp == role - 1) ? 1.f : 0.f;  // tangent e_{role-1}; role > D: zero column
+        } else {
+          v = comp < D ? a.states_in[static_cast<size_t>(col_row[c]) * D + comp] : (comp == D ? 1.f : 0.f);
+        }
+        b[c] = v;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float w = lds[off_w0() + (32 * t + j) * kW0Cols + comp];
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+          X.v[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b[c], X.v[t][c], 0, 0, 0);
+      }
+    }
+    relu<CT, JAC>(X, primal);
+
+    // ---- encoder residual block (layers 0, 1)
+    res_block<CT, JAC>(lds, NRES, 0, X, H, lane, primal);
+
+    // ---- join layer (2): per-trajectory hoisted half arrives as the accumulator init
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const float* tb = a.traj_bias + static_cast<size_t>(col_traj[c]) * kUnits + 32 * t + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(tb + 8 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) H.v[t][c][4 * g + e] = (JAC && !primal) ? 0.f : b[e];
+        }
+      }
+    mfma_layer<CT>(lds + off_layers() + 2 * kLayerFloats, X, H, lane);
+    if (KIND == kMeasure) relu<CT, JAC>(H, primal);
+
+    // ---- residual trunk: activations now live in H, X is scratch
+#pragma unroll
+    for (int i = 0; i < NRES; ++i) res_block<CT, JAC>(lds, NRES, 3 + 2 * i, H, X, lane, primal);
+
+    // ---- head (64 -> NOUT) on the VALU: each lane holds 32 of the 64 features of its columns
+    float out[NOUT][CT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      float part[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) part[c] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(
+              lds + off_whead(NRES) + o * kUnits + 32 * t + 8 * g + 4 * h);
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[c] += w[e] * H.v[t][c][4 * g + e];
+        }
+#pragma unroll
+      for (int c = 0; c < CT; ++c) out[o][c] = part[c] + __shfl_xor(part[c], 32);
+    }
+
+    // ---- epilogue: lane l finalises column l of the tile (CT == 2) or column j (CT == 1, h == 0)
+    float mine[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      if (CT == 2) mine[o] = h ? out[o][CT - 1] : out[o][0];
+      else mine[o] = out[o][0];
+    }
+    const int my_row = base + (CT == 2 ? lane : j);
+    const bool active = my_row < a.R && (CT == 2 || h == 0);
+    const float* bh = lds + off_bhead(NRES);
+
+    if (KIND == kMeasure) {
+      if (active) {
+        const int traj = my_row / a.M;
+        float ll = mine[0] + bh[0];
+        if (a.mod_logw) ll += a.mod_logw[static_cast<size_t>(traj) * a.logw_stride];
+        if (a.combine) {
+          const float prev = a.loglik[my_row];
+          const float m = fmaxf(prev, ll);
+          ll = (m == -INFINITY) ? m : m + logf(expf(prev - m) + expf(ll - m));
+        }
+        a.loglik[my_row] = ll;
+      }
+    } else if (KIND == kDynamics) {
+      if (active) {
+        const float gate = mine[D] + bh[D];
+        const float sg = 1.0f / (1.0f + expf(-gate));
+        float xo[D], eps[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          xo[i] = a.states_in[static_cast<size_t>(my_row) * D + i];
+          eps[i] = a.noise ? a.noise[static_cast<size_t>(my_row) * D + i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          float v = xo[i] + (mine[i] + bh[i]) * sg;
+          if (a.noise) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) v += a.scale_tril[i * D + k] * eps[k];
+          }
+          a.states_out[static_cast<size_t>(my_row) * D + i] = v;
+        }
+      }
+    } else {  // jacobian: primal column -> x', tangent column c -> d x' / d x_c
+      const int role = my_row & 3;
+      const int traj = my_row >> 2;
+      float dirp[D], gatep;
+#pragma unroll
+      for (int i = 0; i < D; ++i) dirp[i] = quad_first(mine[i] + bh[i]);
+      gatep = quad_first(mine[D] + bh[D]);
+      const float sg = 1.0f / (1.0f + expf(-gatep));
+      if (active) {
+        if (role == 0) {
+#pragma unroll
+          for (int i = 0; i < D; ++i)
+            a.states_out[traj * D + i] = a.states_in[traj * D + i] + dirp[i] * sg;
+        } else if (role <= D) {
+          const float dgate = mine[D];  // tangent columns carry no bias
+#pragma unroll
+          for (int i = 0; i < D; ++i) {
+            const float dv = mine[i] * sg + dirp[i] * (sg * (1.0f - sg)) * dgate + ((i == role - 1) ? 1.f : 0.f);
+            a.jac[(static_cast<size_t>(traj) * D + i) * D + (role - 1)] = dv;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int D, int NRES, int KIND>
+int launch_ct(const NetArgs& a, hipStream_t s) {
+  const size_t lds = static_cast<size_t>(blob_floats(NRES)) * sizeof(float);
+  // small problems: 32-particle tiles spread over more waves; large: 64-particle tiles
+  const bool big = a.R >= 256 * kWavesPerBlock * 64;
+  const int tile = big ? 64 : 32;
+  const int ntiles = (a.R + tile - 1) / tile;
+  int grid = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (grid > 256) grid = 256;
+  if (grid < 1) grid = 1;
+  hipError_t e;
+  if (big) {
+    auto k = particle_net_kernel<D, NRES, KIND, 2>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return static_cast<int>(e);
+    k<<<grid, kThreads, lds, s>>>(a);
+  } else {
+    auto k = particle_net_kernel<D, NRES, KIND, 1>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return static_cast<int>(e);
+    k<<<grid, kThreads, lds, s>>>(a);
+  }
+  MMF_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int KIND>
+int launch(const NetArgs& a, int d, int n_res, hipStream_t s) {
+#define MMF_CASE(D, NR) \
+  if (d == D && n_res == NR) return launch_ct<D, NR, KIND>(a, s);
+  if (KIND == kJacobian) {
+    MMF_CASE(2, 3) MMF_CASE(3, 3)
+    return MMF_EINVAL;
+  }
+  if (KIND == kDynamics) {
+    MMF_CASE(2, 3) MMF_CASE(3, 3)
+    return MMF_EINVAL;
+  }
+  MMF_CASE(2, 2) MMF_CASE(3, 2)
+#undef MMF_CASE
+  return MMF_EINVAL;
+}
+
+}  // namespace
+
+extern "C" size_t mmf_particle_net_floats(int n_res) {
+  if (n_res < 0 || n_res > MMF_MAX_RES) return 0;
+  return static_cast<size_t>(blob_floats(n_res));
+}
+
+extern "C" int mmf_pack_particle_net(const MmfParticleNetDesc* d, float* packed, void* stream) {
+  if (!d || !packed) return MMF_EINVAL;
+  if (d->d_in < 1 || d->d_in > MMF_MAX_STATE_DIM || d->n_res < 0 || d->n_res > MMF_MAX_RES) return MMF_EINVAL;
+  if (d->n_out < 1 || d->n_out > kHeadRows) return MMF_EINVAL;
+  if (d->join_state_off < 0 || d->join_state_off + kUnits > d->join_in) return MMF_EINVAL;
+  if (!d->w_in || !d->b_in || !d->w_join || !d->w_head || !d->b_head) return MMF_EINVAL;
+  for (int i = 0; i < 2; ++i)
+    if (!d->w_enc[i] || !d->b_enc[i]) return MMF_EINVAL;
+  for (int i = 0; i < 2 * d->n_res; ++i)
+    if (!d->w_res[i] || !d->b_res[i]) return MMF_EINVAL;
+  const int total = blob_floats(d->n_res);
+  pack_particle_net_kernel<<<(total + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(*d, packed);
+  MMF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int mmf_pf_dynamics(const float* packed, int n_res, const float* states_in,
+                               const float* traj_bias, const float* noise, const float* scale_tril,
+                               float* states_out, int N, int M, int d, void* stream) {
+  if (!packed || !states_in || !traj_bias || !states_out || (noise && !scale_tril)) return MMF_EINVAL;
+  if (N < 0 || M < 1) return MMF_EINVAL;
+  if (static_cast<long long>(N) * M > 0x7fffffffLL / 8) return MMF_ETOOLARGE;
+  if (N == 0) return 0;
+  NetArgs a{};
+  a.packed = packed; a.states_in = states_in; a.traj_bias = traj_bias; a.noise = noise;
+  a.scale_tril = scale_tril; a.states_out = states_out; a.R = N * M; a.M = M;
+  return launch<kDynamics>(a, d, n_res, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mmf_pf_measure(const float* packed, int n_res, const float* states,
+                              const float* traj_bias, const float* modality_logw, int logw_stride,
+                              float* loglik, int combine, int N, int M, int d, void* stream) {
+  if (!packed || !states || !traj_bias || !loglik) return MMF_EINVAL;
+  if (N < 0 || M < 1) return MMF_EINVAL;
+  if (static_cast<long long>(N) * M > 0x7fffffffLL / 8) return MMF_ETOOLARGE;
+  if (N == 0) return 0;
+  NetArgs a{};
+  a.packed = packed; a.states_in = states; a.traj_bias = traj_bias; a.mod_logw = modality_logw;
+  a.logw_stride = logw_stride; a.loglik = loglik; a.combine = combine; a.R = N * M; a.M = M;
+  return launch<kMeasure>(a, d, n_res, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mmf_dynamics_jacobian(const float* packed, int n_res, const float* states_in,
+                                     const float* traj_bias, float* states_out, float* jac, int N,
+                                     int d, void* stream) {
+  if (!packed || !states_in || !traj_bias || !states_out || !jac) return MMF_EINVAL;
+  if (N < 0) return MMF_EINVAL;
+  if (N > 0x7fffffff / 32) return MMF_ETOOLARGE;
+  if (N == 0) return 0;
+  NetArgs a{};
+  a.packed = packed; a.states_in = states_in; a.traj_bias = traj_bias;
+  a.states_out = states_out; a.jac = jac; a.R = 4 * N; a.M = 4;
+  return launch<kJacobian>(a, d, n_res, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,275 @@
+// K1: particle reweight + normalise + weighted-mean estimate + fixed-point CDF + systematic /
+// multinomial resample + gather, one kernel, one workgroup per trajectory.
+//
+// Replaces the post-measurement half of torchfilter's ParticleFilter.forward (external
+// dependency of the reference; call sites /root/reference/crossmodal/eval_helpers.py:139-142;
+// SURVEY.md 3.2 / T1).  The resampling definition is the integer one of
+// oracle/resample.py (weights quantised to 2^-24 of the row max, u64 inclusive CDF), so the
+// ancestor indices do not depend on the scan tree and match the oracle bit for bit.
+//
+// HBM traffic per particle (algorithmic): loglik 4 + logw 4 + states 4d read, states 4d written
+// (+4 logw written in mode 0) = 32 B (d=3) / 24 B (d=2); everything else stays in LDS:
+//   slot[i] (8 B/particle): first the fp32 unnormalised log-weight x_i, then (modes 1/2)
+//   overwritten in place by the u64 inclusive CDF.
+#include "mmf_common.h"
+
+namespace {
+
+constexpr int kBlock = 1024;  // 16 waves; M = 4096 -> one float4 chunk per thread
+constexpr int kMaxWaves = kBlock / MMF_WAVE;
+constexpr int kFixBits = 24;
+
+struct Scratch {  // lives behind the slots in dynamic LDS
+  float red[kMaxWaves][MMF_MAX_STATE_DIM + 1];
+  unsigned long long wave_tot[kMaxWaves];
+  float bcast[MMF_MAX_STATE_DIM + 2];
+};
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
+    const float* __restrict__ loglik, const float* __restrict__ logw_in,
+    const float* __restrict__ states_in, const float* __restrict__ u,
+    float* __restrict__ estimate, float* states_out, float* logw_out,
+    int32_t* __restrict__ indices_out, int M, int M_out, int mode) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const bool need_cdf = mode != 0;
+  const int slot_bytes = need_cdf ? 8 : 4;
+  const size_t slots_sz = (static_cast<size_t>(M) * slot_bytes + 15) & ~static_cast<size_t>(15);
+  float* xf = reinterpret_cast<float*>(smem);                            // mode 0: x_i at [i]
+  unsigned long long* cdf = reinterpret_cast<unsigned long long*>(smem);  // modes 1/2
+  Scratch& sc = *reinterpret_cast<Scratch*>(smem + slots_sz);
+
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & (MMF_WAVE - 1);
+  const int wave = tid >> 6;
+  const int nwaves = blockDim.x >> 6;
+  const int chunk = blockDim.x * 4;
+
+  const float* ll = loglik + static_cast<size_t>(n) * M;
+  const float* lw = logw_in + static_cast<size_t>(n) * M;
+  const float* xs = states_in + static_cast<size_t>(n) * M * D;
+  const bool vec = (M & 3) == 0;  // rows 16-B aligned -> float4 path
+
+  auto x_store = [&](int i, float v) {
+    if (need_cdf) reinterpret_cast<float*>(cdf + i)[0] = v; else xf[i] = v;
+  };
+  auto x_load = [&](int i) -> float {
+    return need_cdf ? reinterpret_cast<const float*>(cdf + i)[0] : xf[i];
+  };
+
+  // ---- pass 1: x_i = logw_i + loglik_i -> LDS, row max
+  float mx = -INFINITY;
+  for (int base = 0; base < M; base += chunk) {
+    const int i0 = base + tid * 4;
+    float v[4];
+    if (vec && i0 + 3 < M) {
+      const float4 a = *reinterpret_cast<const float4*>(ll + i0);
+      const float4 b = *reinterpret_cast<const float4*>(lw + i0);
+      v[0] = b.x + a.x; v[1] = b.y + a.y; v[2] = b.z + a.z; v[3] = b.w + a.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (i0 + j < M) ? lw[i0 + j] + ll[i0 + j] : -INFINITY;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i0 + j < M) { x_store(i0 + j, v[j]); mx = fmaxf(mx, v[j]); }
+  }
+  mx = mmf::wave_max(mx);
+  if (lane == 0) sc.red[wave][0] = mx;
+  __syncthreads();
+  mx = sc.red[0][0];
+  for (int w = 1; w < nwaves; ++w) mx = fmaxf(mx, sc.red[w][0]);
+  __syncthreads();
+
+  // ---- pass 2: e_i = detexp(x_i - max); float sums for the estimate; integer CDF
+  float S = 0.f, acc[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) acc[c] = 0.f;
+  unsigned long long carry = 0;
+  for (int base = 0; base < M; base += chunk) {
+    const int i0 = base + tid * 4;
+    float e[4];
+    unsigned long long q[4], tsum = 0;
+    float st[4 * D];
+    if (vec && i0 + 3 < M) {
+      const float4* p = reinterpret_cast<const float4*>(xs + static_cast<size_t>(i0) * D);
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const float4 t = p[k];
+        st[4 * k] = t.x; st[4 * k + 1] = t.y; st[4 * k + 2] = t.z; st[4 * k + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4 * D; ++k)
+        st[k] = (i0 * D + k < M * D) ? xs[static_cast<size_t>(i0) * D + k] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = i0 + j < M;
+      e[j] = ok ? mmf::detexp(x_load(i0 + j) - mx) : 0.f;
+      q[j] = static_cast<unsigned long long>(floorf(e[j] * 16777216.0f));
+      tsum += q[j];
+      S += e[j];
+#pragma unroll
+      for (int c = 0; c < D; ++c) acc[c] += e[j] * st[j * D + c];
+    }
+    if (need_cdf) {
+      const unsigned long long incl = mmf::wave_inclusive_scan(tsum, lane);
+      if (lane == MMF_WAVE - 1) sc.wave_tot[wave] = incl;
+      __syncthreads();
+      unsigned long long before = carry, total = 0;
+      for (int w = 0; w < nwaves; ++w) {
+        const unsigned long long t = sc.wave_tot[w];
+        if (w < wave) before += t;
+        total += t;
+      }
+      unsigned long long run = before + incl - tsum;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        run += q[j];
+        if (i0 + j < M) cdf[i0 + j] = run;
+      }
+      carry += total;
+      __syncthreads();
+    }
+  }
+  S = mmf::wave_sum(S);
+#pragma unroll
+  for (int c = 0; c < D; ++c) acc[c] = mmf::wave_sum(acc[c]);
+  if (lane == 0) {
+    sc.red[wave][0] = S;
+#pragma unroll
+    for (int c = 0; c < D; ++c) sc.red[wave][1 + c] = acc[c];
+  }
+  __syncthreads();
+  if (tid <= D) {
+    float t = 0.f;
+    for (int w = 0; w < nwaves; ++w) t += sc.red[w][tid];
+    sc.bcast[tid] = t;
+  }
+  __syncthreads();
+  S = sc.bcast[0];
+  if (tid < D) estimate[static_cast<size_t>(n) * D + tid] = sc.bcast[1 + tid] / S;
+
+  // ---- mode 0: normalised log-weights out, particles stay
+  if (!need_cdf) {
+    const float logS = logf(S);
+    float* lo = logw_out + static_cast<size_t>(n) * M;
+    float* so = states_out ? states_out + static_cast<size_t>(n) * M * D : nullptr;
+    const bool copy = so != nullptr && so != xs;
+    for (int i = tid; i < M; i += blockDim.x) {
+      lo[i] = (xf[i] - mx) - logS;
+      if (copy) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) so[static_cast<size_t>(i) * D + c] = xs[static_cast<size_t>(i) * D + c];
+      }
+    }
+    return;
+  }
+
+  // ---- modes 1/2: positions -> ancestor index by upper_bound in the LDS CDF -> gather
+  const unsigned long long Q = cdf[M - 1];
+  unsigned long long R = 0;
+  if (mode == 1) {
+    const unsigned long long U = static_cast<unsigned long long>(floorf(u[n] * 16777216.0f));
+    R = (U * Q) >> kFixBits;
+  }
+  const bool pow2 = (M_out & (M_out - 1)) == 0;
+  const int shift = __ffs(M_out) - 1;
+  const float log_uniform = -logf(static_cast<float>(M_out));
+  float* so = states_out + static_cast<size_t>(n) * M_out * D;
+  float* lo = logw_out + static_cast<size_t>(n) * M_out;
+  int32_t* io = indices_out ? indices_out + static_cast<size_t>(n) * M_out : nullptr;
+  const float* un = (mode == 2) ? u + static_cast<size_t>(n) * M_out : nullptr;
+  const bool vec_out = (M_out & 3) == 0;
+
+  for (int base = 0; base < M_out; base += chunk) {
+    const int k0 = base + tid * 4;
+    int idx[4];
+    float g[4 * D];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + j;
+      idx[j] = 0;
+      if (k < M_out) {
+        unsigned long long p;
+        if (mode == 1) {
+          const unsigned long long num = static_cast<unsigned long long>(k) * Q + R;
+          p = pow2 ? (num >> shift) : (num / static_cast<unsigned long long>(M_out));
+        } else {
+          const unsigned long long U = static_cast<unsigned long long>(floorf(un[k] * 16777216.0f));
+          p = (U * Q) >> kFixBits;
+        }
+        int lo_i = (mode == 1 && j > 0) ? idx[j - 1] : 0, hi_i = M;  // sorted positions
+        while (lo_i < hi_i) {
+          const int mid = (lo_i + hi_i) >> 1;
+          if (cdf[mid] <= p) lo_i = mid + 1; else hi_i = mid;
+        }
+        idx[j] = lo_i;
+#pragma unroll
+        for (int c = 0; c < D; ++c) g[j * D + c] = xs[static_cast<size_t>(lo_i) * D + c];
+      }
+    }
+    if (vec_out && k0 + 3 < M_out) {
+      float4* p = reinterpret_cast<float4*>(so + static_cast<size_t>(k0) * D);
+#pragma unroll
+      for (int k = 0; k < D; ++k) p[k] = make_float4(g[4 * k], g[4 * k + 1], g[4 * k + 2], g[4 * k + 3]);
+      *reinterpret_cast<float4*>(lo + k0) = make_float4(log_uniform, log_uniform, log_uniform, log_uniform);
+      if (io) *reinterpret_cast<int4*>(io + k0) = make_int4(idx[0], idx[1], idx[2], idx[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + j;
+        if (k < M_out) {
+#pragma unroll
+          for (int c = 0; c < D; ++c) so[static_cast<size_t>(k) * D + c] = g[j * D + c];
+          lo[k] = log_uniform;
+          if (io) io[k] = idx[j];
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t mmf_pf_reweight_resample_lds_bytes(int M, int mode) {
+  const size_t slots = (static_cast<size_t>(M) * (mode ? 8 : 4) + 15) & ~static_cast<size_t>(15);
+  return slots + sizeof(Scratch);
+}
+
+extern "C" int mmf_pf_reweight_resample(const float* loglik, const float* logw_in,
+                                        const float* states_in, const float* u, float* estimate,
+                                        float* states_out, float* logw_out, int32_t* indices_out,
+                                        int N, int M, int M_out, int d, int mode, void* stream) {
+  if (!loglik || !logw_in || !states_in || !estimate || !logw_out) return MMF_EINVAL;
+  if (N < 0 || M < 1 || M_out < 1 || d < 1 || d > MMF_MAX_STATE_DIM || mode < 0 || mode > 2) return MMF_EINVAL;
+  if (mode != 0 && (!u || !states_out || states_out == states_in)) return MMF_EINVAL;
+  if (mode == 0 && M_out != M) return MMF_EINVAL;
+  if (M > 65536 || M_out > 65536) return MMF_ETOOLARGE;
+  const size_t lds = mmf_pf_reweight_resample_lds_bytes(M, mode);
+  if (lds > 160 * 1024) return MMF_ETOOLARGE;
+  if (N == 0) return 0;
+  // enough threads to give each one a float4 of work, at least one wave
+  int block = ((M + 3) / 4 + MMF_WAVE - 1) / MMF_WAVE * MMF_WAVE;
+  if (block > kBlock) block = kBlock;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define MMF_K1(D)                                                                              \
+  case D: {                                                                                    \
+    if (lds > 64 * 1024) {                                                                     \
+      hipError_t e = hipFuncSetAttribute(                                                      \
+          reinterpret_cast<const void*>(&pf_reweight_resample_kernel<D>),                      \
+          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                  \
+      if (e != hipSuccess) return static_cast<int>(e);                                         \
+    }                                                                                          \
+    pf_reweight_resample_kernel<D><<<N, block, lds, s>>>(loglik, logw_in, states_in, u,        \
+        estimate, states_out, logw_out, indices_out, M, M_out, mode);                          \
+  } break;
+  switch (d) {
+    MMF_K1(1) MMF_K1(2) MMF_K1(3) MMF_K1(4)
+  }
+#undef MMF_K1
+  MMF_CHECK_LAUNCH();
+  return 0;
+}

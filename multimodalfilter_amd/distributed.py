@@ -1,0 +1,72 @@
+"""Multi-GPU layout: independent trajectories shard across ranks, one process per GPU.
+
+Nothing in the filter recursions mixes batch elements, so the data path has
+no collective: rank ``r`` owns trajectories ``[r*N/P, (r+1)*N/P)`` for all ``T`` and the
+model weights are replicated.  The only exchange is the evaluation statistic: an
+all-gather of the per-sequence squared-error partials ``(N_local, d)`` (RCCL over xGMI when
+the backend is ``"nccl"``; KB-scale, latency-bound).  Particles of one trajectory never
+split across GPUs, so the resampling prefix sum stays inside one workgroup.
+"""
+import os
+from typing import Dict, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str = None) -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from torchrun's environment; no-op for one process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_bounds(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced ownership of the trajectory axis (first ranks get the remainder)."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_trajectories(traj: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[str, torch.Tensor]:
+    """Slice every ``(T, N, ...)`` tensor along ``N`` (dim 1)."""
+    n = next(iter(traj.values())).shape[1]
+    lo, hi = shard_bounds(n, rank, world)
+    return {k: v[:, lo:hi].contiguous() for k, v in traj.items()}
+
+
+def all_gather_rows(x: torch.Tensor) -> torch.Tensor:
+    """Concatenate per-rank ``(N_local, ...)`` tensors along dim 0 (ragged shards allowed)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return x
+    world = dist.get_world_size()
+    sizes = [torch.zeros(1, dtype=torch.int64, device=x.device) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device))
+    sizes = [int(s) for s in sizes]
+    pad = max(sizes)
+    buf = x.new_zeros((pad,) + tuple(x.shape[1:]))
+    buf[: x.shape[0]] = x
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
+
+
+def max_over_ranks(value: float, device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t)
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

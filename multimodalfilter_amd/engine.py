@@ -1,0 +1,179 @@
+"""Bridges ``nn.Module`` parameters to the HIP kernels: fragment-ordered weight blobs for
+the per-particle networks, and the launches of K2 / K5 (``csrc/particle_net.hip``).
+"""
+import ctypes
+from typing import List, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _abi
+from .layers import ResLinear
+
+
+# MAC per row of each per-particle network: enc 64*(d) [+bias via the MFMA],
+# 2 + 1 + 2*n_res layers of 64x64, head 64*n_out.
+def particle_net_macs(d_in: int, n_res: int, n_out: int) -> int:
+    return 64 * d_in + (3 + 2 * n_res) * 64 * 64 + 64 * n_out
+
+
+class KernelTimer:
+    """HIP-event timing of individual kernel launches on the launching stream (used by
+    ``bench.py`` for the roofline figure; off by default, no cost when off)."""
+
+    def __init__(self):
+        self.records = {}
+
+    def launch(self, name: str, flops: float, nbytes: float, fn):
+        start = torch.cuda.Event(enable_timing=True)
+        end = torch.cuda.Event(enable_timing=True)
+        start.record()
+        fn()
+        end.record()
+        self.records.setdefault(name, []).append((start, end, flops, nbytes))
+
+    def summary(self):
+        out = {}
+        for name, recs in self.records.items():
+            ms = [s.elapsed_time(e) for s, e, _, _ in recs]
+            out[name] = {"launches": len(recs), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms),
+                         "flops_per_launch": sum(r[2] for r in recs) / len(recs),
+                         "bytes_per_launch": sum(r[3] for r in recs) / len(recs)}
+        return out
+
+
+_TIMER = None
+
+
+def set_kernel_timer(timer):
+    global _TIMER
+    _TIMER = timer
+
+
+def _timed(name, flops, nbytes, fn):
+    if _TIMER is None:
+        fn()
+    else:
+        _TIMER.launch(name, flops, nbytes, fn)
+
+
+def require_device(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise _abi.MmfError(
+            f"{what}: tensors must live on the MI355X (got {t.device}); the filter hot path has "
+            "no CPU implementation -- move the module and its inputs to 'cuda'"
+        )
+
+
+class PackedParticleNet:
+    """One per-particle network (``enc -> join -> res* -> head``, see ``include/mmf.h``)
+    packed into MFMA-fragment order on the device.
+
+    The blob is rebuilt lazily whenever a source parameter changed (``Tensor._version``),
+    moved, or was replaced, so optimiser steps and ``load_state_dict`` are picked up.
+    """
+
+    def __init__(self, *, encoder: nn.Sequential, join: nn.Linear, join_state_off: int,
+                 res_blocks: Sequence[ResLinear], head: nn.Linear, relu_after_join: bool):
+        enc_in, enc_res = encoder[0], encoder[2]
+        assert isinstance(enc_in, nn.Linear) and isinstance(enc_res, ResLinear)
+        assert enc_in.out_features == _abi.MMF_UNITS and join.out_features == _abi.MMF_UNITS
+        assert len(res_blocks) <= _abi.MMF_MAX_RES
+        self.d_in = enc_in.in_features
+        self.n_res = len(res_blocks)
+        self.n_out = head.out_features
+        self.relu_after_join = bool(relu_after_join)
+        self.join = join
+        self.join_state_off = int(join_state_off)
+        self._enc_in, self._enc_res = enc_in, enc_res
+        self._res = list(res_blocks)
+        self._head = head
+        self._blob = None
+        self._stamp = None
+
+    def _sources(self) -> List[torch.Tensor]:
+        ts = [self._enc_in.weight, self._enc_in.bias,
+              self._enc_res.block1.weight, self._enc_res.block1.bias,
+              self._enc_res.block2.weight, self._enc_res.block2.bias, self.join.weight]
+        for rb in self._res:
+            ts += [rb.block1.weight, rb.block1.bias, rb.block2.weight, rb.block2.bias]
+        ts += [self._head.weight, self._head.bias]
+        return ts
+
+    def blob(self) -> torch.Tensor:
+        src = self._sources()
+        stamp = tuple((t.data_ptr(), t._version, str(t.device)) for t in src)
+        if self._blob is not None and stamp == self._stamp:
+            return self._blob
+        dev = src[0].device
+        require_device(src[0], "PackedParticleNet")
+        keep = [t.detach().to(torch.float32).contiguous() for t in src]
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        d = _abi.MmfParticleNetDesc()
+        d.d_in, d.n_res, d.relu_after_join, d.n_out = self.d_in, self.n_res, int(self.relu_after_join), self.n_out
+        d.join_in, d.join_state_off = self.join.in_features, self.join_state_off
+        d.w_in, d.b_in = P(keep[0]), P(keep[1])
+        d.w_enc[0], d.b_enc[0], d.w_enc[1], d.b_enc[1] = P(keep[2]), P(keep[3]), P(keep[4]), P(keep[5])
+        d.w_join = P(keep[6])
+        for i in range(self.n_res):
+            base = 7 + 4 * i
+            d.w_res[2 * i], d.b_res[2 * i] = P(keep[base]), P(keep[base + 1])
+            d.w_res[2 * i + 1], d.b_res[2 * i + 1] = P(keep[base + 2]), P(keep[base + 3])
+        d.w_head, d.b_head = P(keep[-2]), P(keep[-1])
+        blob = torch.empty(_abi.particle_net_floats(self.n_res), dtype=torch.float32, device=dev)
+        _abi.pack_particle_net(d, blob)
+        self._blob, self._stamp = blob, stamp
+        return blob
+
+    def traj_bias(self, traj_features: torch.Tensor) -> torch.Tensor:
+        """Hoisted per-trajectory half of the join layer: ``W[:, traj cols] f + b`` -> ``(N, 64)``."""
+        W = self.join.weight
+        off = self.join_state_off
+        cols = torch.cat((W[:, :off], W[:, off + _abi.MMF_UNITS:]), dim=1) if off + _abi.MMF_UNITS < W.shape[1] else W[:, :off]
+        return torch.addmm(self.join.bias, traj_features, cols.t()).contiguous()
+
+
+def run_dynamics(net: PackedParticleNet, states: torch.Tensor, traj_bias: torch.Tensor,
+                 noise, scale_tril, out: torch.Tensor = None) -> torch.Tensor:
+    """``states`` ``(N, M, d)`` or ``(R, d)`` with ``traj_bias`` ``(N, 64)``."""
+    require_device(states, "run_dynamics")
+    d = states.shape[-1]
+    N = traj_bias.shape[0]
+    R = states.numel() // d
+    assert R % N == 0
+    states = states.contiguous()
+    out = torch.empty_like(states) if out is None else out
+    blob = net.blob()
+    noise_c = None if noise is None else noise.contiguous()
+    tril_c = None if noise is None else scale_tril.contiguous()
+    _timed("particle_net_dynamics", 2.0 * R * particle_net_macs(d, net.n_res, net.n_out),
+           R * 4.0 * (2 * d + (d if noise is not None else 0)),
+           lambda: _abi.pf_dynamics(blob, net.n_res, states, traj_bias, noise_c, tril_c, out,
+                                    N, R // N, d))
+    return out
+
+
+def run_measure(net: PackedParticleNet, states: torch.Tensor, traj_bias: torch.Tensor,
+                modality_logw, logw_stride: int, loglik: torch.Tensor, combine: bool):
+    require_device(states, "run_measure")
+    d = states.shape[-1]
+    N = traj_bias.shape[0]
+    R = states.numel() // d
+    assert R % N == 0 and loglik.numel() == R
+    blob = net.blob()
+    states = states.contiguous()
+    _timed("particle_net_measure", 2.0 * R * particle_net_macs(d, net.n_res, net.n_out),
+           R * 4.0 * (d + 1 + (1 if combine else 0)),
+           lambda: _abi.pf_measure(blob, net.n_res, states, traj_bias, modality_logw, logw_stride,
+                                   loglik, combine, N, R // N, d))
+    return loglik
+
+
+def run_jacobian(net: PackedParticleNet, states: torch.Tensor, traj_bias: torch.Tensor):
+    """``(N, d)`` -> ``(x' (N, d), J (N, d, d))`` by forward-mode tangents (K5)."""
+    require_device(states, "run_jacobian")
+    N, d = states.shape
+    out = torch.empty_like(states)
+    jac = torch.empty((N, d, d), dtype=torch.float32, device=states.device)
+    _abi.dynamics_jacobian(net.blob(), net.n_res, states.contiguous(), traj_bias, out, jac, N, d)
+    return out, jac

@@ -1,0 +1,257 @@
+"""``torchfilter.filters`` on MI355X: the particle filter and the virtual-sensor EKF.
+
+API as the reference uses it -- ``ParticleFilter(dynamics_model=, measurement_model=,
+num_particles=)`` with public mutable ``num_particles`` / ``dynamics_model`` /
+``measurement_model`` (``/root/reference/crossmodal/door_models/pf.py:14-27``,
+``train_helpers.py:46,94``); ``VirtualSensorExtendedKalmanFilter(dynamics_model=,
+virtual_sensor_model=)`` with ``_belief_mean`` / ``_belief_covariance``
+(``door_models/kf.py:14-28``, ``base_models/crossmodal_kf.py:180``) -- with the recursion
+itself running in hand-written HIP: K1 (``mmf_pf_reweight_resample``) for reweight /
+normalise / estimate / resample / gather and K3 (``mmf_ekf_step``) for the Kalman algebra.
+Step order follows upstream torchfilter.
+"""
+import math
+from typing import Optional
+
+import torch
+
+from . import _abi, base
+from .engine import _timed, require_device
+from .utils import NoiseSource, tree_index, tree_leading_shape, tree_map
+
+_MODES = {"none": 0, "systematic": 1, "multinomial": 2}
+
+
+class ParticleFilter(base.Filter):
+    """Bootstrap particle filter (T1).
+
+    ``resample=None`` resamples iff ``not self.training`` (upstream behaviour).
+    ``resample_mode``: ``"systematic"`` (low variance, one uniform per trajectory; what
+    ``north_star`` asks for) or ``"multinomial"`` (upstream's distribution, one uniform per
+    particle).  Both use the fixed-point CDF of ``csrc/pf_resample.hip``.
+
+    Belief: ``particle_states (N, M, d)``, ``particle_log_weights (N, M)``.
+    Randomness comes from ``self.noise`` (``utils.NoiseSource``), never from global RNG state.
+    """
+
+    def __init__(self, *, dynamics_model: base.DynamicsModel,
+                 measurement_model: base.ParticleFilterMeasurementModel,
+                 num_particles: int = 100, resample: Optional[bool] = None,
+                 resample_mode: str = "systematic",
+                 estimation_method: str = "weighted_average"):
+        super().__init__(state_dim=dynamics_model.state_dim)
+        assert isinstance(dynamics_model, base.DynamicsModel)
+        assert isinstance(measurement_model, base.ParticleFilterMeasurementModel)
+        assert measurement_model.state_dim == self.state_dim
+        assert resample_mode in ("systematic", "multinomial")
+        assert estimation_method in ("weighted_average", "argmax")
+        self.dynamics_model = dynamics_model
+        self.measurement_model = measurement_model
+        self.num_particles = num_particles
+        self.resample = resample
+        self.resample_mode = resample_mode
+        self.estimation_method = estimation_method
+        self.noise = NoiseSource(0)
+        self.record_indices = False
+        self.last_resample_indices = None
+        self.particle_states: torch.Tensor = None
+        self.particle_log_weights: torch.Tensor = None
+        self._spare_states = None
+        self._initialized = False
+
+    # ------------------------------------------------------------------ belief
+    def initialize_beliefs(self, *, mean: torch.Tensor, covariance: torch.Tensor) -> None:
+        N, d = mean.shape
+        assert d == self.state_dim
+        assert covariance.shape == (N, d, d)
+        require_device(mean, "ParticleFilter.initialize_beliefs")
+        M = self.num_particles
+        eps = self.noise.gaussian((N, M, d), like=mean)
+        L = torch.linalg.cholesky(covariance.to(torch.float32))
+        self.particle_states = (mean[:, None, :] + torch.einsum("nij,nmj->nmi", L, eps)).contiguous()
+        self.particle_log_weights = mean.new_full((N, M), -math.log(M))
+        self._spare_states = None
+        self._initialized = True
+
+    # ------------------------------------------------------------------ one step
+    def _propagate(self, controls, ctrl_ctx, N, M, d):
+        eps = self.noise.gaussian((N, M, d), like=self.particle_states)
+        dyn = self.dynamics_model
+        if hasattr(dyn, "propagate_encoded"):
+            if ctrl_ctx is None:
+                ctrl_ctx = dyn.encode_controls(controls)
+            spare = self._spare_states
+            if spare is not None and spare.shape != self.particle_states.shape:
+                spare = None
+            return dyn.propagate_encoded(self.particle_states, ctrl_ctx, eps, out=spare)
+        # generic user model (torch ops on the device): same control for a trajectory's particles
+        flat = self.particle_states.reshape(N * M, d)
+        rep = tree_map(controls, lambda t: torch.repeat_interleave(t, repeats=M, dim=0))
+        pred, tril = dyn(initial_states=flat, controls=rep)
+        return (pred + torch.einsum("rij,rj->ri", tril, eps.reshape(N * M, d))).reshape(N, M, d).contiguous()
+
+    def _measure(self, states, observations, obs_ctx):
+        meas = self.measurement_model
+        if hasattr(meas, "forward_encoded"):
+            if obs_ctx is None:
+                obs_ctx = meas.encode_observations(observations)
+            return meas.forward_encoded(states, obs_ctx)
+        return meas(states=states, observations=observations).to(torch.float32).contiguous()
+
+    def _step(self, observations, controls, obs_ctx=None, ctrl_ctx=None) -> torch.Tensor:
+        assert self._initialized, "Particle filter not initialized!"
+        N, M, d = self.particle_states.shape
+        do_resample = (not self.training) if self.resample is None else bool(self.resample)
+        if not do_resample and self.num_particles != M:
+            raise NotImplementedError(
+                "changing num_particles without resampling (upstream's copy / randperm "
+                "adaptation) is not implemented: call initialize_beliefs() after changing it")
+
+        with torch.no_grad():
+            states = self._propagate(controls, ctrl_ctx, N, M, d)
+            loglik = self._measure(states, observations, obs_ctx)
+            assert loglik.shape == (N, M)
+
+            estimate = torch.empty((N, d), dtype=torch.float32, device=states.device)
+            if do_resample:
+                Mo = self.num_particles
+                mode = _MODES[self.resample_mode]
+                u = self.noise.uniform((N,) if mode == 1 else (N, Mo), like=states)
+                # two buffers ping-pong: dynamics wrote `states`; the old belief is free again
+                out = self.particle_states
+                if out.shape != (N, Mo, d) or out.data_ptr() == states.data_ptr():
+                    out = torch.empty((N, Mo, d), dtype=torch.float32, device=states.device)
+                logw_out = torch.empty((N, Mo), dtype=torch.float32, device=states.device)
+                idx = (torch.empty((N, Mo), dtype=torch.int32, device=states.device)
+                       if self.record_indices else None)
+                lw_in = self.particle_log_weights
+                _timed("pf_reweight_resample", 0.0, N * M * 4.0 * (2 + d) + N * Mo * 4.0 * d,
+                       lambda: _abi.pf_reweight_resample(loglik, lw_in, states, u, estimate,
+                                                         out, logw_out, idx, mode))
+                self._spare_states = states
+                self.last_resample_indices = idx
+            else:
+                out, logw_out = states, torch.empty_like(loglik)
+                _abi.pf_reweight_resample(loglik, self.particle_log_weights, states, None, estimate,
+                                          None, logw_out, None, 0)
+            if self.estimation_method == "argmax":
+                # arg-max of the *pre-resampling* normalised weights
+                tot = self.particle_log_weights + loglik
+                best = torch.argmax(tot, dim=1)
+                estimate = states[torch.arange(N, device=states.device), best]
+            self.particle_states = out
+            self.particle_log_weights = logw_out
+        return estimate
+
+    def forward(self, *, observations, controls) -> torch.Tensor:
+        return self._step(observations, controls)
+
+    def forward_loop(self, *, observations, controls) -> torch.Tensor:
+        """Sequential in ``t``; everything that does not depend on the belief (control and
+        observation encoders, CNNs, modality weights) is evaluated once for all ``T*N`` rows."""
+        T, N = tree_leading_shape(controls)[:2]
+        assert tree_leading_shape(observations)[:2] == (T, N)
+        flat = lambda t: t.reshape((T * N,) + tuple(t.shape[2:]))
+        obs_all = ctrl_all = None
+        with torch.no_grad():
+            if hasattr(self.measurement_model, "forward_encoded"):
+                obs_all = self.measurement_model.encode_observations(tree_map(observations, flat))
+            if hasattr(self.dynamics_model, "propagate_encoded"):
+                ctrl_all = self.dynamics_model.encode_controls(tree_map(controls, flat))
+        out = []
+        for t in range(T):
+            sl = slice(t * N, (t + 1) * N)
+            out.append(self._step(
+                tree_index(observations, t), tree_index(controls, t),
+                None if obs_all is None else {k: v[sl] for k, v in obs_all.items()},
+                None if ctrl_all is None else {k: v[sl] for k, v in ctrl_all.items()}))
+        return torch.stack(out, dim=0)
+
+
+class VirtualSensorExtendedKalmanFilter(base.Filter):
+    """EKF whose measurement is a learned virtual sensor ``(z, R^1/2)`` observed through
+    ``C = I`` (T2).  predict: ``S- = A S A^T + L L^T`` with ``A`` the dynamics Jacobian;
+    correct: ``K = S-(S- + R)^-1``, ``mu = mu- + K(z - mu-)``, ``S = (I - K) S-``."""
+
+    def __init__(self, *, dynamics_model: base.DynamicsModel,
+                 virtual_sensor_model: base.VirtualSensorModel):
+        super().__init__(state_dim=dynamics_model.state_dim)
+        assert isinstance(dynamics_model, base.DynamicsModel)
+        assert isinstance(virtual_sensor_model, base.VirtualSensorModel)
+        self.dynamics_model = dynamics_model
+        self.virtual_sensor_model = virtual_sensor_model
+        self._belief_mean = None
+        self._belief_covariance = None
+        self._initialized = False
+
+    @property
+    def belief_mean(self):
+        return self._belief_mean
+
+    @belief_mean.setter
+    def belief_mean(self, v):
+        self._belief_mean = v
+
+    @property
+    def belief_covariance(self):
+        return self._belief_covariance
+
+    @belief_covariance.setter
+    def belief_covariance(self, v):
+        self._belief_covariance = v
+
+    def initialize_beliefs(self, *, mean, covariance):
+        N, d = mean.shape
+        assert d == self.state_dim
+        assert covariance.shape == (N, d, d)
+        require_device(mean, "VirtualSensorExtendedKalmanFilter.initialize_beliefs")
+        self._belief_mean = mean.to(torch.float32).contiguous().clone()
+        self._belief_covariance = covariance.to(torch.float32).contiguous().clone()
+        self._initialized = True
+
+    def _predict_pieces(self, controls, ctrl_ctx=None):
+        """``(mu-, A, L)`` for the current belief mean; ``L`` is ``(d, d)`` (constant noise)."""
+        dyn = self.dynamics_model
+        mu = self._belief_mean
+        if hasattr(dyn, "predict_with_jacobian"):
+            if ctrl_ctx is None:
+                ctrl_ctx = dyn.encode_controls(controls)
+            return dyn.predict_with_jacobian(mu, ctrl_ctx)
+        mu_pred, tril = dyn(initial_states=mu, controls=controls)
+        A = dyn.jacobian(initial_states=mu, controls=controls)
+        # the C ABI takes one scale_tril per sub-filter: user models must keep it constant
+        return mu_pred.detach().contiguous(), A.detach().contiguous(), tril[0].detach().contiguous()
+
+    def _step(self, observations, controls, sensor_out=None, ctrl_ctx=None):
+        assert self._initialized, "Kalman filter not initialized!"
+        with torch.no_grad():
+            z, r_tril = sensor_out if sensor_out is not None else self.virtual_sensor_model(observations=observations)
+            mu_pred, A, L = self._predict_pieces(controls, ctrl_ctx)
+            N, d = mu_pred.shape
+            mu = torch.empty((1, N, d), dtype=torch.float32, device=mu_pred.device)
+            Sigma = self._belief_covariance.reshape(1, N, d, d).clone()
+            _abi.ekf_step(A.reshape(1, N, d, d), mu_pred.reshape(1, N, d), L.reshape(1, d, d).contiguous(),
+                          z.to(torch.float32).reshape(1, N, d).contiguous(),
+                          r_tril.to(torch.float32).reshape(1, N, d, d).contiguous(), None,
+                          mu, Sigma, None, None, fusion=0, feedback=0)
+            self._belief_mean, self._belief_covariance = mu[0], Sigma[0]
+        return self._belief_mean
+
+    def forward(self, *, observations, controls):
+        return self._step(observations, controls)
+
+    def forward_loop(self, *, observations, controls):
+        T, N = tree_leading_shape(controls)[:2]
+        flat = lambda t: t.reshape((T * N,) + tuple(t.shape[2:]))
+        with torch.no_grad():
+            z_all, r_all = self.virtual_sensor_model(observations=tree_map(observations, flat))
+            ctrl_all = None
+            if hasattr(self.dynamics_model, "predict_with_jacobian"):
+                ctrl_all = self.dynamics_model.encode_controls(tree_map(controls, flat))
+        out = []
+        for t in range(T):
+            sl = slice(t * N, (t + 1) * N)
+            out.append(self._step(tree_index(observations, t), tree_index(controls, t),
+                                  (z_all[sl], r_all[sl]),
+                                  None if ctrl_all is None else {k: v[sl] for k, v in ctrl_all.items()}))
+        return torch.stack(out, dim=0)

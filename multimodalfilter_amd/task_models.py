@@ -1,0 +1,434 @@
+"""Door- and push-task model classes with the reference's names, constructor signatures and
+``state_dict`` keys, built once from a task description.
+
+Mirrors ``/root/reference/crossmodal/door_models/*`` and ``push_models/*`` (the two
+directories differ only in ``state_dim``, noise constants, the push virtual sensor's image
+tail and the PF weight model's depth -- SURVEY.md appendix B), so both tasks come from one
+parametrised factory; ``door_models`` / ``push_models`` expose the resulting classes.
+
+Where the arithmetic runs:
+* per particle (N*M rows): dynamics and measurement MLPs -> ``csrc/particle_net.hip`` (K2)
+* per trajectory (N rows): control / observation encoders, CNNs, virtual sensors, weight
+  models -> device-side torch modules from ``layers.py`` (K4 image-encoder kernel: DESIGN.md)
+* EKF Jacobian -> forward-mode tangents in ``csrc/particle_net.hip`` (K5)
+"""
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Sequence, Set
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import base, base_models, engine, filters, layers
+
+_ROW_CHUNK = 8192  # cap on rows per encoder call (bounds conv activations for big T*N)
+
+
+@dataclass(frozen=True)
+class TaskSpec:
+    name: str                      # "door" | "push"
+    prefix: str                    # class-name prefix
+    state_dim: int
+    q_var: Sequence[float]         # dynamics noise variances (dynamics.py:20-23,85-88 / push :17-20)
+    pf_dynamics_brent: bool        # door PF uses DoorDynamicsModelBrent
+    vs_spanning_pool: bool         # push virtual sensor image tail (push_models/kf.py:50-52)
+    pf_weight_resblocks: int       # door 3 (crossmodal_pf.py:64-72), push 1
+    rmse_scale: Sequence[float]    # eval_helpers.py:166,195
+    control_dim: int = 7
+    obs_pos_dim: int = 3
+    obs_sensors_dim: int = 7
+
+
+DOOR = TaskSpec("door", "Door", 3, (0.05, 0.01, 0.01), True, False, 3,
+                (0.39479038, 0.05650279, 0.0565098))
+PUSH = TaskSpec("push", "Push", 2, (0.02, 0.02), False, True, 1, (0.0572766, 0.06118315))
+
+
+def _chunked(module: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    if x.shape[0] <= _ROW_CHUNK:
+        return module(x)
+    return torch.cat([module(x[i:i + _ROW_CHUNK]) for i in range(0, x.shape[0], _ROW_CHUNK)], dim=0)
+
+
+def blackout_rows(image: torch.Tensor) -> torch.Tensor:
+    N = image.shape[0]
+    return torch.sum(torch.abs(image.reshape((N, -1))), dim=1) < 1e-8
+
+
+def make_task_models(task: TaskSpec) -> SimpleNamespace:
+    P = task.prefix
+    D = task.state_dim
+    ns = SimpleNamespace(task=task, model_types={})
+
+    def register(cls):
+        ns.model_types[cls.__name__] = cls
+        return cls
+
+    # ------------------------------------------------------------- observation encoders
+    class _ObsEncoders:
+        def _build_obs_encoders(self, modalities, units, spanning_avg_pool=False):
+            valid_modalities = {"image", "pos", "sensors"}
+            assert len(valid_modalities | set(modalities)) == 3, "Received invalid modality"
+            assert len(modalities) > 0, "Received empty modality list"
+            self.modalities = set(modalities)
+            if "image" in self.modalities:
+                self.observation_image_layers = layers.image_encoder(units, spanning_avg_pool)
+            if "pos" in self.modalities:
+                self.observation_pos_layers = layers.vector_encoder(task.obs_pos_dim, units)
+            if "sensors" in self.modalities:
+                self.observation_sensors_layers = layers.vector_encoder(task.obs_sensors_dim, units)
+
+        def observation_features(self, observations) -> torch.Tensor:
+            assert type(observations) == dict
+            obs = []
+            if "image" in self.modalities:
+                obs.append(_chunked(self.observation_image_layers, observations["image"][:, None, :, :]))
+            if "pos" in self.modalities:
+                obs.append(self.observation_pos_layers(observations["gripper_pos"]))
+            if "sensors" in self.modalities:
+                obs.append(self.observation_sensors_layers(observations["gripper_sensors"]))
+            return torch.cat(obs, dim=1)
+
+    # ------------------------------------------------------------- R1 dynamics
+    class _Dynamics(base.DynamicsModel):
+        """``x' = x + dir(x, u) * sigmoid(gate(x, u))``, constant noise
+        (``door_models/dynamics.py:11-67,76-134``; ``push_models/dynamics.py:10-64``)."""
+
+        _brent = False
+
+        def __init__(self, units=64):
+            super().__init__(state_dim=D)
+            var = torch.tensor(list(task.q_var), dtype=torch.float32)
+            if self._brent:
+                self.Q_scale_tril_diag = nn.Parameter(torch.sqrt(var) / 8.0, requires_grad=False)
+            else:
+                self.Q_scale_tril = nn.Parameter(torch.linalg.cholesky(torch.diag(var)), requires_grad=False)
+            self.state_layers = layers.vector_encoder(D, units)
+            self.control_layers = layers.vector_encoder(task.control_dim, units)
+            self.shared_layers = nn.Sequential(
+                nn.Linear(units * 2, units),
+                layers.ResLinear(units), layers.ResLinear(units), layers.ResLinear(units),
+                nn.Linear(units, D + 1),
+            )
+            self.units = units
+            self._net = engine.PackedParticleNet(
+                encoder=self.state_layers, join=self.shared_layers[0], join_state_off=units,
+                res_blocks=[self.shared_layers[1], self.shared_layers[2], self.shared_layers[3]],
+                head=self.shared_layers[4], relu_after_join=False)
+
+        def scale_tril(self) -> torch.Tensor:
+            if self._brent:
+                return torch.diag(self.Q_scale_tril_diag)
+            return self.Q_scale_tril
+
+        # encoded protocol (see base.py)
+        def encode_controls(self, controls):
+            with torch.no_grad():
+                return {"bias": self._net.traj_bias(self.control_layers(controls))}
+
+        def propagate_encoded(self, states, ctx, noise, out=None):
+            return engine.run_dynamics(self._net, states, ctx["bias"], noise, self.scale_tril(), out=out)
+
+        def predict_with_jacobian(self, mean, ctx):
+            mu_pred, A = engine.run_jacobian(self._net, mean, ctx["bias"])
+            return mu_pred, A, self.scale_tril().contiguous()
+
+        def forward(self, *, initial_states, controls):
+            N, state_dim = initial_states.shape[:2]
+            assert state_dim == self.state_dim
+            with torch.no_grad():
+                new = engine.run_dynamics(self._net, initial_states, self.encode_controls(controls)["bias"],
+                                          None, None)
+            return new, self.scale_tril()[None, :, :].expand(N, state_dim, state_dim)
+
+        def jacobian(self, *, initial_states, controls):
+            with torch.no_grad():
+                return engine.run_jacobian(self._net, initial_states, self.encode_controls(controls)["bias"])[1]
+
+    dyn_name = f"{P}DynamicsModel"
+    DynamicsModel = type(dyn_name, (_Dynamics,), {"__doc__": _Dynamics.__doc__})
+    setattr(ns, dyn_name, DynamicsModel)
+    if task.pf_dynamics_brent:
+        PFDynamics = type(f"{P}DynamicsModelBrent", (_Dynamics,), {"_brent": True})
+        setattr(ns, f"{P}DynamicsModelBrent", PFDynamics)
+    else:
+        PFDynamics = DynamicsModel
+
+    # ------------------------------------------------------------- R2 PF measurement model
+    class MeasurementModel(base.ParticleFilterMeasurementModel, _ObsEncoders):
+        """Per-particle log-likelihood MLP on ``[obs features | state features]``
+        (``door_models/pf.py:30-107``; ``push_models/pf.py:30-109``)."""
+
+        def __init__(self, units: int = 64, modalities: Set[str] = {"image", "pos", "sensors"}):
+            super().__init__(state_dim=D)
+            self._build_obs_encoders(modalities, units, spanning_avg_pool=False)
+            self.state_layers = layers.vector_encoder(D, units)
+            k = len(self.modalities)
+            self.shared_layers = nn.Sequential(
+                nn.Linear(units * (1 + k), units), nn.ReLU(),
+                layers.ResLinear(units), layers.ResLinear(units),
+                nn.Linear(units, 1),
+            )
+            self.units = units
+            self._net = engine.PackedParticleNet(
+                encoder=self.state_layers, join=self.shared_layers[0], join_state_off=units * k,
+                res_blocks=[self.shared_layers[2], self.shared_layers[3]],
+                head=self.shared_layers[4], relu_after_join=True)
+
+        def encode_observations(self, observations):
+            with torch.no_grad():
+                return {"bias": self._net.traj_bias(self.observation_features(observations))}
+
+        def forward_encoded(self, states, ctx, *, loglik=None, combine=False, modality_logw=None,
+                            logw_stride=0):
+            N, M, _ = states.shape
+            if loglik is None:
+                loglik = torch.empty((N, M), dtype=torch.float32, device=states.device)
+            return engine.run_measure(self._net, states, ctx["bias"], modality_logw, logw_stride,
+                                      loglik, combine)
+
+        def forward(self, *, states, observations):
+            assert type(observations) == dict
+            assert len(states.shape) == 3  # (N, M, state_dim)
+            assert states.shape[2] == self.state_dim
+            with torch.no_grad():
+                return self.forward_encoded(states.contiguous(), self.encode_observations(observations))
+
+    MeasurementModel.__name__ = MeasurementModel.__qualname__ = f"{P}MeasurementModel"
+    setattr(ns, f"{P}MeasurementModel", MeasurementModel)
+
+    # ------------------------------------------------------------- R4 PF weight model
+    class CrossmodalWeightModel(base_models.CrossmodalWeightModel, _ObsEncoders):
+        """obs -> ``(N, 2)`` modality log-weights (``door_models/crossmodal_pf.py:52-106``)."""
+
+        def __init__(self, know_image_blackout: bool, units: int = 64):
+            modality_count = 2
+            super().__init__(modality_count=modality_count)
+            self.know_image_blackout = know_image_blackout
+            self._build_obs_encoders({"image", "pos", "sensors"}, units)
+            self.fusion_layers = nn.Sequential(
+                nn.Linear(units * 3, units), nn.ReLU(),
+                *[layers.ResLinear(units) for _ in range(task.pf_weight_resblocks)],
+                nn.Linear(units, modality_count),
+            )
+
+        def forward(self, *, observations):
+            N, _ = observations["gripper_pos"].shape
+            output = self.fusion_layers(self.observation_features(observations))
+            assert output.shape == (N, self.modality_count)
+            if self.know_image_blackout:
+                output[blackout_rows(observations["image"]), 0] -= np.inf
+            return output
+
+    CrossmodalWeightModel.__name__ = CrossmodalWeightModel.__qualname__ = f"{P}CrossmodalWeightModel"
+    setattr(ns, f"{P}CrossmodalWeightModel", CrossmodalWeightModel)
+
+    # ------------------------------------------------------------- particle filters
+    class _TaskParticleFilter(filters.ParticleFilter):
+        """Train/eval particle-count switch 30 <-> 300 (``door_models/pf.py:24-27``).  The
+        reference's ``train()`` drops ``super().train()``'s return value (``model.eval()``
+        yields ``None``); here it returns ``self``."""
+
+        def train(self, mode: bool = True):
+            self.num_particles = 30 if mode else 300
+            return super().train(mode)
+
+    def _pair():
+        return [MeasurementModel(modalities={"image"}), MeasurementModel(modalities={"pos", "sensors"})]
+
+    @register
+    class ParticleFilter(_TaskParticleFilter):
+        def __init__(self):
+            super().__init__(dynamics_model=PFDynamics(), measurement_model=MeasurementModel(),
+                             num_particles=30)
+
+    @register
+    class CrossmodalParticleFilter(_TaskParticleFilter):
+        def __init__(self, know_image_blackout: bool = False):
+            super().__init__(
+                dynamics_model=PFDynamics(),
+                measurement_model=base_models.CrossmodalParticleFilterMeasurementModel(
+                    measurement_models=_pair(),
+                    crossmodal_weight_model=CrossmodalWeightModel(know_image_blackout=know_image_blackout),
+                    state_dim=D),
+                num_particles=30)
+
+    @register
+    class CrossmodalParticleFilterSeq5(CrossmodalParticleFilter):
+        def __init__(self):
+            super().__init__(know_image_blackout=True)
+
+    @register
+    class UnimodalParticleFilter(_TaskParticleFilter):
+        def __init__(self):
+            super().__init__(
+                dynamics_model=PFDynamics(),
+                measurement_model=base_models.CrossmodalParticleFilterMeasurementModel(
+                    measurement_models=_pair(), crossmodal_weight_model=None, state_dim=D),
+                num_particles=30)
+
+    # ------------------------------------------------------------- R7 virtual sensor
+    class VirtualSensorModel(base.VirtualSensorModel, _ObsEncoders):
+        """obs -> ``(z, sqrt(diag(r)^2 + 1e-6 I))`` (``door_models/kf.py:31-126``;
+        ``push_models/kf.py:31-128``)."""
+
+        def __init__(self, units: int = 64, modalities: Set[str] = {"image", "pos", "sensors"},
+                     add_R_noise: float = 1e-6, noise_R_tril: torch.Tensor = None):
+            super().__init__(state_dim=D)
+            self.noise_R_tril = noise_R_tril
+            self._build_obs_encoders(modalities, units, spanning_avg_pool=task.vs_spanning_pool)
+            self.shared_layers = nn.Sequential(
+                nn.Linear(units * len(self.modalities), units * 2), nn.ReLU(),
+                layers.ResLinear(units * 2), layers.ResLinear(units * 2),
+            )
+
+            def head():
+                return nn.Sequential(nn.Linear(units, D), nn.ReLU(), layers.ResLinear(D), nn.Linear(D, D))
+
+            self.r_layer = head()
+            self.z_layer = head()
+            self.units = units
+            self.add_R_noise = torch.ones(D) * add_R_noise
+
+        def forward(self, *, observations):
+            assert type(observations) == dict
+            N, _ = observations["gripper_pos"].shape
+            shared = self.shared_layers(self.observation_features(observations))
+            z = self.z_layer(shared[:, : self.units])
+            assert z.shape == (N, self.state_dim)
+            lt_hat = self.r_layer(shared[:, self.units:]) if self.noise_R_tril is None else self.noise_R_tril
+            cov = torch.diag_embed(lt_hat) ** 2
+            if self.add_R_noise[0] > 0:
+                cov = cov + torch.diag(self.add_R_noise).to(cov.device)
+            return z, torch.sqrt(cov)
+
+    VirtualSensorModel.__name__ = VirtualSensorModel.__qualname__ = f"{P}VirtualSensorModel"
+    setattr(ns, f"{P}VirtualSensorModel", VirtualSensorModel)
+
+    @register
+    class KalmanFilter(filters.VirtualSensorExtendedKalmanFilter):
+        def __init__(self, dynamics_model=None, virtual_sensor_model=None):
+            if dynamics_model is None and virtual_sensor_model is None:
+                dynamics_model, virtual_sensor_model = DynamicsModel(), VirtualSensorModel()
+            super().__init__(dynamics_model=dynamics_model, virtual_sensor_model=virtual_sensor_model)
+
+    # ------------------------------------------------------------- R8 EKF weight model
+    class CrossmodalKalmanFilterWeightModel(base_models.CrossmodalKalmanFilterWeightModel, _ObsEncoders):
+        """obs -> ``(2, N, d)`` (``door_models/crossmodal_kf.py:101-167``).  Q3: the reference
+        *reshapes* ``(N, 2d)`` into ``(2, N, d)`` (``:158``), coupling trajectories;
+        ``fix_weight_layout=True`` does the intended ``view(N, 2, d).permute(1, 0, 2)``."""
+
+        def __init__(self, units: int = 64, state_dim: int = 2, know_image_blackout=False,
+                     fix_weight_layout: bool = False):
+            modality_count = 2
+            super().__init__(modality_count=modality_count, state_dim=state_dim)
+            self._build_obs_encoders({"image", "pos", "sensors"}, units)
+            self.weighting_type = "sigmoid"
+            self.fusion_layers = nn.Sequential(
+                nn.Linear(units * 3, units), nn.ReLU(), layers.ResLinear(units),
+                nn.Linear(units, modality_count * self.state_dim), nn.Sigmoid(),
+            )
+            self.know_image_blackout = know_image_blackout
+            self.fix_weight_layout = fix_weight_layout
+
+        def forward(self, *, observations):
+            N, _ = observations["gripper_pos"].shape
+            output = self.fusion_layers(self.observation_features(observations))
+            assert output.shape == (N, self.modality_count * self.state_dim)
+            if self.fix_weight_layout:
+                w = output.view(N, self.modality_count, self.state_dim).permute(1, 0, 2)
+            else:
+                w = output.reshape(self.modality_count, N, self.state_dim)
+            return w / (torch.sum(w, dim=0) + 1e-9)
+
+    CrossmodalKalmanFilterWeightModel.__name__ = CrossmodalKalmanFilterWeightModel.__qualname__ = \
+        f"{P}CrossmodalKalmanFilterWeightModel"
+    setattr(ns, f"{P}CrossmodalKalmanFilterWeightModel", CrossmodalKalmanFilterWeightModel)
+
+    def _modal_filters():
+        return [KalmanFilter(dynamics_model=DynamicsModel(),
+                             virtual_sensor_model=VirtualSensorModel(modalities={"image"})),
+                KalmanFilter(dynamics_model=DynamicsModel(),
+                             virtual_sensor_model=VirtualSensorModel(modalities={"pos", "sensors"}))]
+
+    def _modal_sensors():
+        return [VirtualSensorModel(modalities={"image"}), VirtualSensorModel(modalities={"pos", "sensors"})]
+
+    # ------------------------------------------------------------- R9 crossmodal EKF
+    @register
+    class CrossmodalKalmanFilter(base_models.CrossmodalKalmanFilter):
+        """``door_models/crossmodal_kf.py:20-98`` incl. the blackout override (Q2: that branch
+        skips the write-back and broadcasts ``(N, 1)`` masks; the branch is chosen by a
+        batch-global test)."""
+
+        def __init__(self, know_image_blackout=False, feedback: str = "none",
+                     fix_weight_layout: bool = False):
+            super().__init__(
+                filter_models=_modal_filters(),
+                crossmodal_weight_model=CrossmodalKalmanFilterWeightModel(
+                    state_dim=D, fix_weight_layout=fix_weight_layout),
+                state_dim=D, feedback=feedback)
+            self.know_image_blackout = know_image_blackout
+
+        def _forward_pre(self, observations, controls, pre, extra):
+            if not self.know_image_blackout:
+                return super()._forward_pre(observations, controls, pre, extra)
+            N, _ = controls.shape
+            dark = blackout_rows(observations["image"])
+            on = self._enabled_models
+            if torch.sum(dark) == 0 or np.sum(on) < len(on):
+                return super()._forward_pre(observations, controls, pre, extra)
+            with torch.no_grad():
+                raw = self.crossmodal_weight_model(observations=observations)
+                keep = (~dark).to(torch.float32)[:, None]
+                drk = dark.to(torch.float32)[:, None]
+                image_weight = drk * 1e-9 + keep * raw[0]
+                force_weight = drk * (1.0 - 1e-9) + keep * raw[1]
+                w = torch.stack([image_weight, force_weight])
+                assert w.shape == (np.sum(on), N, self.state_dim)
+                mu_f, Sigma_f, _, _ = self._fused_step(observations, controls, fusion=1, fuse_w=w,
+                                                       feedback=0, pre=pre)
+                self.weighted_covariances = Sigma_f
+            return mu_f
+
+    # ------------------------------------------------------------- R10 unimodal EKF
+    @register
+    class UnimodalKalmanFilter(base_models.UnimodalKalmanFilter):
+        def __init__(self):
+            super().__init__(filter_models=_modal_filters(), state_dim=D)
+
+    # ------------------------------------------------------------- R11 fused-sensor EKFs
+    @register
+    class MeasurementCrossmodalKalmanFilter(KalmanFilter):
+        """Q8: the reference's push variant passes the dynamics *class* (constructor fails);
+        here both tasks construct."""
+
+        def __init__(self, fix_weight_layout: bool = False):
+            super().__init__(
+                dynamics_model=DynamicsModel(),
+                virtual_sensor_model=base_models.CrossmodalVirtualSensorModel(
+                    virtual_sensor_model=_modal_sensors(),
+                    crossmodal_weight_model=CrossmodalKalmanFilterWeightModel(
+                        state_dim=D, fix_weight_layout=fix_weight_layout),
+                    state_dim=D))
+
+    @register
+    class MeasurementUnimodalKalmanFilter(KalmanFilter):
+        """Q9: the reference's push variant omits ``state_dim`` (constructor fails)."""
+
+        def __init__(self):
+            super().__init__(
+                dynamics_model=DynamicsModel(),
+                virtual_sensor_model=base_models.UnimodalVirtualSensorModel(
+                    virtual_sensor_model=_modal_sensors(), state_dim=D))
+
+    # reference class names
+    renamed = {}
+    for short, cls in list(ns.model_types.items()):
+        full = f"{P}{short}"
+        cls.__name__ = cls.__qualname__ = full
+        renamed[full] = cls
+        setattr(ns, full, cls)
+    ns.model_types = renamed
+    return ns

@@ -46,8 +46,11 @@ def make_inputs(task: om.TaskSpec, seed: int = 1234) -> Dict[str, np.ndarray]:
     }
 
 
+DEVICE = "cpu"  # tests/test_gpu_*.py switch this to "cuda" to drive the HIP engine
+
+
 def _t(x):
-    return torch.from_numpy(np.ascontiguousarray(x))
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEVICE)
 
 
 def _obs(inp, t, n, dark=False):
@@ -125,7 +128,7 @@ def run_filter_steps(model, inp, n, m, dark=False, measurement_init=False, masks
         if measurement_init:
             model.measurement_initialize_beliefs(_obs(inp, 0, n, dark))
         else:
-            cov = (torch.eye(d) * 0.1)[None].expand(n, d, d)
+            cov = (torch.eye(d, device=DEVICE) * 0.1)[None].expand(n, d, d)
             model.initialize_beliefs(mean=_t(inp["states0"][:n]), covariance=cov)
         ests = []
         for t in range(1, T_STEPS):
@@ -288,6 +291,7 @@ def case_key(case: Case, task: str, n: int, m: int) -> str:
 def run_case(case: Case, model, task: om.TaskSpec, inp, n, m):
     sd = om.seeded_state_dict(model, seed=0, gain=WEIGHT_GAIN)
     model.load_state_dict(sd)
+    model.to(DEVICE)
     return case.run(model, inp, n, m, **case.kw)
 
 

@@ -1,0 +1,207 @@
+"""The HIP engine's model classes against (a) the golden vectors the REFERENCE's crossmodal
+package produced (``tests/golden/*.npz``, see ``oracle/capture_golden.py``) and (b) the CPU
+oracle on larger seeded inputs.  Tolerance: 1e-4 relative (``north_star``), written below.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import golden_cases as gc
+from oracle import models as om
+from oracle.tf.base import ReplayNoise
+
+REL_TOL = 1e-4
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real MI355X")
+
+
+def _product(case_name: str, task: om.TaskSpec):
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import layers
+
+    ns = mmf.door_models if task.name == "door" else mmf.push_models
+    P = task.name.capitalize()
+    g = lambda suffix: getattr(ns, P + suffix)
+    mods = {"image": {"image"}, "possens": {"pos", "sensors"}, "all": {"image", "pos", "sensors"}}
+    table = {
+        "dynamics_ekf": lambda: g("DynamicsModel")(),
+        "dynamics_pf_brent": lambda: ns.DoorDynamicsModelBrent(),
+        "dynamics_jacobian": lambda: g("DynamicsModel")(),
+        "state_encoder": lambda: layers.vector_encoder(task.state_dim, 64),
+        "image_encoder": lambda: layers.image_encoder(64),
+        "image_encoder_spanning": lambda: layers.image_encoder(64, True),
+        "pf_weight_model": lambda: g("CrossmodalWeightModel")(know_image_blackout=False),
+        "pf_weight_model_blackout": lambda: g("CrossmodalWeightModel")(know_image_blackout=True),
+        "pf_crossmodal_measurement": lambda: g("CrossmodalParticleFilter")().measurement_model,
+        "pf_crossmodal_measurement_masks": lambda: g("CrossmodalParticleFilter")().measurement_model,
+        "pf_crossmodal_measurement_blackout": lambda: g("CrossmodalParticleFilterSeq5")().measurement_model,
+        "pf_unimodal_measurement": lambda: g("UnimodalParticleFilter")().measurement_model,
+        "kf_weight_model": lambda: g("CrossmodalKalmanFilterWeightModel")(state_dim=task.state_dim),
+        "crossmodal_virtual_sensor": lambda: g("MeasurementCrossmodalKalmanFilter")().virtual_sensor_model,
+        "unimodal_virtual_sensor": lambda: g("MeasurementUnimodalKalmanFilter")().virtual_sensor_model,
+        "filter_pf_single": lambda: g("ParticleFilter")(),
+        "filter_pf_crossmodal": lambda: g("CrossmodalParticleFilter")(),
+        "filter_pf_unimodal": lambda: g("UnimodalParticleFilter")(),
+        "filter_pf_crossmodal_seq5": lambda: g("CrossmodalParticleFilterSeq5")(),
+        "filter_kf": lambda: g("KalmanFilter")(),
+        "filter_kf_crossmodal": lambda: g("CrossmodalKalmanFilter")(),
+        "filter_kf_crossmodal_blackout": lambda: g("CrossmodalKalmanFilter")(know_image_blackout=True),
+        "filter_kf_crossmodal_masked": lambda: g("CrossmodalKalmanFilter")(),
+        "filter_kf_crossmodal_measinit": lambda: g("CrossmodalKalmanFilter")(),
+        "filter_kf_unimodal": lambda: g("UnimodalKalmanFilter")(),
+        "filter_kf_unimodal_masked": lambda: g("UnimodalKalmanFilter")(),
+        "filter_kf_meas_crossmodal": lambda: g("MeasurementCrossmodalKalmanFilter")(),
+        "filter_kf_meas_unimodal": lambda: g("MeasurementUnimodalKalmanFilter")(),
+    }
+    for tag, m in mods.items():
+        table[f"pf_measurement_{tag}"] = (lambda m: lambda: g("MeasurementModel")(modalities=set(m)))(m)
+        table[f"virtual_sensor_{tag}"] = (lambda m: lambda: g("VirtualSensorModel")(modalities=set(m)))(m)
+    return table[case_name]()
+
+
+_PARAMS = [(c, t, n, m) for c in gc.CASES for t in c.tasks for (n, m) in c.shapes]
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return {t: np.load(os.path.join(golden_dir, f"{t}.npz")) for t in ("door", "push")}
+
+
+@pytest.fixture()
+def on_gpu():
+    _need_gpu()
+    gc.DEVICE = "cuda"
+    yield
+    gc.DEVICE = "cpu"
+
+
+@pytest.mark.parametrize("case,tname,n,m", _PARAMS,
+                         ids=[gc.case_key(c, t, n, m) for c, t, n, m in _PARAMS])
+def test_engine_matches_reference_vectors(golden, on_gpu, case, tname, n, m):
+    task = om.TASKS[tname]
+    z = golden[tname]
+    inp = {k[len("input/"):]: z[k] for k in z.files if k.startswith("input/")}
+    model = _product(case.name, task)
+    out = gc.run_case(case, model, task, inp, n, m)
+    prefix = gc.case_key(case, tname, n, m) + "/"
+    expected = {k[len(prefix):]: z[k] for k in z.files if k.startswith(prefix)}
+    assert set(out) == set(expected) and expected
+    for k, want in expected.items():
+        got = out[k]
+        assert got.shape == want.shape, k
+        np.testing.assert_array_equal(np.isneginf(got), np.isneginf(want), err_msg=k)
+        fin = np.isfinite(want)
+        scale = max(1.0, float(np.abs(want[fin]).max()))
+        err = float(np.abs(got[fin] - want[fin]).max()) / scale
+        assert err < REL_TOL, f"{k}: rel err {err:.3e}"
+
+
+@pytest.mark.parametrize("tname,kind,cls", [
+    ("door", "crossmodal", "DoorCrossmodalParticleFilter"),
+    ("push", "crossmodal", "PushCrossmodalParticleFilter"),
+    ("door", "unimodal", "DoorUnimodalParticleFilter"),
+    ("push", "single", "PushParticleFilter"),
+])
+@pytest.mark.parametrize("mode", ["systematic", "multinomial"])
+def test_particle_filter_tracks_oracle(tname, kind, cls, mode):
+    """Whole PF recursion, N=6, M=1024, T=5, identical pre-drawn randomness: posterior
+    means within 1e-4 relative and resample indices equal (bit-exact) at every step."""
+    _need_gpu()
+    import multimodalfilter_amd as mmf
+
+    dev = torch.device("cuda:0")
+    task = om.TASKS[tname]
+    d, N, M, T = task.state_dim, 6, 1024, 5
+    g = torch.Generator().manual_seed(11)
+    obs = {"image": (torch.randn((T, N, 32, 32), generator=g) * 0.5).clamp(-1, 1),
+           "gripper_pos": torch.randn((T, N, 3), generator=g),
+           "gripper_sensors": torch.randn((T, N, 7), generator=g)}
+    ctrl = torch.randn((T, N, 7), generator=g)
+    x0 = torch.randn((N, d), generator=g)
+    eps0 = torch.randn((N, M, d), generator=g)
+    eps = [torch.randn((N, M, d), generator=g) for _ in range(T)]
+    us = [torch.rand((N,) if mode == "systematic" else (N, M), generator=g) for _ in range(T)]
+
+    oracle = om.ParticleFilter(task, kind, resample_mode=mode)
+    oracle.load_state_dict(om.seeded_state_dict(oracle, seed=3, gain=1.0))
+    oracle.eval()
+    oracle.num_particles = M
+    oracle.noise = ReplayNoise([eps0] + eps, us)
+    cov = (torch.eye(d) * 0.1)[None].expand(N, d, d)
+    want, want_idx = [], []
+    with torch.no_grad():
+        oracle.initialize_beliefs(mean=x0, covariance=cov)
+        for t in range(T):
+            want.append(oracle(observations={k: v[t] for k, v in obs.items()}, controls=ctrl[t]))
+            want_idx.append(oracle.last_resample_indices.clone())
+
+    engine = mmf.model_types(tname)[cls]()
+    engine.load_state_dict(oracle.state_dict())
+    engine.to(dev)
+    engine.eval()
+    engine.num_particles = M
+    engine.resample_mode = mode
+    engine.record_indices = True
+    engine.noise = mmf.ReplayNoise([eps0] + eps, us)
+    engine.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
+    same = 0
+    for t in range(T):
+        est = engine(observations={k: v[t].to(dev) for k, v in obs.items()}, controls=ctrl[t].to(dev))
+        scale = max(1.0, float(want[t].abs().max()))
+        assert float((est.cpu() - want[t]).abs().max()) / scale < REL_TOL, f"step {t}"
+        same += int((engine.last_resample_indices.cpu().long() == want_idx[t]).sum())
+    assert same == T * N * M, f"{T * N * M - same} resample indices differ"
+
+    # forward_loop (observation encoders batched over T*N) gives the same trajectory
+    engine.noise = mmf.ReplayNoise([eps0] + eps, us)
+    engine.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
+    loop = engine.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
+    torch.testing.assert_close(loop.cpu(), torch.stack(want), rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("tname,cls,okw", [
+    ("door", "DoorKalmanFilter", {}),
+    ("door", "DoorCrossmodalKalmanFilter", {}),
+    ("push", "PushCrossmodalKalmanFilter", {"feedback": "belief", "fix_weight_layout": True}),
+    ("push", "PushUnimodalKalmanFilter", {}),
+])
+def test_kalman_filters_track_oracle(tname, cls, okw):
+    """EKF recursions, N=32 (config 1's batch), T=6: means and covariances within 1e-4."""
+    _need_gpu()
+    import multimodalfilter_amd as mmf
+
+    dev = torch.device("cuda:0")
+    task = om.TASKS[tname]
+    d, N, T = task.state_dim, 32, 6
+    g = torch.Generator().manual_seed(5)
+    obs = {"image": (torch.randn((T, N, 32, 32), generator=g) * 0.5).clamp(-1, 1),
+           "gripper_pos": torch.randn((T, N, 3), generator=g),
+           "gripper_sensors": torch.randn((T, N, 7), generator=g)}
+    ctrl = torch.randn((T, N, 7), generator=g)
+    x0 = torch.randn((N, d), generator=g)
+    cov = (torch.eye(d) * 0.1)[None].expand(N, d, d)
+    oracle = om.build(cls, **okw)
+    oracle.load_state_dict(om.seeded_state_dict(oracle, seed=4, gain=1.0))
+    oracle.eval()
+    with torch.no_grad():
+        oracle.initialize_beliefs(mean=x0, covariance=cov)
+        want = oracle.forward_loop(observations=obs, controls=ctrl)
+    engine = mmf.model_types(tname)[cls](**okw)
+    engine.load_state_dict(oracle.state_dict())
+    engine.to(dev).eval()
+    engine.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
+    got = engine.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
+    scale = max(1.0, float(want.abs().max()))
+    assert float((got.cpu() - want).abs().max()) / scale < REL_TOL
+    subs_o = list(oracle.filter_models) if hasattr(oracle, "filter_models") else [oracle]
+    subs_e = list(engine.filter_models) if hasattr(engine, "filter_models") else [engine]
+    for fo, fe in zip(subs_o, subs_e):
+        s = max(1.0, float(fo._belief_covariance.abs().max()))
+        assert float((fe._belief_covariance.cpu() - fo._belief_covariance).abs().max()) / s < REL_TOL
