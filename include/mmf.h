@@ -60,7 +60,8 @@ int mmf_version(void);
  *                              mode 1/2: -log(M_out) (may alias logw_in when M_out == M)
  *  indices_out (N, M_out) int32 ancestor indices, or null
  *  mode        0 none, 1 systematic, 2 multinomial
- * Limits: d <= 4; M, M_out <= 65536; modes 1/2 keep the 8-byte CDF in LDS: M <= 16384.
+ * Limits: d <= 4; M, M_out <= 65536; mode 0 stages 4 B/particle in LDS (M <= 40000),
+ *         modes 1/2 keep the 8-byte CDF there (M <= 20000); larger -> MMF_ETOOLARGE.
  */
 int mmf_pf_reweight_resample(const float* loglik, const float* logw_in, const float* states_in,
                              const float* u, float* estimate, float* states_out,

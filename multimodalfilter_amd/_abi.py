@@ -94,6 +94,12 @@ def ptr(t: torch.Tensor, *, dtype=torch.float32):
     return t.data_ptr()
 
 
+def _on(t: torch.Tensor):
+    """Device context of ``t``; CPU tensors are refused here, before any launch."""
+    ptr(t, dtype=t.dtype)
+    return torch.cuda.device(t.device)
+
+
 def stream_of(t: torch.Tensor):
     return torch.cuda.current_stream(t.device).cuda_stream
 
@@ -104,7 +110,7 @@ def pf_reweight_resample(loglik, logw_in, states_in, u, estimate, states_out, lo
     N, M, d = states_in.shape
     M_out = logw_out.shape[1]
     assert loglik.shape == (N, M) and logw_in.shape == (N, M) and estimate.shape == (N, d)
-    with torch.cuda.device(states_in.device):
+    with _on(states_in):
         _check(load().mmf_pf_reweight_resample(
             ptr(loglik), ptr(logw_in), ptr(states_in), ptr(u), ptr(estimate), ptr(states_out),
             ptr(logw_out), ptr(indices_out, dtype=torch.int32), N, M, M_out, d, mode,
@@ -116,27 +122,27 @@ def particle_net_floats(n_res: int) -> int:
 
 
 def pack_particle_net(desc: MmfParticleNetDesc, packed: torch.Tensor):
-    with torch.cuda.device(packed.device):
+    with _on(packed):
         _check(load().mmf_pack_particle_net(ctypes.byref(desc), ptr(packed), stream_of(packed)),
                "mmf_pack_particle_net")
 
 
 def pf_dynamics(packed, n_res, states_in, traj_bias, noise, scale_tril, states_out, N, M, d):
-    with torch.cuda.device(states_in.device):
+    with _on(states_in):
         _check(load().mmf_pf_dynamics(ptr(packed), n_res, ptr(states_in), ptr(traj_bias), ptr(noise),
                                       ptr(scale_tril), ptr(states_out), N, M, d,
                                       stream_of(states_in)), "mmf_pf_dynamics")
 
 
 def pf_measure(packed, n_res, states, traj_bias, modality_logw, logw_stride, loglik, combine, N, M, d):
-    with torch.cuda.device(states.device):
+    with _on(states):
         _check(load().mmf_pf_measure(ptr(packed), n_res, ptr(states), ptr(traj_bias),
                                      ptr(modality_logw), logw_stride, ptr(loglik), int(combine),
                                      N, M, d, stream_of(states)), "mmf_pf_measure")
 
 
 def dynamics_jacobian(packed, n_res, states_in, traj_bias, states_out, jac, N, d):
-    with torch.cuda.device(states_in.device):
+    with _on(states_in):
         _check(load().mmf_dynamics_jacobian(ptr(packed), n_res, ptr(states_in), ptr(traj_bias),
                                             ptr(states_out), ptr(jac), N, d,
                                             stream_of(states_in)), "mmf_dynamics_jacobian")
@@ -145,7 +151,7 @@ def dynamics_jacobian(packed, n_res, states_in, traj_bias, states_out, jac, N, d
 def ekf_step(A, mu_pred, q_tril, z, r_tril, fuse_w, mu, Sigma, mu_f, Sigma_f, fusion: int,
              feedback: int):
     K, N, d = mu_pred.shape
-    with torch.cuda.device(mu_pred.device):
+    with _on(mu_pred):
         _check(load().mmf_ekf_step(ptr(A), ptr(mu_pred), ptr(q_tril), ptr(z), ptr(r_tril),
                                    ptr(fuse_w), ptr(mu), ptr(Sigma), ptr(mu_f), ptr(Sigma_f),
                                    N, d, K, fusion, feedback, stream_of(mu_pred)), "mmf_ekf_step")
