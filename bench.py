@@ -71,7 +71,11 @@ def run_pf(f, traj_dev, noise_dev, M, mode="systematic"):
     return evaluation.run_filter(f, traj_dev)
 
 
-def cpu_baseline_pf(wl, engine_filter, state_dim, cores, sample_batch=32, sample_steps=8, warm=1):
+CPU_THREADS = 16  # measured on the GPU box's host (2 x EPYC 9575F, 256 hw threads): the oracle
+                  # step is fastest at 16 torch threads (8: 0.88x, 32: 0.84x, 64: 0.45x, 128: 0.24x)
+
+
+def cpu_baseline_pf(wl, engine_filter, state_dim, cores, sample_batch=32, sample_steps=12, warm=1):
     """The oracle (pure torch, fp32, CPU) on a bounded sample of the same workload, with the
     engine run on the identical sample (same weights, observations, noise) for parity."""
     from multimodalfilter_amd import synthetic
@@ -108,10 +112,15 @@ def cpu_baseline_pf(wl, engine_filter, state_dim, cores, sample_batch=32, sample
     got = run_pf(engine_filter, to_device(traj, dev),
                  (eps0.to(dev), [e.to(dev) for e in eps], [u.to(dev) for u in us]), M).cpu()
     scale = max(1.0, float(want.abs().max()))
+    rm_e = ((got - traj["states"][1:]) ** 2).mean((0, 1)).sqrt()
+    rm_o = ((want - traj["states"][1:]) ** 2).mean((0, 1)).sqrt()
     parity = {
-        "max_rel_err_posterior_mean": float((got - want).abs().max()) / scale,
-        "rmse_engine": [float(x) for x in ((got - traj["states"][1:]) ** 2).mean((0, 1)).sqrt()],
-        "rmse_oracle": [float(x) for x in ((want - traj["states"][1:]) ** 2).mean((0, 1)).sqrt()],
+        # step 1 isolates kernel arithmetic; later steps also carry the (rare) resampling
+        # flips that a 1e-7 log-likelihood difference can cause ("Parity")
+        "max_rel_err_posterior_mean_step1": float((got[0] - want[0]).abs().max()) / scale,
+        "max_rel_err_posterior_mean_all_steps": float((got - want).abs().max()) / scale,
+        "rmse_engine": [float(x) for x in rm_e], "rmse_oracle": [float(x) for x in rm_o],
+        "rmse_rel_diff": float(((rm_e - rm_o).abs() / rm_o).max()),
     }
     return {"value": cpu_rate, "unit": "particle-steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle PF (oracle/), {wl['cls']}, batch {sample_batch} x {M} particles x "
@@ -263,7 +272,7 @@ def main():
         out["roofline"] = None
 
     if world == 1 and not args.no_cpu_baseline:
-        cores = os.cpu_count() or 1
+        cores = min(CPU_THREADS, os.cpu_count() or 1)
         if wl["kind"] == "pf":
             base, parity = cpu_baseline_pf(wl, f, d, cores)
         else:

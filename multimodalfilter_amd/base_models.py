@@ -173,7 +173,9 @@ class _FusedKalmanFilters(base.Filter, _EnabledModels):
         obs_f, ctrl_f = tree_map(observations, flat), tree_map(controls, flat)
         pre = {"sensor": [], "ctrl": []}
         for f in self.filter_models:
-            pre["sensor"].append(f.virtual_sensor_model(observations=obs_f))
+            # one time step per call: encoder batch shapes do not depend on T
+            outs = [f.virtual_sensor_model(observations=tree_index(observations, t)) for t in range(T)]
+            pre["sensor"].append((torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])))
             pre["ctrl"].append(f.dynamics_model.encode_controls(ctrl_f)
                                if hasattr(f.dynamics_model, "predict_with_jacobian") else None)
         return pre, obs_f

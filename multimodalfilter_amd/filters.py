@@ -147,24 +147,25 @@ class ParticleFilter(base.Filter):
         return self._step(observations, controls)
 
     def forward_loop(self, *, observations, controls) -> torch.Tensor:
-        """Sequential in ``t``; everything that does not depend on the belief (control and
-        observation encoders, CNNs, modality weights) is evaluated once for all ``T*N`` rows."""
+        """Sequential in ``t``.  Everything that does not depend on the belief (control and
+        observation encoders, CNNs, modality weights) is evaluated ahead of the recursion,
+        one time step per call so that encoder batch shapes do not depend on ``T``."""
         T, N = tree_leading_shape(controls)[:2]
         assert tree_leading_shape(observations)[:2] == (T, N)
-        flat = lambda t: t.reshape((T * N,) + tuple(t.shape[2:]))
-        obs_all = ctrl_all = None
+        obs_ctx = ctrl_ctx = None
         with torch.no_grad():
             if hasattr(self.measurement_model, "forward_encoded"):
-                obs_all = self.measurement_model.encode_observations(tree_map(observations, flat))
+                obs_ctx = [self.measurement_model.encode_observations(tree_index(observations, t))
+                           for t in range(T)]
             if hasattr(self.dynamics_model, "propagate_encoded"):
-                ctrl_all = self.dynamics_model.encode_controls(tree_map(controls, flat))
+                flat = tree_map(controls, lambda x: x.reshape((T * N,) + tuple(x.shape[2:])))
+                ctrl_all = self.dynamics_model.encode_controls(flat)
+                ctrl_ctx = [{k: v[t * N:(t + 1) * N] for k, v in ctrl_all.items()} for t in range(T)]
         out = []
         for t in range(T):
-            sl = slice(t * N, (t + 1) * N)
-            out.append(self._step(
-                tree_index(observations, t), tree_index(controls, t),
-                None if obs_all is None else {k: v[sl] for k, v in obs_all.items()},
-                None if ctrl_all is None else {k: v[sl] for k, v in ctrl_all.items()}))
+            out.append(self._step(tree_index(observations, t), tree_index(controls, t),
+                                  None if obs_ctx is None else obs_ctx[t],
+                                  None if ctrl_ctx is None else ctrl_ctx[t]))
         return torch.stack(out, dim=0)
 
 
@@ -244,14 +245,13 @@ class VirtualSensorExtendedKalmanFilter(base.Filter):
         T, N = tree_leading_shape(controls)[:2]
         flat = lambda t: t.reshape((T * N,) + tuple(t.shape[2:]))
         with torch.no_grad():
-            z_all, r_all = self.virtual_sensor_model(observations=tree_map(observations, flat))
+            sensors = [self.virtual_sensor_model(observations=tree_index(observations, t)) for t in range(T)]
             ctrl_all = None
             if hasattr(self.dynamics_model, "predict_with_jacobian"):
                 ctrl_all = self.dynamics_model.encode_controls(tree_map(controls, flat))
         out = []
         for t in range(T):
             sl = slice(t * N, (t + 1) * N)
-            out.append(self._step(tree_index(observations, t), tree_index(controls, t),
-                                  (z_all[sl], r_all[sl]),
+            out.append(self._step(tree_index(observations, t), tree_index(controls, t), sensors[t],
                                   None if ctrl_all is None else {k: v[sl] for k, v in ctrl_all.items()}))
         return torch.stack(out, dim=0)

@@ -164,8 +164,11 @@ def test_k1_full_size_properties():
 
 # ------------------------------------------------------------------------------ K3
 def _spd(rng, K, N, d):
-    a = rng.standard_normal((K, N, d, d)).astype(np.float32)
-    return (a @ a.transpose(0, 1, 3, 2) * 0.2 + 0.1 * np.eye(d, dtype=np.float32)).astype(np.float32)
+    """Covariances with eigenvalues in [0.05, 0.5] (condition number <= 10, like a belief
+    that started at 0.1 I)."""
+    q, _ = np.linalg.qr(rng.standard_normal((K, N, d, d)))
+    lam = rng.uniform(0.05, 0.5, (K, N, d))
+    return np.einsum("knij,knj,knlj->knil", q, lam, q).astype(np.float32)
 
 
 @pytest.mark.parametrize("d", [1, 2, 3, 4])
@@ -179,7 +182,8 @@ def test_k3_matches_oracle_algebra(d, K, fusion):
     mu_pred = rng.standard_normal((K, N, d)).astype(np.float32)
     L = np.tril(0.2 * rng.standard_normal((K, d, d))).astype(np.float32)
     z = rng.standard_normal((K, N, d)).astype(np.float32)
-    r = (np.tril(0.3 * rng.standard_normal((K, N, d, d))) + 0.3 * np.eye(d)).astype(np.float32)
+    r = (np.tril(0.05 * rng.standard_normal((K, N, d, d)), -1)
+         + rng.uniform(0.3, 0.6, (K, N, d, 1)) * np.eye(d)).astype(np.float32)
     S0 = _spd(rng, K, N, d)
     w = rng.uniform(0.05, 1.0, (K, N, d)).astype(np.float32)
     T = lambda a: torch.from_numpy(a).to(dev)
