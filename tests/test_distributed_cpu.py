@@ -1,0 +1,114 @@
+"""The N>1 path on CPU: two ``gloo`` ranks shard the trajectory axis, each filters its own
+shard, and the per-sequence squared errors are all-gathered (the only collective of the
+path, ``multimodalfilter_amd/distributed.py``).  The HIP engine cannot run here, so the
+CPU oracle stands in as the per-rank filter: what is under test is the sharding, the ragged
+all-gather and the shard-invariance of the result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from multimodalfilter_amd import distributed, evaluation, synthetic
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _filter_oracle(traj, noise, M, d):
+    from oracle import models as om
+    from oracle.tf.base import ReplayNoise
+
+    torch.set_num_threads(1)
+    f = om.build("PushUnimodalParticleFilter")
+    f.load_state_dict(om.seeded_state_dict(f, seed=5, gain=1.0))
+    f.eval()
+    f.num_particles = M
+    eps0, eps, us = noise
+    f.noise = ReplayNoise([eps0] + eps, us)
+    N = traj["states"].shape[1]
+    cov = (torch.eye(d) * 0.1)[None].expand(N, d, d)
+    with torch.no_grad():
+        f.initialize_beliefs(mean=traj["states"][0], covariance=cov)
+        return f.forward_loop(observations={k: traj[k][1:] for k in ("image", "gripper_pos", "gripper_sensors")},
+                              controls=traj["controls"][1:])
+
+
+def _slice_noise(noise, lo, hi):
+    eps0, eps, us = noise
+    return eps0[lo:hi], [e[lo:hi] for e in eps], [u[lo:hi] for u in us]
+
+
+def _worker(rank, world, port, N, T, M, d, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, w, _ = distributed.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    traj = synthetic.make_trajectories(state_dim=d, T=T, N=N, seed=9)
+    noise = synthetic.draw_filter_noise(T=T, N=N, M=M, state_dim=d, seed=10)
+    lo, hi = distributed.shard_bounds(N, rank, world)
+    mine = distributed.shard_trajectories(traj, rank, world)
+    assert mine["states"].shape[1] == hi - lo
+    pred = _filter_oracle(mine, _slice_noise(noise, lo, hi), M, d)
+    mse = evaluation.per_trajectory_mse(pred, mine["states"][1:], start=1)
+    distributed.barrier()
+    gathered = distributed.all_gather_rows(mse)
+    slowest = distributed.max_over_ranks(float(rank + 1), torch.device("cpu"))
+    assert slowest == float(world)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "gathered.npy"), gathered.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharding_matches_single_process(tmp_path):
+    N, T, M, d = 5, 3, 16, 2  # ragged: rank 0 owns 3 trajectories, rank 1 owns 2
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, N, T, M, d, str(tmp_path)), nprocs=2, join=True)
+    gathered = np.load(tmp_path / "gathered.npy")
+    traj = synthetic.make_trajectories(state_dim=d, T=T, N=N, seed=9)
+    noise = synthetic.draw_filter_noise(T=T, N=N, M=M, state_dim=d, seed=10)
+    pred = _filter_oracle(traj, noise, M, d)
+    want = evaluation.per_trajectory_mse(pred, traj["states"][1:], start=1).numpy()
+    assert gathered.shape == (N, d)
+    np.testing.assert_allclose(gathered, want, rtol=1e-5, atol=1e-7)  # PF path is shard-invariant
+
+
+def test_shard_bounds_cover_the_batch():
+    for n in (1, 7, 256, 8192):
+        for world in (1, 2, 3, 8):
+            spans = [distributed.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_eval_arithmetic_matches_reference_vectors(golden_dir):
+    """H1 on the product side: same numbers as the reference's run_eval (tests/golden/eval.npz)."""
+    z = np.load(os.path.join(golden_dir, "eval.npz"))
+    for tname in ("door", "push"):
+        pred = torch.from_numpy(z[f"{tname}/pred"])
+        true = torch.from_numpy(z[f"{tname}/true"][1:])
+        rmse = evaluation.raw_rmse(evaluation.per_trajectory_mse(pred, true))
+        res = evaluation.task_metrics(tname, rmse)
+        for k, v in res.items():
+            np.testing.assert_allclose(np.asarray(v), z[f"{tname}/{k}"], rtol=1e-6)
+
+
+def test_synthetic_generator_is_seeded_and_shaped():
+    a = synthetic.make_trajectories(state_dim=3, T=4, N=3, seed=1, image_blackout_ratio=0.4)
+    b = synthetic.make_trajectories(state_dim=3, T=4, N=3, seed=1, image_blackout_ratio=0.4)
+    for k in a:
+        assert torch.equal(a[k], b[k])
+    assert a["states"].shape == (5, 3, 3) and a["image"].shape == (5, 3, 32, 32)
+    assert a["controls"].shape == (5, 3, 7) and set(a["controls"][..., 6].unique().tolist()) <= {-1.0, 1.0}
+    assert float(a["image"].abs().max()) <= 1.0
+    dark = (a["image"].abs().sum((-1, -2)) == 0)
+    assert 0 < int(dark.sum()) < dark.numel()
