@@ -146,6 +146,34 @@ int mmf_dynamics_jacobian(const float* packed, int n_res, const float* states_in
                           const float* traj_bias, float* states_out, float* jac, int N, int d,
                           void* stream);
 
+/* ---------------------------------------------------------------- K4: image encoder
+ * Replaces observation_image_layers (crossmodal/door_models/layers.py:43-63;
+ * push_models/layers.py:91-104, default variant): Conv 1->32 k5, ReLU, ResConv 32 k3,
+ * Conv 32->16 k3, ReLU, Conv 16->8 k3, Flatten, Linear 8192->64, ReLU, ResLinear 64 --
+ * as implicit-GEMM convolutions on v_mfma_f32_16x16x4_f32 with bias / skip / ReLU fused,
+ * one launch per layer for ALL encoders of a step (they share the image, not the weights).
+ */
+typedef struct MmfImageEncoderDesc {
+  const float* conv_w[5];   /* torch layouts: (32,1,5,5) (32,32,3,3) (32,32,3,3) (16,32,3,3) (8,16,3,3) */
+  const float* conv_b[5];
+  const float* fc_w;        /* (64, 8192) */
+  const float* fc_b;        /* (64) */
+  const float* res_w[2];    /* ResLinear(64): block1, block2 (64,64) */
+  const float* res_b[2];
+} MmfImageEncoderDesc;      /* host struct holding device pointers */
+
+size_t mmf_image_encoder_floats(void);                 /* floats of one packed encoder blob */
+size_t mmf_image_encoder_workspace_bytes(int n_images, int n_nets);
+int mmf_pack_image_encoder(const MmfImageEncoderDesc* desc /* host */, float* packed, void* stream);
+
+/*  packed    host array of n_nets (1..4) device pointers to packed encoder blobs
+ *  images    (N, 32, 32)        shared by every encoder
+ *  feat      (n_nets, N, 64)    out
+ *  workspace >= mmf_image_encoder_workspace_bytes(N, n_nets) bytes of device memory
+ */
+int mmf_image_encoder(const float* const* packed, int n_nets, const float* images, float* feat,
+                      void* workspace, int N, void* stream);
+
 /* ---------------------------------------------------------------- K3: EKF algebra + fusion
  * Replaces torchfilter's EKF predict/update (A S A^T + L L^T; K = S-(S- + R)^-1;
  * mu = mu- + K(z - mu-); S = (I-K)S-) for K sub-filters and the reference's

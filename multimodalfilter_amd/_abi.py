@@ -34,6 +34,11 @@ class MmfParticleNetDesc(Structure):
     ]
 
 
+class MmfImageEncoderDesc(Structure):
+    _fields_ = [("conv_w", _FP * 5), ("conv_b", _FP * 5), ("fc_w", _FP), ("fc_b", _FP),
+                ("res_w", _FP * 2), ("res_b", _FP * 2)]
+
+
 SIGNATURES = {
     "mmf_version": (c_int, []),
     "mmf_pf_reweight_resample": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP,
@@ -45,6 +50,10 @@ SIGNATURES = {
     "mmf_pf_measure": (c_int, [_FP, c_int, _FP, _FP, _FP, c_int, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_dynamics_jacobian": (c_int, [_FP, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_ekf_step": (c_int, [_FP] * 10 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmf_image_encoder_floats": (c_size_t, []),
+    "mmf_image_encoder_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "mmf_pack_image_encoder": (c_int, [POINTER(MmfImageEncoderDesc), _FP, c_void_p]),
+    "mmf_image_encoder": (c_int, [POINTER(c_void_p), c_int, _FP, _FP, _FP, c_int, c_void_p]),
 }
 
 _lib = None
@@ -155,3 +164,28 @@ def ekf_step(A, mu_pred, q_tril, z, r_tril, fuse_w, mu, Sigma, mu_f, Sigma_f, fu
         _check(load().mmf_ekf_step(ptr(A), ptr(mu_pred), ptr(q_tril), ptr(z), ptr(r_tril),
                                    ptr(fuse_w), ptr(mu), ptr(Sigma), ptr(mu_f), ptr(Sigma_f),
                                    N, d, K, fusion, feedback, stream_of(mu_pred)), "mmf_ekf_step")
+
+
+def image_encoder_floats() -> int:
+    return int(load().mmf_image_encoder_floats())
+
+
+def image_encoder_workspace_bytes(n_images: int, n_nets: int) -> int:
+    return int(load().mmf_image_encoder_workspace_bytes(n_images, n_nets))
+
+
+def pack_image_encoder(desc: MmfImageEncoderDesc, packed: torch.Tensor):
+    with _on(packed):
+        _check(load().mmf_pack_image_encoder(ctypes.byref(desc), ptr(packed), stream_of(packed)),
+               "mmf_pack_image_encoder")
+
+
+def image_encoder(blobs, images: torch.Tensor, feat: torch.Tensor, workspace: torch.Tensor):
+    n = len(blobs)
+    arr = (c_void_p * n)(*[ptr(b) for b in blobs])
+    N = images.shape[0]
+    assert tuple(images.shape[1:]) == (32, 32) and tuple(feat.shape) == (n, N, 64)
+    with _on(images):
+        _check(load().mmf_image_encoder(arr, n, ptr(images), ptr(feat),
+                                        ptr(workspace, dtype=torch.uint8), N, stream_of(images)),
+               "mmf_image_encoder")

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _abi, base, filters
-from .engine import require_device
+from .engine import call_with_image_feat, encode_observation_images, require_device
 from .utils import tree_index, tree_leading_shape, tree_map
 
 
@@ -81,13 +81,19 @@ class CrossmodalParticleFilterMeasurementModel(base.ParticleFilterMeasurementMod
         """Everything that depends on the observation only: each unimodal model's hoisted
         join-layer bias and the modality log-weights."""
         ctx = {}
-        for i, m in enumerate(self.measurement_models):
-            if self._enabled_models[i]:
-                for k, v in m.encode_observations(observations).items():
+        live = [m if self._enabled_models[i] else None for i, m in enumerate(self.measurement_models)]
+        # every image encoder of this step (unimodal models + weight model) in one K4 batch
+        feats = encode_observation_images(live + [self.crossmodal_weight_model], observations)
+        for i, m in enumerate(live):
+            if m is not None:
+                enc = call_with_image_feat(m.encode_observations, feats[i], observations=observations) \
+                    if feats[i] is not None else m.encode_observations(observations)
+                for k, v in enc.items():
                     ctx[f"m{i}.{k}"] = v
         if self.crossmodal_weight_model is not None:
-            ctx["modality_log_weights"] = self.crossmodal_weight_model(
-                observations=observations).to(torch.float32).contiguous()
+            ctx["modality_log_weights"] = call_with_image_feat(
+                self.crossmodal_weight_model, feats[-1], observations=observations
+            ).to(torch.float32).contiguous()
         return ctx
 
     def forward_encoded(self, states: torch.Tensor, ctx) -> torch.Tensor:
@@ -162,36 +168,36 @@ class _FusedKalmanFilters(base.Filter, _EnabledModels):
         for model in self.filter_models:
             model.initialize_beliefs(mean=mean, covariance=covariance)
 
-    def _live(self):
-        return [f for i, f in enumerate(self.filter_models) if self._enabled_models[i]]
+    # -- belief-independent work of one time step: virtual sensors (+ fusion weights), with
+    #    every image encoder involved batched into one K4 launch sequence
+    def _encode_step(self, observations):
+        on = self._enabled_models
+        sensors = [f.virtual_sensor_model if on[i] else None for i, f in enumerate(self.filter_models)]
+        wm = getattr(self, "crossmodal_weight_model", None)
+        if wm is not None and np.sum(on) < len(on):
+            wm = None  # masked fusion uses 0/1 weights (crossmodal_kf.py:124-133)
+        feats = encode_observation_images(sensors + [wm], observations)
+        out = {"sensor": [None if m is None else call_with_image_feat(m, feats[i], observations=observations)
+                          for i, m in enumerate(sensors)],
+               "weights": None if wm is None else call_with_image_feat(wm, feats[-1], observations=observations)}
+        return out
 
-    def _encode_loop_inputs(self, observations, controls):
-        """Belief-independent work for a whole ``forward_loop``: virtual sensors, control
-        encoders (and, in subclasses, fusion weights) over all ``T*N`` rows."""
-        T, N = tree_leading_shape(controls)[:2]
-        flat = lambda t: t.reshape((T * N,) + tuple(t.shape[2:]))
-        obs_f, ctrl_f = tree_map(observations, flat), tree_map(controls, flat)
-        pre = {"sensor": [], "ctrl": []}
-        for f in self.filter_models:
-            # one time step per call: encoder batch shapes do not depend on T
-            outs = [f.virtual_sensor_model(observations=tree_index(observations, t)) for t in range(T)]
-            pre["sensor"].append((torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])))
-            pre["ctrl"].append(f.dynamics_model.encode_controls(ctrl_f)
-                               if hasattr(f.dynamics_model, "predict_with_jacobian") else None)
-        return pre, obs_f
+    def _encode_controls(self, controls):
+        return [f.dynamics_model.encode_controls(controls)
+                if hasattr(f.dynamics_model, "predict_with_jacobian") else None
+                for f in self.filter_models]
 
-    def _fused_step(self, observations, controls, *, fusion: int, fuse_w, feedback: int, pre=None):
-        """Run every enabled sub-filter's predict + correct and the fusion in one launch.
-        Returns ``(mu_fused, Sigma_fused)`` (``None`` for ``fusion == 0``)."""
+    def _fused_step(self, controls, enc, ctrl, *, fusion: int, fuse_w, feedback: int):
+        """Every enabled sub-filter's predict + correct and the fusion in ONE launch.
+        Returns ``(mu_fused, Sigma_fused, mu_k, Sigma_k)`` (fused ones ``None`` for fusion 0)."""
         live_idx = [i for i, on in enumerate(self._enabled_models) if on]
         live = [self.filter_models[i] for i in live_idx]
         A, mu_pred, L, z, r = [], [], [], [], []
         for i, f in zip(live_idx, live):
             assert f._initialized, "Kalman filter not initialized!"
-            sens = pre["sensor"][i] if pre is not None else f.virtual_sensor_model(observations=observations)
-            mp, Ak, Lk = f._predict_pieces(controls, pre["ctrl"][i] if pre is not None else None)
+            mp, Ak, Lk = f._predict_pieces(controls, None if ctrl is None else ctrl[i])
             A.append(Ak); mu_pred.append(mp); L.append(Lk)
-            z.append(sens[0].to(torch.float32)); r.append(sens[1].to(torch.float32))
+            z.append(enc["sensor"][i][0].to(torch.float32)); r.append(enc["sensor"][i][1].to(torch.float32))
         K = len(live)
         N, d = mu_pred[0].shape
         dev = mu_pred[0].device
@@ -210,25 +216,27 @@ class _FusedKalmanFilters(base.Filter, _EnabledModels):
             f._belief_mean, f._belief_covariance = mu[k], Sigma[k]
         return mu_f, Sigma_f, mu, Sigma
 
+    def forward(self, *, observations, controls):
+        N, _ = controls.shape
+        with torch.no_grad():
+            return self._forward_encoded(observations, controls, self._encode_step(observations),
+                                         self._encode_controls(controls))
+
     def forward_loop(self, *, observations, controls):
+        """Sensors, fusion weights and control encoders do not depend on the belief: they are
+        evaluated ahead of the recursion (one time step per call, so shapes do not depend on T)."""
         T, N = tree_leading_shape(controls)[:2]
         with torch.no_grad():
-            pre_all, obs_f = self._encode_loop_inputs(observations, controls)
-            extra_all = self._encode_loop_extra(obs_f)
-        out = []
-        for t in range(T):
-            sl = slice(t * N, (t + 1) * N)
-            pre = {"sensor": [(s[0][sl], s[1][sl]) for s in pre_all["sensor"]],
-                   "ctrl": [None if c is None else {k: v[sl] for k, v in c.items()} for c in pre_all["ctrl"]]}
-            extra = None if extra_all is None else self._slice_extra(extra_all, t, N)
-            out.append(self._forward_pre(tree_index(observations, t), tree_index(controls, t), pre, extra))
+            encs = [self._encode_step(tree_index(observations, t)) for t in range(T)]
+            flat = tree_map(controls, lambda x: x.reshape((T * N,) + tuple(x.shape[2:])))
+            ctrl_all = self._encode_controls(flat)
+            out = []
+            for t in range(T):
+                sl = slice(t * N, (t + 1) * N)
+                ctrl = [None if c is None else {k: v[sl] for k, v in c.items()} for c in ctrl_all]
+                out.append(self._forward_encoded(tree_index(observations, t), tree_index(controls, t),
+                                                 encs[t], ctrl))
         return torch.stack(out, dim=0)
-
-    def _encode_loop_extra(self, obs_flat):
-        return None
-
-    def _slice_extra(self, extra, t, N):
-        return extra
 
 
 class CrossmodalKalmanFilter(_FusedKalmanFilters):
@@ -249,39 +257,28 @@ class CrossmodalKalmanFilter(_FusedKalmanFilters):
         assert feedback in ("none", "belief")
         self.feedback = feedback
 
-    def _state_weights(self, observations, N, device, raw=None):
+    def _state_weights(self, raw, N, device):
         on = self._enabled_models
         if np.sum(on) < len(on):
             w = torch.tensor(on, dtype=torch.float32, device=device)
             w = w[:, None, None].repeat(1, N, self.state_dim)
         else:
-            w = raw if raw is not None else self.crossmodal_weight_model(observations=observations)
+            w = raw
         w = w[on]
         assert w.shape == (np.sum(on), N, self.state_dim)
         return w
 
-    def _encode_loop_extra(self, obs_flat):
-        # Q3: the reference's weight model mixes batch and feature axes, so it must see
-        # exactly the per-step batch; it is therefore evaluated per step, not over T*N rows.
-        return None
-
-    def _forward_pre(self, observations, controls, pre, extra):
+    def _forward_encoded(self, observations, controls, enc, ctrl):
         N = tree_leading_shape(controls)[0]
-        with torch.no_grad():
-            dev = self.filter_models[0]._belief_mean.device
-            w = self._state_weights(observations, N, dev)
-            fb = 1 if self.feedback == "belief" else 0
-            mu_f, Sigma_f, _, _ = self._fused_step(observations, controls, fusion=1, fuse_w=w,
-                                                   feedback=fb, pre=pre)
-            self.weighted_covariances = Sigma_f
-            for f in self.filter_models:  # inert attributes, exactly as the reference sets them
-                f.states_prev = mu_f
-                f.states_covariance_prev = Sigma_f
+        dev = self.filter_models[0]._belief_mean.device
+        w = self._state_weights(enc["weights"], N, dev)
+        fb = 1 if self.feedback == "belief" else 0
+        mu_f, Sigma_f, _, _ = self._fused_step(controls, enc, ctrl, fusion=1, fuse_w=w, feedback=fb)
+        self.weighted_covariances = Sigma_f
+        for f in self.filter_models:  # inert attributes, exactly as the reference sets them
+            f.states_prev = mu_f
+            f.states_covariance_prev = Sigma_f
         return mu_f
-
-    def forward(self, *, observations, controls):
-        N, _ = controls.shape
-        return self._forward_pre(observations, controls, None, None)
 
     # kept for API parity with the reference (``crossmodal_kf.py:153-186``)
     def calculate_weighted_states(self, state_weights, unimodal_states, unimodal_covariances):
@@ -293,21 +290,25 @@ class CrossmodalKalmanFilter(_FusedKalmanFilters):
         return mu, torch.sum(cw * unimodal_covariances, 0)
 
     def calculate_unimodal_states(self, observations, controls):
-        _, _, mu, Sigma = self._fused_step(observations, controls, fusion=0, fuse_w=None, feedback=0)
+        with torch.no_grad():
+            _, _, mu, Sigma = self._fused_step(controls, self._encode_step(observations),
+                                               self._encode_controls(controls),
+                                               fusion=0, fuse_w=None, feedback=0)
         return mu, Sigma
 
     def measurement_initialize_beliefs(self, observations):
         """``crossmodal_kf.py:208-240`` (per trajectory, off the hot path)."""
         on = self._enabled_models
-        outs = [f.virtual_sensor_model(observations=observations)
-                for i, f in enumerate(self.filter_models) if on[i]]
-        means = torch.stack([x[0] for x in outs])
-        trils = torch.stack([x[1] for x in outs])
-        covs = trils @ trils.transpose(-1, -2)
-        w = self.crossmodal_weight_model(observations=observations)[on]
-        mu = weighted_average(means, w)
-        mult = torch.prod(torch.prod(w, dim=-1), dim=0).unsqueeze(-1).unsqueeze(-1)
-        self.initialize_beliefs(mean=mu, covariance=mult * torch.sum(covs, dim=0))
+        with torch.no_grad():
+            outs = [f.virtual_sensor_model(observations=observations)
+                    for i, f in enumerate(self.filter_models) if on[i]]
+            means = torch.stack([x[0] for x in outs])
+            trils = torch.stack([x[1] for x in outs])
+            covs = trils @ trils.transpose(-1, -2)
+            w = self.crossmodal_weight_model(observations=observations)[on]
+            mu = weighted_average(means, w)
+            mult = torch.prod(torch.prod(w, dim=-1), dim=0).unsqueeze(-1).unsqueeze(-1)
+            self.initialize_beliefs(mean=mu, covariance=mult * torch.sum(covs, dim=0))
 
 
 class UnimodalKalmanFilter(_FusedKalmanFilters):
@@ -318,18 +319,12 @@ class UnimodalKalmanFilter(_FusedKalmanFilters):
     def __init__(self, *, filter_models, state_dim: int):
         super().__init__(filter_models=filter_models, state_dim=state_dim)
 
-    def _forward_pre(self, observations, controls, pre, extra):
-        with torch.no_grad():
-            if np.sum(self._enabled_models) == 1:
-                _, _, mu, _ = self._fused_step(observations, controls, fusion=0, fuse_w=None,
-                                               feedback=0, pre=pre)
-                return mu[0]
-            mu_f, _, _, _ = self._fused_step(observations, controls, fusion=2, fuse_w=None,
-                                             feedback=0, pre=pre)
+    def _forward_encoded(self, observations, controls, enc, ctrl):
+        if np.sum(self._enabled_models) == 1:
+            _, _, mu, _ = self._fused_step(controls, enc, ctrl, fusion=0, fuse_w=None, feedback=0)
+            return mu[0]
+        mu_f, _, _, _ = self._fused_step(controls, enc, ctrl, fusion=2, fuse_w=None, feedback=0)
         return mu_f
-
-    def forward(self, *, observations, controls):
-        return self._forward_pre(observations, controls, None, None)
 
 
 # ===================================================================== fused virtual sensors

@@ -1,0 +1,399 @@
+// K4: the 32x32 image encoder (R5) as implicit-GEMM convolutions on v_mfma_f32_16x16x4_f32.
+//
+// Replaces nn.Sequential(Conv 1->32 k5, ReLU, ResConv 32 k3, Conv 32->16 k3, ReLU,
+// Conv 16->8 k3, Flatten, Linear 8192->64, ReLU, ResLinear 64) of
+//   /root/reference/crossmodal/door_models/layers.py:43-63  (push_models/layers.py:91-104)
+// which the reference runs as ~12 stock torch launches per encoder (26.1 M MAC per image, 72 %
+// of it in the two 32->32 3x3 convolutions).
+//
+// One launch per layer, all encoders of a step batched on blockIdx.y (they share the input
+// image but not the weights).  A workgroup owns a 16-row band of one image:
+//   * the band (+halo, zero padded) of every input channel is staged in LDS as
+//     [ci][row][40] floats; 18 rows * 40 = 720 floats per channel == 16 (mod 32) banks, so the
+//     two channel groups that share a 32-lane LDS access land on disjoint bank halves
+//   * the layer's weights sit next to it in MFMA-fragment order (packed once on the device)
+//   * GEMM view: M = output channels (16 per tile), N = 16 pixels of one image row,
+//     K = (tap, 4 input channels): lane (j, q) feeds pixel j of channel 4cg+q, a plain
+//     conflict-free ds_read_b32 at a compile-time offset per (tap, channel group)
+//   * bias is the accumulator initialiser; skip-add and ReLU are fused in the epilogue.
+// Activations between layers go through global memory but stay L2 / Infinity-Cache
+// resident (256 images * 128 KiB).  The 8192->64 linear is a split-K MFMA GEMM reading W and
+// the activations in their natural row-major layouts (k order permuted identically on both
+// operands), followed by a one-wave-per-image tail (bias, ReLU, ResLinear 64).
+//
+// Roofline: 2 * 26.12 MFLOP per image against ~0.9 MB of L2-resident activation traffic:
+// compute-bound on the f32 MFMA peak (157.3 TFLOP/s); DESIGN.md section 3.
+#include "mmf_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kImg = 32;         // images are 32 x 32
+constexpr int kBand = 16;        // output rows per workgroup
+constexpr int kWP = 40;          // padded LDS row: 4 | 32 pixels | 4
+constexpr int kConvThreads = 512;
+constexpr int kMaxNets = 4;
+constexpr int kFeat = 64;
+constexpr int kFcK = 8 * kImg * kImg;  // 8192
+constexpr int kFcSplit = 16;
+
+__host__ __device__ constexpr int ksteps(int cin, int ks) {  // K / 4, padded to a multiple of 4
+  return ((cin == 1 ? (ks * ks + 3) / 4 : ks * ks * (cin / 4)) + 3) / 4 * 4;
+}
+__host__ __device__ constexpr int mtiles(int cout) { return (cout + 15) / 16; }
+__host__ __device__ constexpr int conv_w_floats(int cin, int cout, int ks) {
+  return mtiles(cout) * ksteps(cin, ks) * 64;
+}
+
+// ---- packed blob of one encoder (floats) -------------------------------------------------
+struct Layout {
+  int w1, b1, w2a, b2a, w2b, b2b, w3, b3, w4, b4, fcw, fcb, r1t, r1b, r2t, r2b, total;
+};
+__host__ __device__ constexpr Layout layout() {
+  Layout L{};
+  int o = 0;
+  L.w1 = o; o += conv_w_floats(1, 32, 5);
+  L.b1 = o; o += 32;
+  L.w2a = o; o += conv_w_floats(32, 32, 3);
+  L.b2a = o; o += 32;
+  L.w2b = o; o += conv_w_floats(32, 32, 3);
+  L.b2b = o; o += 32;
+  L.w3 = o; o += conv_w_floats(32, 16, 3);
+  L.b3 = o; o += 16;
+  L.w4 = o; o += conv_w_floats(16, 8, 3);
+  L.b4 = o; o += 16;
+  L.fcw = o; o += kFeat * kFcK;
+  L.fcb = o; o += kFeat;
+  L.r1t = o; o += kFeat * kFeat;
+  L.r1b = o; o += kFeat;
+  L.r2t = o; o += kFeat * kFeat;
+  L.r2b = o; o += kFeat;
+  L.total = o;
+  return L;
+}
+
+// k-step s, lane quarter q -> (input channel, ky, kx); false if it is a zero-padding slot
+__host__ __device__ inline bool kdecode(int cin, int ks, int s, int q, int* ci, int* ky, int* kx) {
+  if (cin == 1) {
+    const int t = 4 * s + q;
+    if (t >= ks * ks) return false;
+    *ci = 0; *ky = t / ks; *kx = t % ks;
+    return true;
+  }
+  const int groups = cin / 4;
+  const int tap = s / groups, cg = s % groups;
+  if (tap >= ks * ks) return false;
+  *ci = 4 * cg + q; *ky = tap / ks; *kx = tap % ks;
+  return true;
+}
+
+struct PackConv {
+  const float* w;  // (cout, cin, ks, ks) torch layout
+  const float* b;
+  int cin, cout, ks, woff, boff;
+};
+
+__global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ out) {
+  constexpr Layout L = layout();
+  const PackConv convs[5] = {
+      {d.conv_w[0], d.conv_b[0], 1, 32, 5, L.w1, L.b1}, {d.conv_w[1], d.conv_b[1], 32, 32, 3, L.w2a, L.b2a},
+      {d.conv_w[2], d.conv_b[2], 32, 32, 3, L.w2b, L.b2b}, {d.conv_w[3], d.conv_b[3], 32, 16, 3, L.w3, L.b3},
+      {d.conv_w[4], d.conv_b[4], 16, 8, 3, L.w4, L.b4}};
+  for (int q0 = blockIdx.x * blockDim.x + threadIdx.x; q0 < L.total; q0 += gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (q0 < L.fcw) {
+      for (int c = 0; c < 5; ++c) {
+        const PackConv& p = convs[c];
+        const int nw = conv_w_floats(p.cin, p.cout, p.ks);
+        if (q0 >= p.woff && q0 < p.woff + nw) {
+          // [mt][s4][lane][4]
+          const int e = q0 - p.woff;
+          const int ksub = e & 3, lane = (e >> 2) & 63, rest = e >> 8;
+          const int S4 = ksteps(p.cin, p.ks) / 4;
+          const int s4 = rest % S4, mt = rest / S4;
+          const int s = 4 * s4 + ksub, i = lane & 15, q = lane >> 4;
+          const int co = 16 * mt + i;
+          int ci, ky, kx;
+          if (co < p.cout && kdecode(p.cin, p.ks, s, q, &ci, &ky, &kx))
+            v = p.w[((co * p.cin + ci) * p.ks + ky) * p.ks + kx];
+        } else if (q0 >= p.boff && q0 < p.boff + (p.cout < 16 ? 16 : p.cout)) {
+          const int co = q0 - p.boff;
+          if (co < p.cout) v = p.b[co];
+        }
+      }
+    } else if (q0 < L.fcb) {
+      v = d.fc_w[q0 - L.fcw];
+    } else if (q0 < L.r1t) {
+      v = d.fc_b[q0 - L.fcb];
+    } else if (q0 < L.r1b) {  // transposed: [k][o]
+      const int e = q0 - L.r1t, k = e / kFeat, o = e % kFeat;
+      v = d.res_w[0][o * kFeat + k];
+    } else if (q0 < L.r2t) {
+      v = d.res_b[0][q0 - L.r1b];
+    } else if (q0 < L.r2b) {
+      const int e = q0 - L.r2t, k = e / kFeat, o = e % kFeat;
+      v = d.res_w[1][o * kFeat + k];
+    } else {
+      v = d.res_b[1][q0 - L.r2b];
+    }
+    out[q0] = v;
+  }
+}
+
+// ---- one convolution layer ----------------------------------------------------------------
+struct ConvArgs {
+  const float* packed[kMaxNets];  // encoder blobs
+  const float* in;                // (nets?, N, CIN, 32, 32)
+  const float* skip;              // (nets, N, COUT, 32, 32) or null
+  float* out;                     // (nets, N, COUT, 32, 32)
+  long long in_net_stride;        // 0 when every net reads the same input (layer 1)
+  int N;
+  int woff, boff;
+};
+
+template <int CIN, int COUT, int KS, bool RELU, bool SKIP>
+__global__ __launch_bounds__(kConvThreads) void conv_kernel(ConvArgs a) {
+  constexpr int HALO = KS / 2;
+  constexpr int RB = kBand + 2 * HALO;
+  constexpr int CS = RB * kWP;  // channel stride in LDS
+  constexpr int S = ksteps(CIN, KS);
+  constexpr int MT = mtiles(COUT);
+  constexpr int NW = MT * S * 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* tile = lds;            // [CIN][RB][kWP]
+  float* wl = lds + CIN * CS;   // [MT][S/4][64][4]
+
+  const int img = blockIdx.x >> 1, band = blockIdx.x & 1, net = blockIdx.y;
+  const int y0 = band * kBand;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const float* blob = a.packed[net];
+
+  // ---- stage weights and the input band (zero halo) into LDS
+  {
+    const float4* src = reinterpret_cast<const float4*>(blob + a.woff);
+    float4* dst = reinterpret_cast<float4*>(wl);
+    for (int i = tid; i < NW / 4; i += kConvThreads) dst[i] = src[i];
+    const float* in = a.in + net * a.in_net_stride + static_cast<size_t>(img) * CIN * kImg * kImg;
+    for (int i = tid; i < CIN * RB * 10; i += kConvThreads) {
+      const int ci = i / (RB * 10), rem = i % (RB * 10), rr = rem / 10, x4 = rem % 10;
+      const int y = y0 - HALO + rr;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (x4 >= 1 && x4 <= 8 && y >= 0 && y < kImg)
+        v = *reinterpret_cast<const float4*>(in + (ci * kImg + y) * kImg + 4 * (x4 - 1));
+      *reinterpret_cast<float4*>(tile + ci * CS + rr * kWP + 4 * x4) = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- each wave: 2 output rows x 2 half-rows (4 pixel tiles of 16) x MT channel tiles
+  const int r0 = 2 * wave;
+  f32x4 acc[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(blob + a.boff + 16 * mt + 4 * q);
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) acc[mt][pt] = b;
+  }
+  int base[4];
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt)
+    base[pt] = (CIN == 1 ? 0 : q * CS) + (r0 + (pt >> 1)) * kWP + (4 - HALO) + 16 * (pt & 1) + j;
+  int toff[S];  // CIN == 1: the tap (hence the offset) depends on the lane quarter
+  if (CIN == 1) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int t = 4 * s + q;
+      toff[s] = t < KS * KS ? (t / KS) * kWP + (t % KS) : 0;  // zero weight there anyway
+    }
+  }
+#pragma unroll
+  for (int s4 = 0; s4 < S / 4; ++s4) {
+    f32x4 a4[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      a4[mt] = *reinterpret_cast<const f32x4*>(wl + ((mt * (S / 4) + s4) * 64 + lane) * 4);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int s = 4 * s4 + ks;
+      int off;
+      if (CIN == 1) {
+        off = toff[s];
+      } else {
+        constexpr int G = CIN / 4;
+        const int tap = s / G, cg = s % G;
+        if (tap >= KS * KS) continue;  // padding k-steps carry zero weights
+        off = 4 * cg * CS + (tap / KS) * kWP + (tap % KS);
+      }
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) {
+        const float b = tile[base[pt] + off];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[mt][ks], b, acc[mt][pt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: (+skip) (ReLU) store; lane (j, q) reg r -> channel 16mt + 4q + r, pixel j
+  const size_t obase = (static_cast<size_t>(net) * a.N + img) * COUT * kImg * kImg;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ch = 16 * mt + 4 * q + r;
+        if (ch < COUT) {
+          const size_t o = obase + (static_cast<size_t>(ch) * kImg + (y0 + r0 + (pt >> 1))) * kImg + 16 * (pt & 1) + j;
+          float v = acc[mt][pt][r];
+          if (SKIP) v += a.skip[o];
+          if (RELU) v = fmaxf(v, 0.f);
+          a.out[o] = v;
+        }
+      }
+}
+
+// ---- 8192 -> 64 linear, split-K partial sums ----------------------------------------------
+struct FcArgs {
+  const float* packed[kMaxNets];
+  const float* act;   // (nets, N, 8192)
+  float* partial;     // (nets, kFcSplit, N, 64)
+  float* feat;        // (nets, N, 64)
+  int N;
+};
+
+__global__ __launch_bounds__(256) void fc_partial_kernel(FcArgs a) {
+  constexpr Layout L = layout();
+  const int tile = blockIdx.x, split = blockIdx.y, net = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;  // wave = 16-output tile
+  const int j = lane & 15, q = lane >> 4;
+  const int img = min(tile * 16 + j, a.N - 1);
+  constexpr int KS = kFcK / kFcSplit;  // 512 per split
+  const float* W = a.packed[net] + L.fcw + static_cast<size_t>(16 * wave + j) * kFcK + split * KS + 4 * q;
+  const float* X = a.act + (static_cast<size_t>(net) * a.N + img) * kFcK + split * KS + 4 * q;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int k = 0; k < KS; k += 16) {
+    // both operands take k = k0 + 4q + e for element e: the same permutation of K on A and B
+    const f32x4 w = *reinterpret_cast<const f32x4*>(W + k);
+    const f32x4 x = *reinterpret_cast<const f32x4*>(X + k);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0], x[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1], x[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2], x[2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[3], x[3], acc1, 0, 0, 0);
+  }
+  if (tile * 16 + j < a.N) {
+    float* p = a.partial + ((static_cast<size_t>(net) * kFcSplit + split) * a.N + tile * 16 + j) * kFeat + 16 * wave + 4 * q;
+    *reinterpret_cast<f32x4*>(p) = acc0 + acc1;  // lane (j, q) reg r -> output 16*wave + 4q + r of image j
+  }
+}
+
+// one wave per (image, net): bias + ReLU, then ResLinear(64)
+__global__ __launch_bounds__(256) void fc_tail_kernel(FcArgs a) {
+  constexpr Layout L = layout();
+  const int lane = threadIdx.x & 63;
+  const int img = blockIdx.x * 4 + (threadIdx.x >> 6), net = blockIdx.y;
+  if (img >= a.N) return;
+  const float* blob = a.packed[net];
+  float h = blob[L.fcb + lane];
+  for (int s = 0; s < kFcSplit; ++s)
+    h += a.partial[((static_cast<size_t>(net) * kFcSplit + s) * a.N + img) * kFeat + lane];
+  h = fmaxf(h, 0.f);
+  float t = blob[L.r1b + lane];
+#pragma unroll 8
+  for (int k = 0; k < kFeat; ++k) t += blob[L.r1t + k * kFeat + lane] * __shfl(h, k);
+  t = fmaxf(t, 0.f);
+  float y = blob[L.r2b + lane] + h;
+#pragma unroll 8
+  for (int k = 0; k < kFeat; ++k) y += blob[L.r2t + k * kFeat + lane] * __shfl(t, k);
+  a.feat[(static_cast<size_t>(net) * a.N + img) * kFeat + lane] = fmaxf(y, 0.f);
+}
+
+template <int CIN, int COUT, int KS, bool RELU, bool SKIP>
+int launch_conv(const ConvArgs& a, int nets, hipStream_t s) {
+  constexpr int RB = kBand + 2 * (KS / 2);
+  constexpr size_t lds = (static_cast<size_t>(CIN) * RB * kWP + mtiles(COUT) * ksteps(CIN, KS) * 64) * sizeof(float);
+  static_assert(lds <= 160 * 1024, "conv tile + weights must fit LDS");
+  auto k = conv_kernel<CIN, COUT, KS, RELU, SKIP>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  k<<<dim3(2 * a.N, nets), kConvThreads, lds, s>>>(a);
+  MMF_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t mmf_image_encoder_floats(void) { return static_cast<size_t>(layout().total); }
+
+extern "C" size_t mmf_image_encoder_workspace_bytes(int n_images, int n_nets) {
+  if (n_images < 0 || n_nets < 1 || n_nets > kMaxNets) return 0;
+  // three 32-channel activation tensors (ping, pong, skip) + FC partial sums
+  const size_t act = static_cast<size_t>(n_nets) * n_images * 32 * kImg * kImg;
+  return (3 * act + static_cast<size_t>(n_nets) * kFcSplit * n_images * kFeat) * sizeof(float);
+}
+
+extern "C" int mmf_pack_image_encoder(const MmfImageEncoderDesc* d, float* packed, void* stream) {
+  if (!d || !packed || !d->fc_w || !d->fc_b) return MMF_EINVAL;
+  for (int i = 0; i < 5; ++i)
+    if (!d->conv_w[i] || !d->conv_b[i]) return MMF_EINVAL;
+  for (int i = 0; i < 2; ++i)
+    if (!d->res_w[i] || !d->res_b[i]) return MMF_EINVAL;
+  const int total = layout().total;
+  pack_encoder_kernel<<<(total + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(*d, packed);
+  MMF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int mmf_image_encoder(const float* const* packed, int n_nets, const float* images,
+                                 float* feat, void* workspace, int N, void* stream) {
+  if (!packed || !images || !feat || !workspace) return MMF_EINVAL;
+  if (n_nets < 1 || n_nets > kMaxNets || N < 0) return MMF_EINVAL;
+  if (N == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  constexpr Layout L = layout();
+  const size_t act = static_cast<size_t>(n_nets) * N * 32 * kImg * kImg;
+  float* bufA = static_cast<float*>(workspace);
+  float* bufB = bufA + act;
+  float* bufC = bufB + act;
+  float* partial = bufC + act;
+
+  ConvArgs c{};
+  for (int i = 0; i < n_nets; ++i) {
+    if (!packed[i]) return MMF_EINVAL;
+    c.packed[i] = packed[i];
+  }
+  c.N = N;
+  int rc;
+  // conv 1 -> 32, k5, ReLU                      images -> A
+  c.in = images; c.in_net_stride = 0; c.skip = nullptr; c.out = bufA; c.woff = L.w1; c.boff = L.b1;
+  if ((rc = launch_conv<1, 32, 5, true, false>(c, n_nets, s))) return rc;
+  // ResConv block1: conv 32 -> 32, ReLU          A -> B
+  c.in = bufA; c.in_net_stride = static_cast<long long>(N) * 32 * kImg * kImg; c.out = bufB;
+  c.woff = L.w2a; c.boff = L.b2a;
+  if ((rc = launch_conv<32, 32, 3, true, false>(c, n_nets, s))) return rc;
+  // ResConv block2: conv 32 -> 32, + A, ReLU     B -> C
+  c.in = bufB; c.skip = bufA; c.out = bufC; c.woff = L.w2b; c.boff = L.b2b;
+  if ((rc = launch_conv<32, 32, 3, true, true>(c, n_nets, s))) return rc;
+  // conv 32 -> 16, ReLU                          C -> A
+  c.in = bufC; c.skip = nullptr; c.out = bufA; c.woff = L.w3; c.boff = L.b3;
+  if ((rc = launch_conv<32, 16, 3, true, false>(c, n_nets, s))) return rc;
+  // conv 16 -> 8 (no ReLU before Flatten)        A -> B
+  c.in = bufA; c.in_net_stride = static_cast<long long>(N) * 16 * kImg * kImg; c.out = bufB;
+  c.woff = L.w4; c.boff = L.b4;
+  if ((rc = launch_conv<16, 8, 3, false, false>(c, n_nets, s))) return rc;
+  // Linear 8192 -> 64 (split-K partials), then bias + ReLU + ResLinear
+  FcArgs f{};
+  for (int i = 0; i < n_nets; ++i) f.packed[i] = packed[i];
+  f.act = bufB; f.partial = partial; f.feat = feat; f.N = N;
+  fc_partial_kernel<<<dim3((N + 15) / 16, kFcSplit, n_nets), 256, 0, s>>>(f);
+  MMF_CHECK_LAUNCH();
+  fc_tail_kernel<<<dim3((N + 3) / 4, n_nets), 256, 0, s>>>(f);
+  MMF_CHECK_LAUNCH();
+  return 0;
+}

@@ -177,3 +177,123 @@ def run_jacobian(net: PackedParticleNet, states: torch.Tensor, traj_bias: torch.
     jac = torch.empty((N, d, d), dtype=torch.float32, device=states.device)
     _abi.dynamics_jacobian(net.blob(), net.n_res, states.contiguous(), traj_bias, out, jac, N, d)
     return out, jac
+
+
+# ------------------------------------------------------------------------------ K4 image encoders
+def _is_default_image_encoder(seq) -> bool:
+    from .layers import ResConv2d
+
+    try:
+        return (len(seq) == 10 and isinstance(seq[0], nn.Conv2d) and seq[0].weight.shape == (32, 1, 5, 5)
+                and isinstance(seq[2], ResConv2d) and seq[3].weight.shape == (16, 32, 3, 3)
+                and isinstance(seq[5], nn.Conv2d) and seq[5].weight.shape == (8, 16, 3, 3)
+                and isinstance(seq[7], nn.Linear) and seq[7].weight.shape == (64, 8192)
+                and isinstance(seq[9], ResLinear))
+    except (TypeError, AttributeError, IndexError):
+        return False
+
+
+class PackedImageEncoder:
+    """Fragment-ordered device copy of one default ``observation_image_layers`` stack
+    (``layers.image_encoder``), rebuilt lazily when a source parameter changes."""
+
+    def __init__(self, seq: nn.Sequential):
+        assert _is_default_image_encoder(seq)
+        self.seq = seq
+        self._blob = None
+        self._stamp = None
+
+    def _sources(self):
+        q = self.seq
+        return [q[0].weight, q[2].block1.weight, q[2].block2.weight, q[3].weight, q[5].weight,
+                q[0].bias, q[2].block1.bias, q[2].block2.bias, q[3].bias, q[5].bias,
+                q[7].weight, q[7].bias, q[9].block1.weight, q[9].block2.weight,
+                q[9].block1.bias, q[9].block2.bias]
+
+    def blob(self) -> torch.Tensor:
+        src = self._sources()
+        stamp = tuple((t.data_ptr(), t._version, str(t.device)) for t in src)
+        if self._blob is not None and stamp == self._stamp:
+            return self._blob
+        require_device(src[0], "PackedImageEncoder")
+        keep = [t.detach().to(torch.float32).contiguous() for t in src]
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        d = _abi.MmfImageEncoderDesc()
+        for i in range(5):
+            d.conv_w[i], d.conv_b[i] = P(keep[i]), P(keep[5 + i])
+        d.fc_w, d.fc_b = P(keep[10]), P(keep[11])
+        d.res_w[0], d.res_w[1], d.res_b[0], d.res_b[1] = P(keep[12]), P(keep[13]), P(keep[14]), P(keep[15])
+        blob = torch.empty(_abi.image_encoder_floats(), dtype=torch.float32, device=src[0].device)
+        _abi.pack_image_encoder(d, blob)
+        self._blob, self._stamp = blob, stamp
+        return blob
+
+
+_IMAGE_WORKSPACES = {}
+_MAX_NETS = 4
+
+
+def _image_workspace(device, n_images: int, n_nets: int) -> torch.Tensor:
+    need = _abi.image_encoder_workspace_bytes(n_images, n_nets)
+    key = str(device)
+    ws = _IMAGE_WORKSPACES.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _IMAGE_WORKSPACES[key] = ws
+    return ws
+
+
+def image_encoder_flops(n_images: int) -> float:
+    return 2.0 * 26_124_288 * n_images  # SURVEY.md 8a R5: MAC per image of the default stack
+
+
+def encode_images(encoders, images: torch.Tensor):
+    """Run several image encoders on the same ``(N, 32, 32)`` batch: default stacks go
+    through K4 in one batched launch sequence, any other architecture (the push virtual
+    sensor's spanning-pool tail) through its torch module.  Returns one ``(N, 64)`` per encoder."""
+    require_device(images, "encode_images")
+    images = images.to(torch.float32).contiguous()
+    N = images.shape[0]
+    out = [None] * len(encoders)
+    fused = [i for i, e in enumerate(encoders) if _is_default_image_encoder(e)]
+    for i, e in enumerate(encoders):
+        if i not in fused:
+            out[i] = e(images[:, None, :, :])
+    for lo in range(0, len(fused), _MAX_NETS):
+        grp = fused[lo:lo + _MAX_NETS]
+        packs = []
+        for i in grp:
+            e = encoders[i]
+            if not hasattr(e, "_mmf_packed"):
+                object.__setattr__(e, "_mmf_packed", PackedImageEncoder(e))
+            packs.append(e._mmf_packed.blob())
+        feat = torch.empty((len(grp), N, 64), dtype=torch.float32, device=images.device)
+        ws = _image_workspace(images.device, N, len(grp))
+        _timed("image_encoder", image_encoder_flops(N) * len(grp), 0.0,
+               lambda: _abi.image_encoder(packs, images, feat, ws))
+        for k, i in enumerate(grp):
+            out[i] = feat[k]
+    return out
+
+
+def encode_observation_images(models, observations):
+    """Image features for every model in ``models`` that owns an image encoder (``None`` for
+    the others, and for models that do not accept handed-over features): all default
+    stacks of a step run as ONE batched K4 launch sequence."""
+    idx = [i for i, m in enumerate(models)
+           if m is not None and getattr(m, "accepts_image_feat", False)
+           and "image" in getattr(m, "modalities", ())]
+    out = [None] * len(models)
+    if idx:
+        with torch.no_grad():
+            feats = encode_images([models[i].observation_image_layers for i in idx], observations["image"])
+        for i, f in zip(idx, feats):
+            out[i] = f
+    return out
+
+
+def call_with_image_feat(fn, image_feat, **kwargs):
+    """Call ``fn(**kwargs)``, adding ``image_feat=`` when features were pre-computed."""
+    if image_feat is None:
+        return fn(**kwargs)
+    return fn(image_feat=image_feat, **kwargs)

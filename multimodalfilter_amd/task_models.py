@@ -67,6 +67,8 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
 
     # ------------------------------------------------------------- observation encoders
     class _ObsEncoders:
+        accepts_image_feat = True  # containers may hand over batched K4 features
+
         def _build_obs_encoders(self, modalities, units, spanning_avg_pool=False):
             valid_modalities = {"image", "pos", "sensors"}
             assert len(valid_modalities | set(modalities)) == 3, "Received invalid modality"
@@ -79,11 +81,15 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             if "sensors" in self.modalities:
                 self.observation_sensors_layers = layers.vector_encoder(task.obs_sensors_dim, units)
 
-        def observation_features(self, observations) -> torch.Tensor:
+        def observation_features(self, observations, image_feat=None) -> torch.Tensor:
+            """``image_feat``: this model's image features when a container already ran the
+            image encoders of a step as one batch (``engine.encode_images``)."""
             assert type(observations) == dict
             obs = []
             if "image" in self.modalities:
-                obs.append(_chunked(self.observation_image_layers, observations["image"][:, None, :, :]))
+                if image_feat is None:
+                    image_feat = engine.encode_observation_images([self], observations)[0]
+                obs.append(image_feat)
             if "pos" in self.modalities:
                 obs.append(self.observation_pos_layers(observations["gripper_pos"]))
             if "sensors" in self.modalities:
@@ -176,9 +182,9 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
                 res_blocks=[self.shared_layers[2], self.shared_layers[3]],
                 head=self.shared_layers[4], relu_after_join=True)
 
-        def encode_observations(self, observations):
+        def encode_observations(self, observations, image_feat=None):
             with torch.no_grad():
-                return {"bias": self._net.traj_bias(self.observation_features(observations))}
+                return {"bias": self._net.traj_bias(self.observation_features(observations, image_feat))}
 
         def forward_encoded(self, states, ctx, *, loglik=None, combine=False, modality_logw=None,
                             logw_stride=0):
@@ -213,9 +219,9 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
                 nn.Linear(units, modality_count),
             )
 
-        def forward(self, *, observations):
+        def forward(self, *, observations, image_feat=None):
             N, _ = observations["gripper_pos"].shape
-            output = self.fusion_layers(self.observation_features(observations))
+            output = self.fusion_layers(self.observation_features(observations, image_feat))
             assert output.shape == (N, self.modality_count)
             if self.know_image_blackout:
                 output[blackout_rows(observations["image"]), 0] -= np.inf
@@ -291,10 +297,10 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             self.units = units
             self.add_R_noise = torch.ones(D) * add_R_noise
 
-        def forward(self, *, observations):
+        def forward(self, *, observations, image_feat=None):
             assert type(observations) == dict
             N, _ = observations["gripper_pos"].shape
-            shared = self.shared_layers(self.observation_features(observations))
+            shared = self.shared_layers(self.observation_features(observations, image_feat))
             z = self.z_layer(shared[:, : self.units])
             assert z.shape == (N, self.state_dim)
             lt_hat = self.r_layer(shared[:, self.units:]) if self.noise_R_tril is None else self.noise_R_tril
@@ -332,9 +338,9 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             self.know_image_blackout = know_image_blackout
             self.fix_weight_layout = fix_weight_layout
 
-        def forward(self, *, observations):
+        def forward(self, *, observations, image_feat=None):
             N, _ = observations["gripper_pos"].shape
-            output = self.fusion_layers(self.observation_features(observations))
+            output = self.fusion_layers(self.observation_features(observations, image_feat))
             assert output.shape == (N, self.modality_count * self.state_dim)
             if self.fix_weight_layout:
                 w = output.view(N, self.modality_count, self.state_dim).permute(1, 0, 2)
@@ -371,25 +377,23 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
                 state_dim=D, feedback=feedback)
             self.know_image_blackout = know_image_blackout
 
-        def _forward_pre(self, observations, controls, pre, extra):
+        def _forward_encoded(self, observations, controls, enc, ctrl):
             if not self.know_image_blackout:
-                return super()._forward_pre(observations, controls, pre, extra)
+                return super()._forward_encoded(observations, controls, enc, ctrl)
             N, _ = controls.shape
             dark = blackout_rows(observations["image"])
             on = self._enabled_models
             if torch.sum(dark) == 0 or np.sum(on) < len(on):
-                return super()._forward_pre(observations, controls, pre, extra)
-            with torch.no_grad():
-                raw = self.crossmodal_weight_model(observations=observations)
-                keep = (~dark).to(torch.float32)[:, None]
-                drk = dark.to(torch.float32)[:, None]
-                image_weight = drk * 1e-9 + keep * raw[0]
-                force_weight = drk * (1.0 - 1e-9) + keep * raw[1]
-                w = torch.stack([image_weight, force_weight])
-                assert w.shape == (np.sum(on), N, self.state_dim)
-                mu_f, Sigma_f, _, _ = self._fused_step(observations, controls, fusion=1, fuse_w=w,
-                                                       feedback=0, pre=pre)
-                self.weighted_covariances = Sigma_f
+                return super()._forward_encoded(observations, controls, enc, ctrl)
+            raw = enc["weights"]
+            keep = (~dark).to(torch.float32)[:, None]
+            drk = dark.to(torch.float32)[:, None]
+            image_weight = drk * 1e-9 + keep * raw[0]
+            force_weight = drk * (1.0 - 1e-9) + keep * raw[1]
+            w = torch.stack([image_weight, force_weight])
+            assert w.shape == (np.sum(on), N, self.state_dim)
+            mu_f, Sigma_f, _, _ = self._fused_step(controls, enc, ctrl, fusion=1, fuse_w=w, feedback=0)
+            self.weighted_covariances = Sigma_f
             return mu_f
 
     # ------------------------------------------------------------- R10 unimodal EKF

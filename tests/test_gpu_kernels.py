@@ -323,3 +323,33 @@ def test_k5_jacobian_matches_autograd(task, N):
     assert _rel_err(got, want) < 1e-4
     assert _rel_err(A.cpu(), want) < 1e-4
     assert _rel_err(mu.cpu(), want_x) < 1e-4
+
+
+# ------------------------------------------------------------------------------ K4
+@pytest.mark.parametrize("N", [1, 3, 16, 50, 256])
+@pytest.mark.parametrize("nets", [1, 2, 3])
+def test_k4_image_encoders_match_oracle(N, nets):
+    """Batched image encoders (shared images, different weights) vs the oracle's torch stack."""
+    from multimodalfilter_amd import engine, layers
+
+    dev = _cuda()
+    g = torch.Generator().manual_seed(N + 100 * nets)
+    img = (torch.randn((N, 32, 32), generator=g) * 0.5).clamp(-1, 1)
+    img[N // 2] = 0.0  # a blacked-out frame
+    oracles = [_seeded(om.image_encoder(64), seed=k) for k in range(nets)]
+    encs = []
+    for o in oracles:
+        e = layers.image_encoder(64)
+        e.load_state_dict(o.state_dict())
+        encs.append(e.to(dev))
+    got = engine.encode_images(encs, img.to(dev))
+    for o, gk in zip(oracles, got):
+        with torch.no_grad():
+            want = o(img[:, None])
+        assert _rel_err(gk.cpu(), want) < 1e-4
+    # weights changed in place (optimiser step / load_state_dict) -> blob is re-packed
+    with torch.no_grad():
+        encs[0][7].weight.mul_(0.5)
+        oracles[0][7].weight.mul_(0.5)
+        want = oracles[0](img[:, None])
+    assert _rel_err(engine.encode_images(encs[:1], img.to(dev))[0].cpu(), want) < 1e-4

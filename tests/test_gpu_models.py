@@ -26,6 +26,19 @@ def _product(case_name: str, task: om.TaskSpec):
     import multimodalfilter_amd as mmf
     from multimodalfilter_amd import layers
 
+    class K4Sequential(torch.nn.Sequential):
+        """The default image stack evaluated by the HIP image-encoder kernels (K4)."""
+
+        def forward(self, x):
+            from multimodalfilter_amd import engine
+
+            return engine.encode_images([self], x[:, 0])[0]
+
+    def k4_encoder():
+        seq = layers.image_encoder(64)
+        seq.__class__ = K4Sequential
+        return seq
+
     ns = mmf.door_models if task.name == "door" else mmf.push_models
     P = task.name.capitalize()
     g = lambda suffix: getattr(ns, P + suffix)
@@ -35,7 +48,7 @@ def _product(case_name: str, task: om.TaskSpec):
         "dynamics_pf_brent": lambda: ns.DoorDynamicsModelBrent(),
         "dynamics_jacobian": lambda: g("DynamicsModel")(),
         "state_encoder": lambda: layers.vector_encoder(task.state_dim, 64),
-        "image_encoder": lambda: layers.image_encoder(64),
+        "image_encoder": k4_encoder,
         "image_encoder_spanning": lambda: layers.image_encoder(64, True),
         "pf_weight_model": lambda: g("CrossmodalWeightModel")(know_image_blackout=False),
         "pf_weight_model_blackout": lambda: g("CrossmodalWeightModel")(know_image_blackout=True),
