@@ -231,6 +231,7 @@ class PackedImageEncoder:
 
 _IMAGE_WORKSPACES = {}
 _MAX_NETS = 4
+_IMAGE_CHUNK = 2048  # images per K4 launch sequence (workspace ~0.8 GB per encoder)
 
 
 def _image_workspace(device, n_images: int, n_nets: int) -> torch.Tensor:
@@ -267,12 +268,19 @@ def encode_images(encoders, images: torch.Tensor):
             if not hasattr(e, "_mmf_packed"):
                 object.__setattr__(e, "_mmf_packed", PackedImageEncoder(e))
             packs.append(e._mmf_packed.blob())
-        feat = torch.empty((len(grp), N, 64), dtype=torch.float32, device=images.device)
-        ws = _image_workspace(images.device, N, len(grp))
-        _timed("image_encoder", image_encoder_flops(N) * len(grp), 0.0,
-               lambda: _abi.image_encoder(packs, images, feat, ws))
+        feats = [torch.empty((N, 64), dtype=torch.float32, device=images.device) for _ in grp]
+        # bounded workspace: at most _IMAGE_CHUNK images per launch sequence
+        for c0 in range(0, N, _IMAGE_CHUNK):
+            n = min(_IMAGE_CHUNK, N - c0)
+            chunk = images[c0:c0 + n]
+            feat = torch.empty((len(grp), n, 64), dtype=torch.float32, device=images.device)
+            ws = _image_workspace(images.device, n, len(grp))
+            _timed("image_encoder", image_encoder_flops(n) * len(grp), 0.0,
+                   lambda: _abi.image_encoder(packs, chunk, feat, ws))
+            for k in range(len(grp)):
+                feats[k][c0:c0 + n] = feat[k]
         for k, i in enumerate(grp):
-            out[i] = feat[k]
+            out[i] = feats[k]
     return out
 
 

@@ -148,24 +148,25 @@ class ParticleFilter(base.Filter):
 
     def forward_loop(self, *, observations, controls) -> torch.Tensor:
         """Sequential in ``t``.  Everything that does not depend on the belief (control and
-        observation encoders, CNNs, modality weights) is evaluated ahead of the recursion,
-        one time step per call so that encoder batch shapes do not depend on ``T``."""
+        observation encoders, image CNNs, modality weights) is evaluated ahead of the
+        recursion for all ``T*N`` rows at once: rows are independent, so the per-trajectory
+        work costs one launch sequence per ``forward_loop`` instead of one per step."""
         T, N = tree_leading_shape(controls)[:2]
         assert tree_leading_shape(observations)[:2] == (T, N)
-        obs_ctx = ctrl_ctx = None
+        flat = lambda x: x.reshape((T * N,) + tuple(x.shape[2:]))
+        obs_all = ctrl_all = None
         with torch.no_grad():
             if hasattr(self.measurement_model, "forward_encoded"):
-                obs_ctx = [self.measurement_model.encode_observations(tree_index(observations, t))
-                           for t in range(T)]
+                obs_all = self.measurement_model.encode_observations(tree_map(observations, flat))
             if hasattr(self.dynamics_model, "propagate_encoded"):
-                flat = tree_map(controls, lambda x: x.reshape((T * N,) + tuple(x.shape[2:])))
-                ctrl_all = self.dynamics_model.encode_controls(flat)
-                ctrl_ctx = [{k: v[t * N:(t + 1) * N] for k, v in ctrl_all.items()} for t in range(T)]
+                ctrl_all = self.dynamics_model.encode_controls(tree_map(controls, flat))
         out = []
         for t in range(T):
-            out.append(self._step(tree_index(observations, t), tree_index(controls, t),
-                                  None if obs_ctx is None else obs_ctx[t],
-                                  None if ctrl_ctx is None else ctrl_ctx[t]))
+            sl = slice(t * N, (t + 1) * N)
+            out.append(self._step(
+                tree_index(observations, t), tree_index(controls, t),
+                None if obs_all is None else {k: v[sl] for k, v in obs_all.items()},
+                None if ctrl_all is None else {k: v[sl] for k, v in ctrl_all.items()}))
         return torch.stack(out, dim=0)
 
 
