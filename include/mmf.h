@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 1
+#define MMF_ABI_VERSION 2
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -35,6 +35,11 @@ extern "C" {
 #define MMF_UNITS 64         /* hidden width of every per-particle layer (layers.py: units=64) */
 #define MMF_MAX_RES 3        /* residual blocks after the join layer (LDS: 3 -> 149.5 KiB) */
 #define MMF_MAX_STATE_DIM 4
+
+/* arithmetic of the 64x64 layers of the per-particle networks (K2) */
+#define MMF_PREC_F32 0    /* v_mfma_f32_32x32x2_f32: exact fp32 products                        */
+#define MMF_PREC_F16X3 1  /* operands split x = hi + lo (2 x f16, exact to 2^-22), products
+                             hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulate   */
 
 int mmf_version(void);
 
@@ -110,8 +115,10 @@ typedef struct MmfParticleNetDesc {
 /* Number of floats of a packed network blob with `n_res` residual blocks. */
 size_t mmf_particle_net_floats(int n_res);
 
-/* Re-order a network's weights into MFMA-fragment order (device -> device). */
-int mmf_pack_particle_net(const MmfParticleNetDesc* desc /* host */, float* packed, void* stream);
+/* Re-order a network's weights into MFMA-fragment order (device -> device) for `precision`
+ * (MMF_PREC_*); the blob size does not depend on it, the blob must be used with the same value. */
+int mmf_pack_particle_net(const MmfParticleNetDesc* desc /* host */, float* packed, int precision,
+                          void* stream);
 
 /* x' = x + dir(x) * sigmoid(gate(x)) + L eps      (dynamics.py:102-134 + the reparameterised
  * MultivariateNormal(loc, scale_tril).rsample() of torchfilter's PF step)
@@ -122,7 +129,7 @@ int mmf_pack_particle_net(const MmfParticleNetDesc* desc /* host */, float* pack
  *  scale_tril  (d, d) row-major lower-triangular, shared by all rows (ignored if noise null)
  *  states_out  (N*M, d)     may alias states_in
  */
-int mmf_pf_dynamics(const float* packed, int n_res, const float* states_in,
+int mmf_pf_dynamics(const float* packed, int n_res, int precision, const float* states_in,
                     const float* traj_bias, const float* noise, const float* scale_tril,
                     float* states_out, int N, int M, int d, void* stream);
 
@@ -134,7 +141,7 @@ int mmf_pf_dynamics(const float* packed, int n_res, const float* states_in,
  * logsumexp_k(log beta_k + ll_k).
  *  states (N*M, d); traj_bias (N, 64); loglik (N*M) in/out
  */
-int mmf_pf_measure(const float* packed, int n_res, const float* states, const float* traj_bias,
+int mmf_pf_measure(const float* packed, int n_res, int precision, const float* states, const float* traj_bias,
                    const float* modality_logw, int logw_stride, float* loglik, int combine,
                    int N, int M, int d, void* stream);
 

@@ -20,12 +20,16 @@
 //
 // Roofline: 2 FLOP/MAC * {37,312 dynamics | 28,928 measurement} MAC per particle against
 // ~32 B of HBM traffic => compute bound on the f32 MFMA peak (157.3 TFLOP/s); DESIGN.md.
+#include <hip/hip_fp16.h>
+
 #include "mmf_common.h"
 
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 constexpr int kUnits = MMF_UNITS;
 constexpr int kW0Cols = 8;                    // first layer padded to K = 8 (state dims, 1, zeros)
@@ -46,7 +50,17 @@ __host__ __device__ constexpr int blob_floats(int n_res) { return off_bhead(n_re
 __host__ __device__ constexpr int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // ------------------------------------------------------------------------------ packing
-__global__ void pack_particle_net_kernel(MmfParticleNetDesc d, float* __restrict__ out) {
+// f16x3 layers: feature index fed by element i of lane half h in k-step s (16 features per
+// step): the rows accumulator registers 8(s&1) .. 8(s&1)+7 of input tile s>>1 hold
+__host__ __device__ constexpr int kmap16(int s, int h, int i) {
+  return 32 * (s >> 1) + 16 * (s & 1) + (i & 3) + 8 * (i >> 2) + 4 * h;
+}
+
+__device__ __forceinline__ unsigned short f16_bits_rz(float x) {
+  return __half_as_ushort(__float2half_rz(x));
+}
+
+__global__ void pack_particle_net_kernel(MmfParticleNetDesc d, float* __restrict__ out, int precision) {
   const int total = blob_floats(d.n_res);
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
     float v = 0.f;
@@ -57,16 +71,28 @@ __global__ void pack_particle_net_kernel(MmfParticleNetDesc d, float* __restrict
     } else if (q < off_bias(d.n_res)) {
       const int rel = q - off_layers();
       const int l = rel / kLayerFloats, e = rel % kLayerFloats;
-      const int ks = e & 3, lane = (e >> 2) & 63, s4 = (e >> 8) & 7, t = e >> 11;
-      const int s = 4 * s4 + ks, h = lane >> 5, i = lane & 31;
-      const int k = 32 * (s >> 4) + rowmap(s & 15, h);
-      const int row = 32 * t + i;
       const float* W;
       int stride = kUnits, coff = 0;
       if (l < 2) W = d.w_enc[l];
       else if (l == 2) { W = d.w_join; stride = d.join_in; coff = d.join_state_off; }
       else W = d.w_res[l - 3];
-      v = W[row * stride + coff + k];
+      if (precision == MMF_PREC_F32) {
+        const int ks = e & 3, lane = (e >> 2) & 63, s4 = (e >> 8) & 7, t = e >> 11;
+        const int s = 4 * s4 + ks, h = lane >> 5, i = lane & 31;
+        const int k = 32 * (s >> 4) + rowmap(s & 15, h);
+        v = W[(32 * t + i) * stride + coff + k];
+      } else {
+        // two halves per float slot; layout [t][s][hi|lo][lane][8]
+        unsigned short hb[2];
+        for (int z = 0; z < 2; ++z) {
+          const int he = 2 * e + z;
+          const int i = he & 7, lane = (he >> 3) & 63, part = (he >> 9) & 1, s = (he >> 10) & 3, t = he >> 12;
+          const float w = W[(32 * t + (lane & 31)) * stride + coff + kmap16(s, lane >> 5, i)];
+          const __half hi = __float2half_rz(w);
+          hb[z] = part ? f16_bits_rz(w - __half2float(hi)) : __half_as_ushort(hi);
+        }
+        v = __uint_as_float(static_cast<unsigned>(hb[0]) | (static_cast<unsigned>(hb[1]) << 16));
+      }
     } else if (q < off_whead(d.n_res)) {
       const int rel = q - off_bias(d.n_res);
       const int l = rel / kUnits, row = rel % kUnits;
@@ -169,6 +195,78 @@ __device__ __forceinline__ void res_block(const float* __restrict__ lds, int n_r
   relu<CT, JAC>(x, primal);
 }
 
+// ------------------------------------------------------------------------------ f16x3 path
+// Each fp32 operand is split exactly into two halves x = hi + lo + O(2^-22 x) (round-toward-
+// zero, so the split never overflows to inf) and a product is evaluated as
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation: 3 MFMAs at 16x the
+// f32-MFMA rate, ~22-bit operands (measured parity: tests/test_gpu_kernels.py).
+template <int CT>
+struct SplitAct {
+  half8 hi[4][CT], lo[4][CT];  // [k-step][col tile]
+};
+
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+  const auto l = __builtin_amdgcn_cvt_pkrtz(x0 - static_cast<float>(h[0]), x1 - static_cast<float>(h[1]));
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+template <int CT>
+__device__ __forceinline__ void split_act(const Act<CT>& x, SplitAct<CT>& o) {
+#pragma unroll
+  for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        u32x4 h, l;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          unsigned hh, ll;
+          split_pair(x.v[tp][c][8 * u + 2 * p], x.v[tp][c][8 * u + 2 * p + 1], hh, ll);
+          h[p] = hh;
+          l[p] = ll;
+        }
+        o.hi[2 * tp + u][c] = __builtin_bit_cast(half8, h);
+        o.lo[2 * tp + u][c] = __builtin_bit_cast(half8, l);
+      }
+}
+
+template <int CT>
+__device__ __forceinline__ void mfma_layer_f16(const float* __restrict__ Wl, const SplitAct<CT>& in,
+                                               Act<CT>& acc, int lane) {
+  asm volatile("" ::: "memory");  // see mfma_layer: keep LICM from hoisting the fragment reads
+  const unsigned char* base = reinterpret_cast<const unsigned char*>(Wl) + lane * 16;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const half8 ahi = *reinterpret_cast<const half8*>(base + ((t * 4 + s) * 2 + 0) * 1024);
+      const half8 alo = *reinterpret_cast<const half8*>(base + ((t * 4 + s) * 2 + 1) * 1024);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        acc.v[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, in.hi[s][c], acc.v[t][c], 0, 0, 0);
+        acc.v[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, in.lo[s][c], acc.v[t][c], 0, 0, 0);
+        acc.v[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, in.hi[s][c], acc.v[t][c], 0, 0, 0);
+      }
+    }
+}
+
+template <int CT>
+__device__ __forceinline__ void res_block_f16(const float* __restrict__ lds, int n_res, int l1,
+                                              Act<CT>& x, Act<CT>& hbuf, SplitAct<CT>& sp, int lane) {
+  const int h = lane >> 5;
+  split_act<CT>(x, sp);
+  add_bias<CT, false>(lds + off_bias(n_res) + l1 * kUnits, hbuf, h, 1.f);
+  mfma_layer_f16<CT>(lds + off_layers() + l1 * kLayerFloats, sp, hbuf, lane);
+  relu<CT, false>(hbuf, true);
+  split_act<CT>(hbuf, sp);
+  add_bias<CT, true>(lds + off_bias(n_res) + (l1 + 1) * kUnits, x, h, 1.f);
+  mfma_layer_f16<CT>(lds + off_layers() + (l1 + 1) * kLayerFloats, sp, x, lane);
+  relu<CT, false>(x, true);
+}
+
 enum Kind { kDynamics = 0, kMeasure = 1, kJacobian = 2 };
 
 struct NetArgs {
@@ -187,10 +285,12 @@ struct NetArgs {
   int combine;
 };
 
-template <int D, int NRES, int KIND, int CT>
+template <int D, int NRES, int KIND, int CT, int PREC>
 __global__ __launch_bounds__(kThreads, 2) void particle_net_kernel(NetArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr bool JAC = KIND == kJacobian;
+  constexpr bool F16 = PREC == MMF_PREC_F16X3;
+  static_assert(!(JAC && F16), "the Jacobian kernel runs in f32");
   constexpr int NOUT = (KIND == kMeasure) ? 1 : D + 1;
   constexpr int TILE = 32 * CT;
   static_assert(!JAC || D <= 3, "jacobian groups are 4 columns: primal + up to 3 tangents");
@@ -260,7 +360,9 @@ __global__ __launch_bounds__(kThreads, 2) void particle_net_kernel(NetArgs a) {
     relu<CT, JAC>(X, primal);
 
     // ---- encoder residual block (layers 0, 1)
-    res_block<CT, JAC>(lds, NRES, 0, X, H, lane, primal);
+    SplitAct<F16 ? CT : 0> SP;
+    if constexpr (F16) res_block_f16<CT>(lds, NRES, 0, X, H, SP, lane);
+    else res_block<CT, JAC>(lds, NRES, 0, X, H, lane, primal);
 
     // ---- join layer (2): per-trajectory hoisted half arrives as the accumulator init
 #pragma unroll
@@ -275,12 +377,20 @@ __global__ __launch_bounds__(kThreads, 2) void particle_net_kernel(NetArgs a) {
           for (int e = 0; e < 4; ++e) H.v[t][c][4 * g + e] = (JAC && !primal) ? 0.f : b[e];
         }
       }
-    mfma_layer<CT>(lds + off_layers() + 2 * kLayerFloats, X, H, lane);
+    if constexpr (F16) {
+      split_act<CT>(X, SP);
+      mfma_layer_f16<CT>(lds + off_layers() + 2 * kLayerFloats, SP, H, lane);
+    } else {
+      mfma_layer<CT>(lds + off_layers() + 2 * kLayerFloats, X, H, lane);
+    }
     if (KIND == kMeasure) relu<CT, JAC>(H, primal);
 
     // ---- residual trunk: activations now live in H, X is scratch
 #pragma unroll
-    for (int i = 0; i < NRES; ++i) res_block<CT, JAC>(lds, NRES, 3 + 2 * i, H, X, lane, primal);
+    for (int i = 0; i < NRES; ++i) {
+      if constexpr (F16) res_block_f16<CT>(lds, NRES, 3 + 2 * i, H, X, SP, lane);
+      else res_block<CT, JAC>(lds, NRES, 3 + 2 * i, H, X, lane, primal);
+    }
 
     // ---- head (64 -> NOUT) on the VALU: each lane holds 32 of the 64 features of its columns
     float out[NOUT][CT];
@@ -373,7 +483,7 @@ __global__ __launch_bounds__(kThreads, 2) void particle_net_kernel(NetArgs a) {
   }
 }
 
-template <int D, int NRES, int KIND>
+template <int D, int NRES, int KIND, int PREC>
 int launch_ct(const NetArgs& a, hipStream_t s) {
   const size_t lds = static_cast<size_t>(blob_floats(NRES)) * sizeof(float);
   // small problems: 32-particle tiles spread over more waves; large: 64-particle tiles
@@ -385,12 +495,12 @@ int launch_ct(const NetArgs& a, hipStream_t s) {
   if (grid < 1) grid = 1;
   hipError_t e;
   if (big) {
-    auto k = particle_net_kernel<D, NRES, KIND, 2>;
+    auto k = particle_net_kernel<D, NRES, KIND, 2, PREC>;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return static_cast<int>(e);
     k<<<grid, kThreads, lds, s>>>(a);
   } else {
-    auto k = particle_net_kernel<D, NRES, KIND, 1>;
+    auto k = particle_net_kernel<D, NRES, KIND, 1, PREC>;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return static_cast<int>(e);
     k<<<grid, kThreads, lds, s>>>(a);
@@ -400,14 +510,15 @@ int launch_ct(const NetArgs& a, hipStream_t s) {
 }
 
 template <int KIND>
-int launch(const NetArgs& a, int d, int n_res, hipStream_t s) {
-#define MMF_CASE(D, NR) \
-  if (d == D && n_res == NR) return launch_ct<D, NR, KIND>(a, s);
-  if (KIND == kJacobian) {
-    MMF_CASE(2, 3) MMF_CASE(3, 3)
-    return MMF_EINVAL;
+int launch(const NetArgs& a, int d, int n_res, int precision, hipStream_t s) {
+#define MMF_CASE(D, NR)                                                              \
+  if (d == D && n_res == NR) {                                                       \
+    if (precision == MMF_PREC_F32) return launch_ct<D, NR, KIND, MMF_PREC_F32>(a, s); \
+    if constexpr (KIND != kJacobian)                                                 \
+      if (precision == MMF_PREC_F16X3) return launch_ct<D, NR, KIND, MMF_PREC_F16X3>(a, s); \
+    return MMF_EINVAL;                                                               \
   }
-  if (KIND == kDynamics) {
+  if (KIND == kJacobian || KIND == kDynamics) {
     MMF_CASE(2, 3) MMF_CASE(3, 3)
     return MMF_EINVAL;
   }
@@ -423,8 +534,10 @@ extern "C" size_t mmf_particle_net_floats(int n_res) {
   return static_cast<size_t>(blob_floats(n_res));
 }
 
-extern "C" int mmf_pack_particle_net(const MmfParticleNetDesc* d, float* packed, void* stream) {
+extern "C" int mmf_pack_particle_net(const MmfParticleNetDesc* d, float* packed, int precision,
+                                     void* stream) {
   if (!d || !packed) return MMF_EINVAL;
+  if (precision != MMF_PREC_F32 && precision != MMF_PREC_F16X3) return MMF_EINVAL;
   if (d->d_in < 1 || d->d_in > MMF_MAX_STATE_DIM || d->n_res < 0 || d->n_res > MMF_MAX_RES) return MMF_EINVAL;
   if (d->n_out < 1 || d->n_out > kHeadRows) return MMF_EINVAL;
   if (d->join_state_off < 0 || d->join_state_off + kUnits > d->join_in) return MMF_EINVAL;
@@ -434,12 +547,12 @@ extern "C" int mmf_pack_particle_net(const MmfParticleNetDesc* d, float* packed,
   for (int i = 0; i < 2 * d->n_res; ++i)
     if (!d->w_res[i] || !d->b_res[i]) return MMF_EINVAL;
   const int total = blob_floats(d->n_res);
-  pack_particle_net_kernel<<<(total + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(*d, packed);
+  pack_particle_net_kernel<<<(total + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(*d, packed, precision);
   MMF_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int mmf_pf_dynamics(const float* packed, int n_res, const float* states_in,
+extern "C" int mmf_pf_dynamics(const float* packed, int n_res, int precision, const float* states_in,
                                const float* traj_bias, const float* noise, const float* scale_tril,
                                float* states_out, int N, int M, int d, void* stream) {
   if (!packed || !states_in || !traj_bias || !states_out || (noise && !scale_tril)) return MMF_EINVAL;
@@ -449,10 +562,10 @@ extern "C" int mmf_pf_dynamics(const float* packed, int n_res, const float* stat
   NetArgs a{};
   a.packed = packed; a.states_in = states_in; a.traj_bias = traj_bias; a.noise = noise;
   a.scale_tril = scale_tril; a.states_out = states_out; a.R = N * M; a.M = M;
-  return launch<kDynamics>(a, d, n_res, static_cast<hipStream_t>(stream));
+  return launch<kDynamics>(a, d, n_res, precision, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int mmf_pf_measure(const float* packed, int n_res, const float* states,
+extern "C" int mmf_pf_measure(const float* packed, int n_res, int precision, const float* states,
                               const float* traj_bias, const float* modality_logw, int logw_stride,
                               float* loglik, int combine, int N, int M, int d, void* stream) {
   if (!packed || !states || !traj_bias || !loglik) return MMF_EINVAL;
@@ -462,7 +575,7 @@ extern "C" int mmf_pf_measure(const float* packed, int n_res, const float* state
   NetArgs a{};
   a.packed = packed; a.states_in = states; a.traj_bias = traj_bias; a.mod_logw = modality_logw;
   a.logw_stride = logw_stride; a.loglik = loglik; a.combine = combine; a.R = N * M; a.M = M;
-  return launch<kMeasure>(a, d, n_res, static_cast<hipStream_t>(stream));
+  return launch<kMeasure>(a, d, n_res, precision, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mmf_dynamics_jacobian(const float* packed, int n_res, const float* states_in,
@@ -475,5 +588,5 @@ extern "C" int mmf_dynamics_jacobian(const float* packed, int n_res, const float
   NetArgs a{};
   a.packed = packed; a.states_in = states_in; a.traj_bias = traj_bias;
   a.states_out = states_out; a.jac = jac; a.R = 4 * N; a.M = 4;
-  return launch<kJacobian>(a, d, n_res, static_cast<hipStream_t>(stream));
+  return launch<kJacobian>(a, d, n_res, MMF_PREC_F32, static_cast<hipStream_t>(stream));
 }

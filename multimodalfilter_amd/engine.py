@@ -2,6 +2,7 @@
 the per-particle networks, and the launches of K2 / K5 (``csrc/particle_net.hip``).
 """
 import ctypes
+import os
 from typing import List, Sequence
 
 import torch
@@ -65,6 +66,17 @@ def require_device(t: torch.Tensor, what: str):
         )
 
 
+# Arithmetic of the per-particle 64x64 layers: "f32" (exact fp32 products on the f32 MFMA) or
+# "f16x3" (operands split into two halves, three f16 MFMA products, fp32 accumulate; ~2^-22).
+DEFAULT_PRECISION = os.environ.get("MMF_PRECISION", "f32")
+
+
+def set_default_precision(name: str):
+    global DEFAULT_PRECISION
+    assert name in _abi.PRECISIONS, name
+    DEFAULT_PRECISION = name
+
+
 class PackedParticleNet:
     """One per-particle network (``enc -> join -> res* -> head``, see ``include/mmf.h``)
     packed into MFMA-fragment order on the device.
@@ -88,8 +100,11 @@ class PackedParticleNet:
         self._enc_in, self._enc_res = enc_in, enc_res
         self._res = list(res_blocks)
         self._head = head
-        self._blob = None
-        self._stamp = None
+        self._blobs = {}       # precision code -> (stamp, blob)
+        self.precision = None  # None -> engine.DEFAULT_PRECISION at call time
+
+    def precision_code(self) -> int:
+        return _abi.PRECISIONS[self.precision or DEFAULT_PRECISION]
 
     def _sources(self) -> List[torch.Tensor]:
         ts = [self._enc_in.weight, self._enc_in.bias,
@@ -100,11 +115,13 @@ class PackedParticleNet:
         ts += [self._head.weight, self._head.bias]
         return ts
 
-    def blob(self) -> torch.Tensor:
+    def blob(self, precision: int = None) -> torch.Tensor:
         src = self._sources()
+        prec = self.precision_code() if precision is None else precision
         stamp = tuple((t.data_ptr(), t._version, str(t.device)) for t in src)
-        if self._blob is not None and stamp == self._stamp:
-            return self._blob
+        cached = self._blobs.get(prec)
+        if cached is not None and cached[0] == stamp:
+            return cached[1]
         dev = src[0].device
         require_device(src[0], "PackedParticleNet")
         keep = [t.detach().to(torch.float32).contiguous() for t in src]
@@ -121,8 +138,8 @@ class PackedParticleNet:
             d.w_res[2 * i + 1], d.b_res[2 * i + 1] = P(keep[base + 2]), P(keep[base + 3])
         d.w_head, d.b_head = P(keep[-2]), P(keep[-1])
         blob = torch.empty(_abi.particle_net_floats(self.n_res), dtype=torch.float32, device=dev)
-        _abi.pack_particle_net(d, blob)
-        self._blob, self._stamp = blob, stamp
+        _abi.pack_particle_net(d, blob, prec)
+        self._blobs[prec] = (stamp, blob)
         return blob
 
     def traj_bias(self, traj_features: torch.Tensor) -> torch.Tensor:
@@ -148,8 +165,8 @@ def run_dynamics(net: PackedParticleNet, states: torch.Tensor, traj_bias: torch.
     tril_c = None if noise is None else scale_tril.contiguous()
     _timed("particle_net_dynamics", 2.0 * R * particle_net_macs(d, net.n_res, net.n_out),
            R * 4.0 * (2 * d + (d if noise is not None else 0)),
-           lambda: _abi.pf_dynamics(blob, net.n_res, states, traj_bias, noise_c, tril_c, out,
-                                    N, R // N, d))
+           lambda: _abi.pf_dynamics(blob, net.n_res, net.precision_code(), states, traj_bias, noise_c,
+                                    tril_c, out, N, R // N, d))
     return out
 
 
@@ -164,8 +181,8 @@ def run_measure(net: PackedParticleNet, states: torch.Tensor, traj_bias: torch.T
     states = states.contiguous()
     _timed("particle_net_measure", 2.0 * R * particle_net_macs(d, net.n_res, net.n_out),
            R * 4.0 * (d + 1 + (1 if combine else 0)),
-           lambda: _abi.pf_measure(blob, net.n_res, states, traj_bias, modality_logw, logw_stride,
-                                   loglik, combine, N, R // N, d))
+           lambda: _abi.pf_measure(blob, net.n_res, net.precision_code(), states, traj_bias,
+                                   modality_logw, logw_stride, loglik, combine, N, R // N, d))
     return loglik
 
 
@@ -175,7 +192,8 @@ def run_jacobian(net: PackedParticleNet, states: torch.Tensor, traj_bias: torch.
     N, d = states.shape
     out = torch.empty_like(states)
     jac = torch.empty((N, d, d), dtype=torch.float32, device=states.device)
-    _abi.dynamics_jacobian(net.blob(), net.n_res, states.contiguous(), traj_bias, out, jac, N, d)
+    blob = net.blob(_abi.PREC_F32)  # the tangent kernel is f32-only
+    _abi.dynamics_jacobian(blob, net.n_res, states.contiguous(), traj_bias, out, jac, N, d)
     return out, jac
 
 

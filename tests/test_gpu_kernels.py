@@ -247,9 +247,20 @@ def _rel_err(got, want):
     return float((got - want).abs().max()) / scale
 
 
+@pytest.fixture()
+def precision(request):
+    from multimodalfilter_amd import engine
+
+    old = engine.DEFAULT_PRECISION
+    engine.set_default_precision(request.param)
+    yield request.param
+    engine.set_default_precision(old)
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"], indirect=True)
 @pytest.mark.parametrize("task", ["door", "push"])
 @pytest.mark.parametrize("N,M", [(1, 1), (3, 5), (2, 64), (4, 300), (2, 4096), (40, 4096)])
-def test_k2_dynamics_and_measurement_match_oracle(task, N, M):
+def test_k2_dynamics_and_measurement_match_oracle(task, N, M, precision):
     import multimodalfilter_amd as mmf
 
     dev = _cuda()
@@ -353,3 +364,37 @@ def test_k4_image_encoders_match_oracle(N, nets):
         oracles[0][7].weight.mul_(0.5)
         want = oracles[0](img[:, None])
     assert _rel_err(engine.encode_images(encs[:1], img.to(dev))[0].cpu(), want) < 1e-4
+
+
+@pytest.mark.parametrize("task", ["door", "push"])
+def test_k2_f16x3_error_against_fp64(task):
+    """The split-f16 path vs the f32-MFMA path, both measured against an fp64 evaluation of
+    the same network: f16x3 must stay within 1e-5 relative (an order below the 1e-4 bar)."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine
+
+    dev = _cuda()
+    spec = om.TASKS[task]
+    d, N, M = spec.state_dim, 8, 2048
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((N, M, d), generator=g) * 2.0
+    u = torch.randn((N, 7), generator=g)
+    o_dyn = _seeded(om.DynamicsModel(spec, brent_noise=spec.pf_noise_brent))
+    ref64 = om.DynamicsModel(spec, brent_noise=spec.pf_noise_brent).double()
+    ref64.load_state_dict({k: v.double() for k, v in o_dyn.state_dict().items()})
+    with torch.no_grad():
+        truth = ref64(initial_states=x.reshape(N * M, d).double(), controls=u.repeat_interleave(M, 0).double())[0]
+    models = mmf.door_models if task == "door" else mmf.push_models
+    p_dyn = getattr(models, "DoorDynamicsModelBrent" if task == "door" else "PushDynamicsModel")()
+    p_dyn.load_state_dict(o_dyn.state_dict())
+    p_dyn.to(dev)
+    errs = {}
+    old = engine.DEFAULT_PRECISION
+    try:
+        for prec in ("f32", "f16x3"):
+            engine.set_default_precision(prec)
+            got = p_dyn.propagate_encoded(x.to(dev), p_dyn.encode_controls(u.to(dev)), None)
+            errs[prec] = float((got.cpu().double().reshape(N * M, d) - truth).abs().max() / truth.abs().max())
+    finally:
+        engine.set_default_precision(old)
+    assert errs["f32"] < 1e-5 and errs["f16x3"] < 1e-5, errs
