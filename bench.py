@@ -28,6 +28,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
+F16_MFMA_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARCH.md)
+MFMA_PEAK = {"f32": FP32_MFMA_PEAK_TFLOPS, "f16x3": F16_MFMA_PEAK_TFLOPS}
+K2_KERNEL = {"f32": "particle_net_kernel<3, 2, 1, 2, 0>", "f16x3": "particle_net_kernel<3, 2, 1, 2, 1>"}
 
 WORKLOADS = {
     "door_pf": dict(task="door", cls="DoorCrossmodalParticleFilter", kind="pf", batch=256, particles=4096,
@@ -183,12 +186,19 @@ def main():
     ap.add_argument("--particles", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--precision", default=None, choices=["f32", "f16x3"],
+                    help="arithmetic of the per-particle 64x64 layers (default: engine default)")
+    ap.add_argument("--no-f32-mode", action="store_true",
+                    help="skip the extra timed pass in exact-f32 mode")
     args = ap.parse_args()
 
     import multimodalfilter_amd as mmf
     from multimodalfilter_amd import _abi, distributed, engine, evaluation, synthetic
 
     _abi.load()  # fail loudly before touching the GPU if the HIP library is missing
+    if args.precision:
+        engine.set_default_precision(args.precision)
+    precision = engine.DEFAULT_PRECISION
     rank, world, local = distributed.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -226,25 +236,33 @@ def main():
         noise_w = noise = None
         run = lambda tr, nz: evaluation.run_filter(f, tr)
 
-    # ---- warm-up (untimed): W steps
-    if W > 0:
-        run(traj_w, noise_w)
-    torch.cuda.synchronize()
+    def timed_pass():
+        """W untimed warm-up steps, then exactly K timed steps; returns (seconds, timer, mse)."""
+        if W > 0:
+            run(traj_w, noise_w)
+        torch.cuda.synchronize()
+        timer = None if args.no_kernel_timers else engine.KernelTimer()
+        engine.set_kernel_timer(timer)
+        distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pred = run(traj, noise)
+        mse_local = evaluation.per_trajectory_mse(pred, traj["states"][1:], start=min(30, K // 2))
+        mse_all = distributed.all_gather_rows(mse_local)  # RCCL all-gather of per-sequence errors
+        torch.cuda.synchronize()
+        distributed.barrier()
+        dt = time.perf_counter() - t0
+        engine.set_kernel_timer(None)
+        return distributed.max_over_ranks(dt, device), timer, mse_all
 
-    # ---- timed region: exactly K steps
-    timer = None if args.no_kernel_timers else engine.KernelTimer()
-    engine.set_kernel_timer(timer)
-    distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    pred = run(traj, noise)
-    mse_local = evaluation.per_trajectory_mse(pred, traj["states"][1:], start=min(30, K // 2))
-    mse_all = distributed.all_gather_rows(mse_local)  # RCCL all-gather of per-sequence errors
-    torch.cuda.synchronize()
-    distributed.barrier()
-    elapsed = time.perf_counter() - t0
-    engine.set_kernel_timer(None)
-    elapsed = distributed.max_over_ranks(elapsed, device)
+    elapsed, timer, mse_all = timed_pass()
+
+    # the same K steps with exact fp32 products on the f32 MFMA, for comparison (all ranks)
+    f32_pass = None
+    if wl["kind"] == "pf" and precision != "f32" and not args.no_f32_mode:
+        engine.set_default_precision("f32")
+        f32_pass = timed_pass()
+        engine.set_default_precision(precision)
 
     units_per_step = B * M * world if wl["kind"] == "pf" else B * world
     value = units_per_step * K / elapsed
@@ -258,7 +276,10 @@ def main():
         "unit": "particle-steps/s" if wl["kind"] == "pf" else "trajectory-steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if precision == "f32" or wl["kind"] != "pf" else
+                 "f32 via f16x3 (operands split into 2 f16 halves exact to 2^-22, 3 f16 MFMA products "
+                 "per product, f32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": wl["desc"], "filter": wl["cls"], "batch_per_gpu": B, "particles": M,
                    "global_batch": B * world, "state_dim": d, "resample": "systematic",
                    "parallelism": f"trajectory-sharded x{world}"},
@@ -267,18 +288,25 @@ def main():
                           "separate passes; bytes per launch = 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction)",
     }
 
+    def k2_roofline(ks, prec):
+        dom = ks["particle_net_measure"]
+        ach = dom["flops_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e12
+        default_shape = (args.workload == "door_pf" and B == 256 and M == 4096)
+        r = {"kernel": K2_KERNEL[prec] + " (measurement network)", "bound": "mfma", "achieved": ach,
+             "peak": MFMA_PEAK[prec], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK[prec],
+             "traffic": pmc_traffic("particle_net_kernel<3, 2, 1, 2>") if default_shape else None}
+        if prec == "f16x3":
+            r["note"] = ("achieved counts ALGORITHMIC fp32 FLOPs; the kernel executes 3 f16 MFMA "
+                         "products per algorithmic product (executed-MFMA fraction = 3 x frac)")
+        return r
+
     if timer is not None:
         ks = timer.summary()
         out["kernels"] = {k: {kk: (round(vv, 6) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                           for k, v in ks.items()}
         if wl["kind"] == "pf" and "particle_net_measure" in ks:
-            dom = ks["particle_net_measure"]
-            ach = dom["flops_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e12
             default_shape = (args.workload == "door_pf" and B == 256 and M == 4096)
-            out["roofline"] = {"kernel": "particle_net_kernel<3, 2, 1, 2> (measurement network)",
-                               "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
-                               "traffic": pmc_traffic("particle_net_kernel<3, 2, 1, 2>") if default_shape else None}
+            out["roofline"] = k2_roofline(ks, precision)
             k1 = ks.get("pf_reweight_resample")
             if k1:
                 gbs = k1["bytes_per_launch"] / (k1["avg_ms"] * 1e-3) / 1e9
@@ -288,6 +316,13 @@ def main():
                                       "traffic": pmc_traffic("pf_reweight_resample_kernel<3>") if default_shape else None}
     if "roofline" not in out:
         out["roofline"] = None
+
+    if f32_pass is not None:
+        e32, t32, _ = f32_pass
+        out["f32_mode"] = {"value": units_per_step * K / e32, "unit": out["unit"],
+                           "ms_per_step": 1e3 * e32 / K, "dtype": "f32"}
+        if t32 is not None:
+            out["f32_mode"]["roofline"] = k2_roofline(t32.summary(), "f32")
 
     if world == 1 and not args.no_cpu_baseline:
         cores = min(CPU_THREADS, os.cpu_count() or 1)

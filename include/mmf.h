@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 2
+#define MMF_ABI_VERSION 3
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -128,10 +128,13 @@ int mmf_pack_particle_net(const MmfParticleNetDesc* desc /* host */, float* pack
  *  noise       (N*M, d) standard normal, or null (EKF predict / open-loop rollouts)
  *  scale_tril  (d, d) row-major lower-triangular, shared by all rows (ignored if noise null)
  *  states_out  (N*M, d)     may alias states_in
+ *  range_flag  int32 on the device or null; MMF_PREC_F16X3 ORs 1 into it when an activation
+ *              exceeded the f16-split range (|x| >= 65504: the result is finite but wrong --
+ *              re-run with MMF_PREC_F32); never written otherwise
  */
 int mmf_pf_dynamics(const float* packed, int n_res, int precision, const float* states_in,
                     const float* traj_bias, const float* noise, const float* scale_tril,
-                    float* states_out, int N, int M, int d, void* stream);
+                    float* states_out, int32_t* range_flag, int N, int M, int d, void* stream);
 
 /* One modality's log-likelihood and its crossmodal combination
  * (pf.py:63-107 + base_models/crossmodal_pf.py:106-139):
@@ -143,7 +146,7 @@ int mmf_pf_dynamics(const float* packed, int n_res, int precision, const float* 
  */
 int mmf_pf_measure(const float* packed, int n_res, int precision, const float* states, const float* traj_bias,
                    const float* modality_logw, int logw_stride, float* loglik, int combine,
-                   int N, int M, int d, void* stream);
+                   int32_t* range_flag, int N, int M, int d, void* stream);
 
 /* Forward-mode Jacobian of the dynamics network (replaces torchfilter's default autograd
  * DynamicsModel.jacobian: batch replicated d times + one autograd.grad):

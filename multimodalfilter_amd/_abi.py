@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmmf_hip.so")
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 PREC_F32, PREC_F16X3 = 0, 1
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}
 
@@ -48,8 +48,8 @@ SIGNATURES = {
     "mmf_pf_reweight_resample_lds_bytes": (c_size_t, [c_int, c_int]),
     "mmf_particle_net_floats": (c_size_t, [c_int]),
     "mmf_pack_particle_net": (c_int, [POINTER(MmfParticleNetDesc), _FP, c_int, c_void_p]),
-    "mmf_pf_dynamics": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
-    "mmf_pf_measure": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, c_int, _FP, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmf_pf_dynamics": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
+    "mmf_pf_measure": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, c_int, _FP, c_int, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_dynamics_jacobian": (c_int, [_FP, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_ekf_step": (c_int, [_FP] * 10 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_image_encoder_floats": (c_size_t, []),
@@ -138,19 +138,22 @@ def pack_particle_net(desc: MmfParticleNetDesc, packed: torch.Tensor, precision:
                                             stream_of(packed)), "mmf_pack_particle_net")
 
 
-def pf_dynamics(packed, n_res, precision, states_in, traj_bias, noise, scale_tril, states_out, N, M, d):
+def pf_dynamics(packed, n_res, precision, states_in, traj_bias, noise, scale_tril, states_out,
+                range_flag, N, M, d):
     with _on(states_in):
         _check(load().mmf_pf_dynamics(ptr(packed), n_res, precision, ptr(states_in), ptr(traj_bias), ptr(noise),
-                                      ptr(scale_tril), ptr(states_out), N, M, d,
+                                      ptr(scale_tril), ptr(states_out),
+                                      ptr(range_flag, dtype=torch.int32), N, M, d,
                                       stream_of(states_in)), "mmf_pf_dynamics")
 
 
 def pf_measure(packed, n_res, precision, states, traj_bias, modality_logw, logw_stride, loglik, combine,
-               N, M, d):
+               range_flag, N, M, d):
     with _on(states):
         _check(load().mmf_pf_measure(ptr(packed), n_res, precision, ptr(states), ptr(traj_bias),
                                      ptr(modality_logw), logw_stride, ptr(loglik), int(combine),
-                                     N, M, d, stream_of(states)), "mmf_pf_measure")
+                                     ptr(range_flag, dtype=torch.int32), N, M, d,
+                                     stream_of(states)), "mmf_pf_measure")
 
 
 def dynamics_jacobian(packed, n_res, states_in, traj_bias, states_out, jac, N, d):

@@ -37,6 +37,7 @@ constexpr int kHeadRows = MMF_MAX_STATE_DIM + 1;
 constexpr int kLayerFloats = kUnits * kUnits;
 constexpr int kThreads = 512;                 // 8 waves = 2 per SIMD, one workgroup per CU (LDS)
 constexpr int kWavesPerBlock = kThreads / MMF_WAVE;
+constexpr float kF16SplitMax = 65504.0f;      // hi = RTZ_f16(x) must stay finite and unsaturated
 
 __host__ __device__ constexpr int num_layers(int n_res) { return 3 + 2 * n_res; }
 __host__ __device__ constexpr int off_w0() { return 0; }
@@ -213,7 +214,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, uns
 }
 
 template <int CT>
-__device__ __forceinline__ void split_act(const Act<CT>& x, SplitAct<CT>& o) {
+__device__ __forceinline__ void split_act(const Act<CT>& x, SplitAct<CT>& o, float& amax) {
 #pragma unroll
   for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
@@ -224,7 +225,9 @@ __device__ __forceinline__ void split_act(const Act<CT>& x, SplitAct<CT>& o) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           unsigned hh, ll;
-          split_pair(x.v[tp][c][8 * u + 2 * p], x.v[tp][c][8 * u + 2 * p + 1], hh, ll);
+          const float x0 = x.v[tp][c][8 * u + 2 * p], x1 = x.v[tp][c][8 * u + 2 * p + 1];
+          amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x0), __builtin_fabsf(x1)));  // v_max3
+          split_pair(x0, x1, hh, ll);
           h[p] = hh;
           l[p] = ll;
         }
@@ -255,13 +258,14 @@ __device__ __forceinline__ void mfma_layer_f16(const float* __restrict__ Wl, con
 
 template <int CT>
 __device__ __forceinline__ void res_block_f16(const float* __restrict__ lds, int n_res, int l1,
-                                              Act<CT>& x, Act<CT>& hbuf, SplitAct<CT>& sp, int lane) {
+                                              Act<CT>& x, Act<CT>& hbuf, SplitAct<CT>& sp, int lane,
+                                              float& amax) {
   const int h = lane >> 5;
-  split_act<CT>(x, sp);
+  split_act<CT>(x, sp, amax);
   add_bias<CT, false>(lds + off_bias(n_res) + l1 * kUnits, hbuf, h, 1.f);
   mfma_layer_f16<CT>(lds + off_layers() + l1 * kLayerFloats, sp, hbuf, lane);
   relu<CT, false>(hbuf, true);
-  split_act<CT>(hbuf, sp);
+  split_act<CT>(hbuf, sp, amax);
   add_bias<CT, true>(lds + off_bias(n_res) + (l1 + 1) * kUnits, x, h, 1.f);
   mfma_layer_f16<CT>(lds + off_layers() + (l1 + 1) * kLayerFloats, sp, x, lane);
   relu<CT, false>(x, true);
@@ -283,6 +287,7 @@ struct NetArgs {
   int M;                    // particles per trajectory (row -> trajectory = row / M)
   int logw_stride;
   int combine;
+  int* range_flag;          // f16x3: set to 1 when an activation left the f16-split range
 };
 
 template <int D, int NRES, int KIND, int CT, int PREC>
@@ -361,7 +366,8 @@ __global__ __launch_bounds__(kThreads, 2) void particle_net_kernel(NetArgs a) {
 
     // ---- encoder residual block (layers 0, 1)
     SplitAct<F16 ? CT : 0> SP;
-    if constexpr (F16) res_block_f16<CT>(lds, NRES, 0, X, H, SP, lane);
+    float amax = 0.f;  // f16x3: largest magnitude handed to the f16 split in this tile
+    if constexpr (F16) res_block_f16<CT>(lds, NRES, 0, X, H, SP, lane, amax);
     else res_block<CT, JAC>(lds, NRES, 0, X, H, lane, primal);
 
     // ---- join layer (2): per-trajectory hoisted half arrives as the accumulator init
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(kThreads, 2) void particle_net_kernel(NetArgs a) {
         }
       }
     if constexpr (F16) {
-      split_act<CT>(X, SP);
+      split_act<CT>(X, SP, amax);
       mfma_layer_f16<CT>(lds + off_layers() + 2 * kLayerFloats, SP, H, lane);
     } else {
       mfma_layer<CT>(lds + off_layers() + 2 * kLayerFloats, X, H, lane);
@@ -388,8 +394,13 @@ __global__ __launch_bounds__(kThreads, 2) void particle_net_kernel(NetArgs a) {
     // ---- residual trunk: activations now live in H, X is scratch
 #pragma unroll
     for (int i = 0; i < NRES; ++i) {
-      if constexpr (F16) res_block_f16<CT>(lds, NRES, 3 + 2 * i, H, X, SP, lane);
+      if constexpr (F16) res_block_f16<CT>(lds, NRES, 3 + 2 * i, H, X, SP, lane, amax);
       else res_block<CT, JAC>(lds, NRES, 3 + 2 * i, H, X, lane, primal);
+    }
+
+    if constexpr (F16) {
+      // an operand beyond the f16 range saturates the split (finite but wrong): report it
+      if (a.range_flag != nullptr && !(amax < kF16SplitMax)) atomicOr(a.range_flag, 1);
     }
 
     // ---- head (64 -> NOUT) on the VALU: each lane holds 32 of the 64 features of its columns
@@ -554,7 +565,7 @@ extern "C" int mmf_pack_particle_net(const MmfParticleNetDesc* d, float* packed,
 
 extern "C" int mmf_pf_dynamics(const float* packed, int n_res, int precision, const float* states_in,
                                const float* traj_bias, const float* noise, const float* scale_tril,
-                               float* states_out, int N, int M, int d, void* stream) {
+                               float* states_out, int* range_flag, int N, int M, int d, void* stream) {
   if (!packed || !states_in || !traj_bias || !states_out || (noise && !scale_tril)) return MMF_EINVAL;
   if (N < 0 || M < 1) return MMF_EINVAL;
   if (static_cast<long long>(N) * M > 0x7fffffffLL / 8) return MMF_ETOOLARGE;
@@ -562,12 +573,14 @@ extern "C" int mmf_pf_dynamics(const float* packed, int n_res, int precision, co
   NetArgs a{};
   a.packed = packed; a.states_in = states_in; a.traj_bias = traj_bias; a.noise = noise;
   a.scale_tril = scale_tril; a.states_out = states_out; a.R = N * M; a.M = M;
+  a.range_flag = range_flag;
   return launch<kDynamics>(a, d, n_res, precision, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mmf_pf_measure(const float* packed, int n_res, int precision, const float* states,
                               const float* traj_bias, const float* modality_logw, int logw_stride,
-                              float* loglik, int combine, int N, int M, int d, void* stream) {
+                              float* loglik, int combine, int* range_flag, int N, int M, int d,
+                              void* stream) {
   if (!packed || !states || !traj_bias || !loglik) return MMF_EINVAL;
   if (N < 0 || M < 1) return MMF_EINVAL;
   if (static_cast<long long>(N) * M > 0x7fffffffLL / 8) return MMF_ETOOLARGE;
@@ -575,6 +588,7 @@ extern "C" int mmf_pf_measure(const float* packed, int n_res, int precision, con
   NetArgs a{};
   a.packed = packed; a.states_in = states; a.traj_bias = traj_bias; a.mod_logw = modality_logw;
   a.logw_stride = logw_stride; a.loglik = loglik; a.combine = combine; a.R = N * M; a.M = M;
+  a.range_flag = range_flag;
   return launch<kMeasure>(a, d, n_res, precision, static_cast<hipStream_t>(stream));
 }
 

@@ -68,13 +68,36 @@ def require_device(t: torch.Tensor, what: str):
 
 # Arithmetic of the per-particle 64x64 layers: "f32" (exact fp32 products on the f32 MFMA) or
 # "f16x3" (operands split into two halves, three f16 MFMA products, fp32 accumulate; ~2^-22).
-DEFAULT_PRECISION = os.environ.get("MMF_PRECISION", "f32")
+DEFAULT_PRECISION = os.environ.get("MMF_PRECISION", "f16x3")
 
 
 def set_default_precision(name: str):
     global DEFAULT_PRECISION
     assert name in _abi.PRECISIONS, name
     DEFAULT_PRECISION = name
+
+
+_RANGE_FLAGS = {}
+
+
+def range_flag(device) -> torch.Tensor:
+    """Per-device sticky int32: the f16x3 kernels OR 1 into it when an activation left the
+    range in which the two-half split is exact."""
+    key = str(device)
+    if key not in _RANGE_FLAGS:
+        _RANGE_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _RANGE_FLAGS[key]
+
+
+def check_range(device):
+    """Raise if any f16x3 launch since the last check saturated its operand split (one
+    4-byte device->host read; filters call it once per ``forward_loop`` / on demand)."""
+    flag = _RANGE_FLAGS.get(str(device))
+    if flag is not None and int(flag.item()) != 0:
+        flag.zero_()
+        raise _abi.MmfError(
+            "an activation exceeded the f16x3 operand range (|x| >= 65504): results of the last "
+            "filter steps are invalid; set MMF_PRECISION=f32 / engine.set_default_precision('f32')")
 
 
 class PackedParticleNet:
@@ -166,7 +189,7 @@ def run_dynamics(net: PackedParticleNet, states: torch.Tensor, traj_bias: torch.
     _timed("particle_net_dynamics", 2.0 * R * particle_net_macs(d, net.n_res, net.n_out),
            R * 4.0 * (2 * d + (d if noise is not None else 0)),
            lambda: _abi.pf_dynamics(blob, net.n_res, net.precision_code(), states, traj_bias, noise_c,
-                                    tril_c, out, N, R // N, d))
+                                    tril_c, out, range_flag(states.device), N, R // N, d))
     return out
 
 
@@ -182,7 +205,8 @@ def run_measure(net: PackedParticleNet, states: torch.Tensor, traj_bias: torch.T
     _timed("particle_net_measure", 2.0 * R * particle_net_macs(d, net.n_res, net.n_out),
            R * 4.0 * (d + 1 + (1 if combine else 0)),
            lambda: _abi.pf_measure(blob, net.n_res, net.precision_code(), states, traj_bias,
-                                   modality_logw, logw_stride, loglik, combine, N, R // N, d))
+                                   modality_logw, logw_stride, loglik, combine,
+                                   range_flag(states.device), N, R // N, d))
     return loglik
 
 
@@ -253,6 +277,10 @@ _IMAGE_CHUNK = 2048  # images per K4 launch sequence (workspace ~0.8 GB per enco
 
 
 def _image_workspace(device, n_images: int, n_nets: int) -> torch.Tensor:
+    # sized for a full chunk as soon as more than one step's worth of images shows up, so a
+    # long forward_loop never re-allocates (hipMalloc of ~1 GB stalls the stream)
+    if n_images > 256:
+        n_images = max(n_images, _IMAGE_CHUNK)
     need = _abi.image_encoder_workspace_bytes(n_images, n_nets)
     key = str(device)
     ws = _IMAGE_WORKSPACES.get(key)

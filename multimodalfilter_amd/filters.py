@@ -16,7 +16,7 @@ from typing import Optional
 import torch
 
 from . import _abi, base
-from .engine import _timed, require_device
+from .engine import _timed, check_range, require_device
 from .utils import NoiseSource, tree_index, tree_leading_shape, tree_map
 
 _MODES = {"none": 0, "systematic": 1, "multinomial": 2}
@@ -167,7 +167,9 @@ class ParticleFilter(base.Filter):
                 tree_index(observations, t), tree_index(controls, t),
                 None if obs_all is None else {k: v[sl] for k, v in obs_all.items()},
                 None if ctrl_all is None else {k: v[sl] for k, v in ctrl_all.items()}))
-        return torch.stack(out, dim=0)
+        result = torch.stack(out, dim=0)
+        check_range(result.device)  # f16x3 operand range (one 4-byte read per loop)
+        return result
 
 
 class VirtualSensorExtendedKalmanFilter(base.Filter):

@@ -398,3 +398,31 @@ def test_k2_f16x3_error_against_fp64(task):
     finally:
         engine.set_default_precision(old)
     assert errs["f32"] < 1e-5 and errs["f16x3"] < 1e-5, errs
+
+
+def test_k2_f16x3_range_flag_reports_saturated_split():
+    """Activations beyond the f16 range make the two-half split inexact: the kernel must say so."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import _abi, engine
+
+    dev = _cuda()
+    dyn = mmf.door_models.DoorDynamicsModelBrent()
+    _seeded(dyn)
+    with torch.no_grad():
+        dyn.state_layers[0].weight.mul_(1e5)  # first-layer outputs ~1e5 > 65504
+    dyn.to(dev)
+    x = torch.randn((2, 64, 3), device=dev)
+    ctx = dyn.encode_controls(torch.randn((2, 7), device=dev))
+    old = engine.DEFAULT_PRECISION
+    try:
+        engine.set_default_precision("f16x3")
+        engine.check_range(dev)  # clear
+        dyn.propagate_encoded(x, ctx, None)
+        with pytest.raises(_abi.MmfError, match="f16x3 operand range"):
+            engine.check_range(dev)
+        engine.check_range(dev)  # flag was reset
+        engine.set_default_precision("f32")
+        dyn.propagate_encoded(x, ctx, None)
+        engine.check_range(dev)  # f32 path never raises it
+    finally:
+        engine.set_default_precision(old)
