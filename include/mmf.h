@@ -184,6 +184,50 @@ int mmf_pack_image_encoder(const MmfImageEncoderDesc* desc /* host */, float* pa
 int mmf_image_encoder(const float* const* packed, int n_nets, const float* images, float* feat,
                       void* workspace, int N, void* stream);
 
+/* ---------------------------------------------------------------- K7: per-trajectory MLP programs
+ * The N-row networks around the filters (vector encoders layers.py:11-40,66-95; PF weight
+ * model crossmodal_pf.py:74-106; virtual sensor kf.py:81-126; EKF weight model
+ * crossmodal_kf.py:134-167; hoisted join-layer halves) as ONE launch per model: a list of
+ * instructions interpreted per row.  Vectors (<= 128 wide) live in MMF_TRAJ_SLOTS per-wave
+ * LDS slots.
+ *   LOAD        slot[dst][0:out_dim] = io[io][row*io_stride + io_off + 0:out_dim]
+ *   LINEAR      slot[dst] = act(W cat(slot[src[s]][src_off[s] : src_off[s]+src_dim[s]] ..) + b (+ slot[res]));  W is stored
+ *               TRANSPOSED in `weights` at w_off as [sum(src_dim)][out_dim <= 64 ? 64 : 128]
+ *   STORE       io[io][row*io_stride + io_off + 0:out_dim] = act(slot[src[0]])
+ *   STORE_DIAG  io[io][row*io_stride + io_off + 0:d*d] = diag(act(slot[src[0]][0:d])), d = out_dim
+ */
+#define MMF_TRAJ_MAX_IO 8
+#define MMF_TRAJ_SLOTS 8
+#define MMF_TRAJ_LOAD 0
+#define MMF_TRAJ_LINEAR 1
+#define MMF_TRAJ_STORE 2
+#define MMF_TRAJ_STORE_DIAG 3
+#define MMF_TRAJ_ACT_NONE 0
+#define MMF_TRAJ_ACT_RELU 1
+#define MMF_TRAJ_ACT_SIGMOID 2
+#define MMF_TRAJ_ACT_SQRT_SQ_PLUS 3   /* sqrt(x*x + fparam): kf.py:117-126 */
+
+typedef struct MmfTrajInstr {
+  int32_t op, dst;
+  int32_t src[4];       /* source slots, -1 = unused */
+  int32_t src_off[4];   /* first feature read from each source slot (multiple of 4) */
+  int32_t src_dim[4];
+  int32_t out_dim;
+  int32_t w_off, b_off; /* float offsets into `weights`; b_off = -1: no bias */
+  int32_t res;          /* residual slot or -1 */
+  int32_t act;
+  int32_t io, io_stride, io_off;
+  float fparam;
+} MmfTrajInstr;
+
+/*  prog     (n_instr) MmfTrajInstr on the DEVICE
+ *  weights  device blob the instructions index
+ *  io       HOST array of MMF_TRAJ_MAX_IO device pointers (inputs and outputs; unused = null)
+ *  R        rows
+ */
+int mmf_traj_program(const MmfTrajInstr* prog, int n_instr, const float* weights,
+                     float* const* io, int R, void* stream);
+
 /* ---------------------------------------------------------------- K3: EKF algebra + fusion
  * Replaces torchfilter's EKF predict/update (A S A^T + L L^T; K = S-(S- + R)^-1;
  * mu = mu- + K(z - mu-); S = (I-K)S-) for K sub-filters and the reference's

@@ -36,6 +36,18 @@ class MmfParticleNetDesc(Structure):
     ]
 
 
+TRAJ_MAX_IO, TRAJ_SLOTS = 8, 8
+TRAJ_LOAD, TRAJ_LINEAR, TRAJ_STORE, TRAJ_STORE_DIAG = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQRT_SQ_PLUS = 0, 1, 2, 3
+
+
+class MmfTrajInstr(Structure):
+    _fields_ = [("op", c_int32), ("dst", c_int32), ("src", c_int32 * 4), ("src_off", c_int32 * 4), ("src_dim", c_int32 * 4),
+                ("out_dim", c_int32), ("w_off", c_int32), ("b_off", c_int32), ("res", c_int32),
+                ("act", c_int32), ("io", c_int32), ("io_stride", c_int32), ("io_off", c_int32),
+                ("fparam", c_float)]
+
+
 class MmfImageEncoderDesc(Structure):
     _fields_ = [("conv_w", _FP * 5), ("conv_b", _FP * 5), ("fc_w", _FP), ("fc_b", _FP),
                 ("res_w", _FP * 2), ("res_b", _FP * 2)]
@@ -52,6 +64,7 @@ SIGNATURES = {
     "mmf_pf_measure": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, c_int, _FP, c_int, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_dynamics_jacobian": (c_int, [_FP, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_ekf_step": (c_int, [_FP] * 10 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmf_traj_program": (c_int, [_FP, c_int, _FP, POINTER(c_void_p), c_int, c_void_p]),
     "mmf_image_encoder_floats": (c_size_t, []),
     "mmf_image_encoder_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mmf_pack_image_encoder": (c_int, [POINTER(MmfImageEncoderDesc), _FP, c_void_p]),
@@ -195,3 +208,12 @@ def image_encoder(blobs, images: torch.Tensor, feat: torch.Tensor, workspace: to
         _check(load().mmf_image_encoder(arr, n, ptr(images), ptr(feat),
                                         ptr(workspace, dtype=torch.uint8), N, stream_of(images)),
                "mmf_image_encoder")
+
+
+def traj_program(prog: torch.Tensor, n_instr: int, weights: torch.Tensor, io_tensors, R: int):
+    """``prog``: uint8 device tensor holding ``n_instr`` MmfTrajInstr; ``io_tensors``: up to
+    TRAJ_MAX_IO float32 device tensors (``None`` = unused)."""
+    arr = (c_void_p * TRAJ_MAX_IO)(*[ptr(t) for t in io_tensors] + [None] * (TRAJ_MAX_IO - len(io_tensors)))
+    with _on(weights):
+        _check(load().mmf_traj_program(ptr(prog, dtype=torch.uint8), n_instr, ptr(weights), arr, R,
+                                       stream_of(weights)), "mmf_traj_program")

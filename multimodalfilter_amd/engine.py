@@ -165,13 +165,6 @@ class PackedParticleNet:
         self._blobs[prec] = (stamp, blob)
         return blob
 
-    def traj_bias(self, traj_features: torch.Tensor) -> torch.Tensor:
-        """Hoisted per-trajectory half of the join layer: ``W[:, traj cols] f + b`` -> ``(N, 64)``."""
-        W = self.join.weight
-        off = self.join_state_off
-        cols = torch.cat((W[:, :off], W[:, off + _abi.MMF_UNITS:]), dim=1) if off + _abi.MMF_UNITS < W.shape[1] else W[:, :off]
-        return torch.addmm(self.join.bias, traj_features, cols.t()).contiguous()
-
 
 def run_dynamics(net: PackedParticleNet, states: torch.Tensor, traj_bias: torch.Tensor,
                  noise, scale_tril, out: torch.Tensor = None) -> torch.Tensor:

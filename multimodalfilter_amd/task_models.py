@@ -20,7 +20,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import base, base_models, engine, filters, layers
+from . import _abi, base, base_models, engine, filters, layers
+from .trajprog import TrajProgram
 
 _ROW_CHUNK = 8192  # cap on rows per encoder call (bounds conv activations for big T*N)
 
@@ -81,20 +82,35 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             if "sensors" in self.modalities:
                 self.observation_sensors_layers = layers.vector_encoder(task.obs_sensors_dim, units)
 
-        def observation_features(self, observations, image_feat=None) -> torch.Tensor:
-            """``image_feat``: this model's image features when a container already ran the
-            image encoders of a step as one batch (``engine.encode_images``)."""
+        def _emit_observation_sources(self, prog: TrajProgram):
+            """LOAD + encode every modality; returns the ``(slot, offset, width)`` list in the
+            reference's concatenation order (image, pos, sensors)."""
+            srcs = []
+            if "image" in self.modalities:
+                srcs.append((prog.load("image_feat", 64), 0, 64))
+            if "pos" in self.modalities:
+                raw = prog.load("gripper_pos", task.obs_pos_dim)
+                srcs.append((prog.vector_encoder(self.observation_pos_layers, raw, task.obs_pos_dim), 0, 64))
+                prog.free(raw)
+            if "sensors" in self.modalities:
+                raw = prog.load("gripper_sensors", task.obs_sensors_dim)
+                srcs.append((prog.vector_encoder(self.observation_sensors_layers, raw, task.obs_sensors_dim), 0, 64))
+                prog.free(raw)
+            return srcs
+
+        def _program_inputs(self, observations, image_feat=None):
+            """Device tensors for the LOADs emitted by ``_emit_observation_sources``."""
             assert type(observations) == dict
-            obs = []
+            t = {}
             if "image" in self.modalities:
                 if image_feat is None:
                     image_feat = engine.encode_observation_images([self], observations)[0]
-                obs.append(image_feat)
+                t["image_feat"] = image_feat.to(torch.float32).contiguous()
             if "pos" in self.modalities:
-                obs.append(self.observation_pos_layers(observations["gripper_pos"]))
+                t["gripper_pos"] = observations["gripper_pos"].to(torch.float32).contiguous()
             if "sensors" in self.modalities:
-                obs.append(self.observation_sensors_layers(observations["gripper_sensors"]))
-            return torch.cat(obs, dim=1)
+                t["gripper_sensors"] = observations["gripper_sensors"].to(torch.float32).contiguous()
+            return t
 
     # ------------------------------------------------------------- R1 dynamics
     class _Dynamics(base.DynamicsModel):
@@ -118,6 +134,7 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
                 nn.Linear(units, D + 1),
             )
             self.units = units
+            self._ctrl_prog = None
             self._net = engine.PackedParticleNet(
                 encoder=self.state_layers, join=self.shared_layers[0], join_state_off=units,
                 res_blocks=[self.shared_layers[1], self.shared_layers[2], self.shared_layers[3]],
@@ -130,8 +147,19 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
 
         # encoded protocol (see base.py)
         def encode_controls(self, controls):
-            with torch.no_grad():
-                return {"bias": self._net.traj_bias(self.control_layers(controls))}
+            """Control encoder + the hoisted control half of ``shared_layers[0]``: one K7 launch."""
+            if self._ctrl_prog is None:
+                p = TrajProgram()
+                u = p.load("controls", task.control_dim)
+                c = p.vector_encoder(self.control_layers, u, task.control_dim)
+                b = p.linear([(c, 0, self.units)], self.shared_layers[0], cols=(0, self.units))
+                p.store("bias", b, self.units)
+                self._ctrl_prog = p
+            engine.require_device(controls, f"{type(self).__name__}.encode_controls")
+            R = controls.shape[0]
+            bias = torch.empty((R, self.units), dtype=torch.float32, device=controls.device)
+            self._ctrl_prog.run({"controls": controls.to(torch.float32).contiguous(), "bias": bias}, R)
+            return {"bias": bias}
 
         def propagate_encoded(self, states, ctx, noise, out=None):
             return engine.run_dynamics(self._net, states, ctx["bias"], noise, self.scale_tril(), out=out)
@@ -177,14 +205,26 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
                 nn.Linear(units, 1),
             )
             self.units = units
+            self._obs_prog = None
             self._net = engine.PackedParticleNet(
                 encoder=self.state_layers, join=self.shared_layers[0], join_state_off=units * k,
                 res_blocks=[self.shared_layers[2], self.shared_layers[3]],
                 head=self.shared_layers[4], relu_after_join=True)
 
         def encode_observations(self, observations, image_feat=None):
-            with torch.no_grad():
-                return {"bias": self._net.traj_bias(self.observation_features(observations, image_feat))}
+            """Observation encoders + the hoisted observation half of ``shared_layers[0]``."""
+            if self._obs_prog is None:
+                p = TrajProgram()
+                srcs = self._emit_observation_sources(p)
+                b = p.linear(srcs, self.shared_layers[0], cols=(0, self.units * len(self.modalities)))
+                p.store("bias", b, self.units)
+                self._obs_prog = p
+            t = self._program_inputs(observations, image_feat)
+            R = observations["gripper_pos"].shape[0]
+            t["bias"] = torch.empty((R, self.units), dtype=torch.float32, device=observations["gripper_pos"].device)
+            engine.require_device(t["bias"], f"{type(self).__name__}.encode_observations")
+            self._obs_prog.run(t, R)
+            return {"bias": t["bias"]}
 
         def forward_encoded(self, states, ctx, *, loglik=None, combine=False, modality_logw=None,
                             logw_stride=0):
@@ -212,6 +252,7 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             modality_count = 2
             super().__init__(modality_count=modality_count)
             self.know_image_blackout = know_image_blackout
+            self._prog = None
             self._build_obs_encoders({"image", "pos", "sensors"}, units)
             self.fusion_layers = nn.Sequential(
                 nn.Linear(units * 3, units), nn.ReLU(),
@@ -221,7 +262,21 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
 
         def forward(self, *, observations, image_feat=None):
             N, _ = observations["gripper_pos"].shape
-            output = self.fusion_layers(self.observation_features(observations, image_feat))
+            if self._prog is None:
+                p = TrajProgram()
+                srcs = self._emit_observation_sources(p)
+                x = p.linear(srcs, self.fusion_layers[0], _abi.ACT_RELU)
+                for blk in list(self.fusion_layers)[2:-1]:
+                    p.res_linear(blk, x, blk.block1.in_features)
+                p.store("out", p.linear([(x, 0, self.fusion_layers[0].out_features)], self.fusion_layers[-1]),
+                        self.modality_count)
+                self._prog = p
+            t = self._program_inputs(observations, image_feat)
+            output = torch.empty((N, self.modality_count), dtype=torch.float32,
+                                 device=observations["gripper_pos"].device)
+            engine.require_device(output, f"{type(self).__name__}.forward")
+            t["out"] = output
+            self._prog.run(t, N)
             assert output.shape == (N, self.modality_count)
             if self.know_image_blackout:
                 output[blackout_rows(observations["image"]), 0] -= np.inf
@@ -295,19 +350,45 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             self.r_layer = head()
             self.z_layer = head()
             self.units = units
+            self._prog = None
             self.add_R_noise = torch.ones(D) * add_R_noise
 
         def forward(self, *, observations, image_feat=None):
             assert type(observations) == dict
             N, _ = observations["gripper_pos"].shape
-            shared = self.shared_layers(self.observation_features(observations, image_feat))
-            z = self.z_layer(shared[:, : self.units])
-            assert z.shape == (N, self.state_dim)
-            lt_hat = self.r_layer(shared[:, self.units:]) if self.noise_R_tril is None else self.noise_R_tril
-            cov = torch.diag_embed(lt_hat) ** 2
-            if self.add_R_noise[0] > 0:
-                cov = cov + torch.diag(self.add_R_noise).to(cov.device)
-            return z, torch.sqrt(cov)
+            if self.noise_R_tril is not None:
+                raise NotImplementedError("a fixed noise_R_tril is not supported by the HIP virtual sensor")
+            d, U = self.state_dim, self.units
+            if self._prog is None:
+                p = TrajProgram()
+                srcs = self._emit_observation_sources(p)
+                sh = p.linear(srcs, self.shared_layers[0], _abi.ACT_RELU)           # 2U wide
+                for (slot, _o, _w) in srcs:
+                    p.free(slot)
+                p.res_linear(self.shared_layers[2], sh, 2 * U)
+                p.res_linear(self.shared_layers[3], sh, 2 * U)
+
+                def head(layer, off, name, **store_kw):
+                    a = p.linear([(sh, off, U)], layer[0], _abi.ACT_RELU)
+                    p.res_linear(layer[2], a, d)
+                    o = p.linear([(a, 0, d)], layer[3])
+                    p.store(name, o, d, **store_kw)
+                    p.free(a)
+                    p.free(o)
+
+                head(self.z_layer, 0, "z")
+                # sqrt(diag(r)^2 + add_R_noise I) (kf.py:117-126)
+                head(self.r_layer, U, "tril", diag=True, act=_abi.ACT_SQRT_SQ_PLUS,
+                     fparam=float(self.add_R_noise[0]) if self.add_R_noise[0] > 0 else 0.0)
+                self._prog = p
+            t = self._program_inputs(observations, image_feat)
+            dev = observations["gripper_pos"].device
+            engine.require_device(observations["gripper_pos"], f"{type(self).__name__}.forward")
+            t["z"] = torch.empty((N, d), dtype=torch.float32, device=dev)
+            t["tril"] = torch.empty((N, d, d), dtype=torch.float32, device=dev)
+            self._prog.run(t, N)
+            assert t["z"].shape == (N, self.state_dim)
+            return t["z"], t["tril"]
 
     VirtualSensorModel.__name__ = VirtualSensorModel.__qualname__ = f"{P}VirtualSensorModel"
     setattr(ns, f"{P}VirtualSensorModel", VirtualSensorModel)
@@ -337,10 +418,25 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             )
             self.know_image_blackout = know_image_blackout
             self.fix_weight_layout = fix_weight_layout
+            self._prog = None
 
         def forward(self, *, observations, image_feat=None):
             N, _ = observations["gripper_pos"].shape
-            output = self.fusion_layers(self.observation_features(observations, image_feat))
+            out_dim = self.modality_count * self.state_dim
+            if self._prog is None:
+                p = TrajProgram()
+                srcs = self._emit_observation_sources(p)
+                x = p.linear(srcs, self.fusion_layers[0], _abi.ACT_RELU)
+                p.res_linear(self.fusion_layers[2], x, self.fusion_layers[0].out_features)
+                o = p.linear([(x, 0, self.fusion_layers[0].out_features)], self.fusion_layers[3],
+                             _abi.ACT_SIGMOID)
+                p.store("out", o, out_dim)
+                self._prog = p
+            t = self._program_inputs(observations, image_feat)
+            output = torch.empty((N, out_dim), dtype=torch.float32, device=observations["gripper_pos"].device)
+            engine.require_device(output, f"{type(self).__name__}.forward")
+            t["out"] = output
+            self._prog.run(t, N)
             assert output.shape == (N, self.modality_count * self.state_dim)
             if self.fix_weight_layout:
                 w = output.view(N, self.modality_count, self.state_dim).permute(1, 0, 2)
