@@ -195,6 +195,10 @@ def main():
     import multimodalfilter_amd as mmf
     from multimodalfilter_amd import _abi, distributed, engine, evaluation, synthetic
 
+    # The host has hundreds of hardware threads; torch's default intra-op pool (one thread per
+    # core) leaves that many OpenMP workers spin-waiting after every CPU tensor op (synthetic
+    # input generation), which starves the launch thread for the next ~0.1 s.
+    torch.set_num_threads(min(CPU_THREADS, os.cpu_count() or 1))
     _abi.load()  # fail loudly before touching the GPU if the HIP library is missing
     if args.precision:
         engine.set_default_precision(args.precision)
@@ -231,6 +235,7 @@ def main():
         noise = synthetic.draw_filter_noise(T=K, N=B, M=M, state_dim=d, seed=78 + rank)
         mv = lambda nz: (nz[0].to(device), [e.to(device) for e in nz[1]], [u.to(device) for u in nz[2]])
         noise_w, noise = mv(noise_w), mv(noise)
+        f.reserve(steps=K, batch=B, particles=M)  # memory planned before the warm-up
         run = lambda tr, nz: run_pf(f, tr, nz, M)
     else:
         noise_w = noise = None
@@ -238,8 +243,10 @@ def main():
 
     def timed_pass():
         """W untimed warm-up steps, then exactly K timed steps; returns (seconds, timer, mse)."""
-        if W > 0:
-            run(traj_w, noise_w)
+        if W > 0:  # the warm-up covers the whole path, including the evaluation statistic
+            pred_w = run(traj_w, noise_w)
+            distributed.all_gather_rows(
+                evaluation.per_trajectory_mse(pred_w, traj_w["states"][1:], start=min(30, W // 2)))
         torch.cuda.synchronize()
         timer = None if args.no_kernel_timers else engine.KernelTimer()
         engine.set_kernel_timer(timer)

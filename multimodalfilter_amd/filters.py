@@ -16,7 +16,7 @@ from typing import Optional
 import torch
 
 from . import _abi, base
-from .engine import _timed, check_range, require_device
+from .engine import _timed, check_range, require_device, reserve_memory
 from .utils import NoiseSource, tree_index, tree_leading_shape, tree_map
 
 _MODES = {"none": 0, "systematic": 1, "multinomial": 2}
@@ -72,6 +72,18 @@ class ParticleFilter(base.Filter):
         self.particle_log_weights = mean.new_full((N, M), -math.log(M))
         self._spare_states = None
         self._initialized = True
+
+    def reserve(self, *, steps: int, batch: int, particles: int = None) -> int:
+        """Plan memory for ``forward_loop`` over ``steps`` x ``batch`` trajectories: grows the
+        allocator once so the loop itself never calls ``hipMalloc``.  Returns the bytes reserved."""
+        M = self.num_particles if particles is None else particles
+        d = self.state_dim
+        dev = next(self.parameters()).device
+        per_row = 64 * 4 * 12               # encoder contexts, image features, program outputs
+        per_step = batch * M * 4 * (2 * d + 4)  # particle ping-pong, log-weights, log-lik, noise views
+        nbytes = steps * batch * per_row + 4 * per_step + (64 << 20)
+        reserve_memory(dev, nbytes)
+        return nbytes
 
     # ------------------------------------------------------------------ one step
     def _propagate(self, controls, ctrl_ctx, N, M, d):
