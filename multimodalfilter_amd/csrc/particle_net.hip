@@ -21,6 +21,7 @@
 // Roofline: 2 FLOP/MAC * {37,312 dynamics | 28,928 measurement} MAC per particle against
 // ~32 B of HBM traffic => compute bound on the f32 MFMA peak (157.3 TFLOP/s); DESIGN.md.
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 #include "mmf_common.h"
 
@@ -35,8 +36,6 @@ constexpr int kUnits = MMF_UNITS;
 constexpr int kW0Cols = 8;                    // first layer padded to K = 8 (state dims, 1, zeros)
 constexpr int kHeadRows = MMF_MAX_STATE_DIM + 1;
 constexpr int kLayerFloats = kUnits * kUnits;
-constexpr int kThreads = 512;                 // 8 waves = 2 per SIMD, one workgroup per CU (LDS)
-constexpr int kWavesPerBlock = kThreads / MMF_WAVE;
 constexpr float kF16SplitMax = 65504.0f;      // hi = RTZ_f16(x) must stay finite and unsaturated
 
 __host__ __device__ constexpr int num_layers(int n_res) { return 3 + 2 * n_res; }
@@ -163,6 +162,14 @@ __device__ __forceinline__ void add_bias(const float* __restrict__ bl, Act<CT>& 
     }
 }
 
+// max(v, 0) as ONE instruction: on accumulator outputs hipcc adds a canonicalising v_max in
+// front of fmaxf (2 ops per element).  On the raw bits, max((int)v, 0) is the same function
+// for every non-NaN float (negative floats are negative ints; -0.0 -> +0.0) and is a single
+// v_max_i32.  (Not inline asm: hipcc pads no MFMA->VALU wait states around asm operands.)
+__device__ __forceinline__ float relu1(float v) {
+  return __int_as_float(max(__float_as_int(v), 0));
+}
+
 template <int CT, bool JAC>
 __device__ __forceinline__ void relu(Act<CT>& a, bool primal) {
 #pragma unroll
@@ -175,9 +182,9 @@ __device__ __forceinline__ void relu(Act<CT>& a, bool primal) {
         if (JAC) {
           // tangent columns follow the primal's mask (sub-gradient 0 at 0, as autograd)
           const float pv = quad_first(v);
-          a.v[t][c][r] = primal ? fmaxf(v, 0.f) : (pv > 0.f ? v : 0.f);
+          a.v[t][c][r] = primal ? relu1(v) : (pv > 0.f ? v : 0.f);
         } else {
-          a.v[t][c][r] = fmaxf(v, 0.f);
+          a.v[t][c][r] = relu1(v);
         }
       }
 }
@@ -206,13 +213,20 @@ struct SplitAct {
   half8 hi[4][CT], lo[4][CT];  // [k-step][col tile]
 };
 
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
   const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-  const auto l = __builtin_amdgcn_cvt_pkrtz(x0 - static_cast<float>(h[0]), x1 - static_cast<float>(h[1]));
+  const f32x2 x = {x0, x1};
+  const f32x2 hf = {static_cast<float>(h[0]), static_cast<float>(h[1])};
+  const f32x2 r = x - hf;  // one v_pk_add_f32; exact (the residual has <= 13 significant bits)
+  const auto l = __builtin_amdgcn_cvt_pkrtz(r[0], r[1]);
   hi = __builtin_bit_cast(unsigned, h);
   lo = __builtin_bit_cast(unsigned, l);
 }
 
+// Every activation that reaches a split is a ReLU output (>= 0): its magnitude is tracked
+// with a plain max (no abs).
 template <int CT>
 __device__ __forceinline__ void split_act(const Act<CT>& x, SplitAct<CT>& o, float& amax) {
 #pragma unroll
@@ -226,7 +240,7 @@ __device__ __forceinline__ void split_act(const Act<CT>& x, SplitAct<CT>& o, flo
         for (int p = 0; p < 4; ++p) {
           unsigned hh, ll;
           const float x0 = x.v[tp][c][8 * u + 2 * p], x1 = x.v[tp][c][8 * u + 2 * p + 1];
-          amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x0), __builtin_fabsf(x1)));  // v_max3
+          amax = __builtin_fmaxf(amax, __builtin_fmaxf(x0, x1));
           split_pair(x0, x1, hh, ll);
           h[p] = hh;
           l[p] = ll;
@@ -290,8 +304,10 @@ struct NetArgs {
   int* range_flag;          // f16x3: set to 1 when an activation left the f16-split range
 };
 
-template <int D, int NRES, int KIND, int CT, int PREC>
-__global__ __launch_bounds__(kThreads, 2) void particle_net_kernel(NetArgs a) {
+template <int D, int NRES, int KIND, int CT, int PREC, int WPS>
+__global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgs a) {
+  constexpr int kThreads = WPS * 256;           // WPS waves per SIMD, one workgroup per CU (LDS)
+  constexpr int kWavesPerBlock = kThreads / MMF_WAVE;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr bool JAC = KIND == kJacobian;
   constexpr bool F16 = PREC == MMF_PREC_F16X3;
@@ -366,7 +382,7 @@ __global__ __launch_bounds__(kThreads, 2) void particle_net_kernel(NetArgs a) {
 
     // ---- encoder residual block (layers 0, 1)
     SplitAct<F16 ? CT : 0> SP;
-    float amax = 0.f;  // f16x3: largest magnitude handed to the f16 split in this tile
+    float amax = 0.f;  // f16x3: largest (non-negative) value handed to the split in this tile
     if constexpr (F16) res_block_f16<CT>(lds, NRES, 0, X, H, SP, lane, amax);
     else res_block<CT, JAC>(lds, NRES, 0, X, H, lane, primal);
 
@@ -494,30 +510,34 @@ __global__ __launch_bounds__(kThreads, 2) void particle_net_kernel(NetArgs a) {
   }
 }
 
-template <int D, int NRES, int KIND, int PREC>
-int launch_ct(const NetArgs& a, hipStream_t s) {
+template <int D, int NRES, int KIND, int PREC, int CT, int WPS>
+int launch_variant(const NetArgs& a, hipStream_t s) {
   const size_t lds = static_cast<size_t>(blob_floats(NRES)) * sizeof(float);
-  // small problems: 32-particle tiles spread over more waves; large: 64-particle tiles
-  const bool big = a.R >= 256 * kWavesPerBlock * 64;
-  const int tile = big ? 64 : 32;
+  constexpr int waves = WPS * 4, tile = 32 * CT;
   const int ntiles = (a.R + tile - 1) / tile;
-  int grid = (ntiles + kWavesPerBlock - 1) / kWavesPerBlock;
+  int grid = (ntiles + waves - 1) / waves;
   if (grid > 256) grid = 256;
   if (grid < 1) grid = 1;
-  hipError_t e;
-  if (big) {
-    auto k = particle_net_kernel<D, NRES, KIND, 2, PREC>;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    if (e != hipSuccess) return static_cast<int>(e);
-    k<<<grid, kThreads, lds, s>>>(a);
-  } else {
-    auto k = particle_net_kernel<D, NRES, KIND, 1, PREC>;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-    if (e != hipSuccess) return static_cast<int>(e);
-    k<<<grid, kThreads, lds, s>>>(a);
-  }
+  auto k = particle_net_kernel<D, NRES, KIND, CT, PREC, WPS>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  if (e != hipSuccess) return static_cast<int>(e);
+  k<<<grid, WPS * 256, lds, s>>>(a);
   MMF_CHECK_LAUNCH();
   return 0;
+}
+
+template <int D, int NRES, int KIND, int PREC>
+int launch_ct(const NetArgs& a, hipStream_t s) {
+  // small problems: 32-particle tiles spread over more waves; large: 64-particle tiles
+  const bool big = a.R >= 256 * 8 * 64;
+  static const int variant = [] { const char* v = getenv("MMF_K2_VARIANT"); return v ? atoi(v) : 0; }();
+  if constexpr (PREC == MMF_PREC_F16X3 && KIND != kJacobian) {
+    if (big && variant == 1) return launch_variant<D, NRES, KIND, PREC, 1, 3>(a, s);  // 32-particle tiles, 3 waves/SIMD
+    if (big && variant == 2) return launch_variant<D, NRES, KIND, PREC, 1, 2>(a, s);
+  }
+  if (big) return launch_variant<D, NRES, KIND, PREC, 2, 2>(a, s);
+  return launch_variant<D, NRES, KIND, PREC, 1, 2>(a, s);
 }
 
 template <int KIND>
