@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 3
+#define MMF_ABI_VERSION 4
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -176,13 +176,18 @@ size_t mmf_image_encoder_floats(void);                 /* floats of one packed e
 size_t mmf_image_encoder_workspace_bytes(int n_images, int n_nets);
 int mmf_pack_image_encoder(const MmfImageEncoderDesc* desc /* host */, float* packed, void* stream);
 
-/*  packed    host array of n_nets (1..4) device pointers to packed encoder blobs
- *  images    (N, 32, 32)        shared by every encoder
- *  feat      (n_nets, N, 64)    out
- *  workspace >= mmf_image_encoder_workspace_bytes(N, n_nets) bytes of device memory
+/*  packed     host array of n_nets (1..4) device pointers to packed encoder blobs
+ *  images     (N, 32, 32)        shared by every encoder
+ *  feat       (n_nets, N, 64)    out
+ *  workspace  >= mmf_image_encoder_workspace_bytes(N, n_nets) bytes of device memory
+ *  range_flag int32 on the device or null: MMF_PREC_F16X3 ORs 1 into it when an activation
+ *             left the f16-split range (see mmf_pf_dynamics)
+ *  precision  MMF_PREC_F32: every layer on the f32 MFMA.  MMF_PREC_F16X3: the four 3x3
+ *             convolutions (97 % of the MACs) as split-f16 products in persistent, register-
+ *             prefetching workgroups; the 5x5 stem and the linear tail stay f32.
  */
 int mmf_image_encoder(const float* const* packed, int n_nets, const float* images, float* feat,
-                      void* workspace, int N, void* stream);
+                      void* workspace, int32_t* range_flag, int precision, int N, void* stream);
 
 /* ---------------------------------------------------------------- K7: per-trajectory MLP programs
  * The N-row networks around the filters (vector encoders layers.py:11-40,66-95; PF weight

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmmf_hip.so")
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 PREC_F32, PREC_F16X3 = 0, 1
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}
 
@@ -68,7 +68,7 @@ SIGNATURES = {
     "mmf_image_encoder_floats": (c_size_t, []),
     "mmf_image_encoder_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mmf_pack_image_encoder": (c_int, [POINTER(MmfImageEncoderDesc), _FP, c_void_p]),
-    "mmf_image_encoder": (c_int, [POINTER(c_void_p), c_int, _FP, _FP, _FP, c_int, c_void_p]),
+    "mmf_image_encoder": (c_int, [POINTER(c_void_p), c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
 }
 
 _lib = None
@@ -199,14 +199,17 @@ def pack_image_encoder(desc: MmfImageEncoderDesc, packed: torch.Tensor):
                "mmf_pack_image_encoder")
 
 
-def image_encoder(blobs, images: torch.Tensor, feat: torch.Tensor, workspace: torch.Tensor):
+def image_encoder(blobs, images: torch.Tensor, feat: torch.Tensor, workspace: torch.Tensor,
+                  range_flag, precision: int):
     n = len(blobs)
     arr = (c_void_p * n)(*[ptr(b) for b in blobs])
     N = images.shape[0]
     assert tuple(images.shape[1:]) == (32, 32) and tuple(feat.shape) == (n, N, 64)
     with _on(images):
         _check(load().mmf_image_encoder(arr, n, ptr(images), ptr(feat),
-                                        ptr(workspace, dtype=torch.uint8), N, stream_of(images)),
+                                        ptr(workspace, dtype=torch.uint8),
+                                        ptr(range_flag, dtype=torch.int32), precision, N,
+                                        stream_of(images)),
                "mmf_image_encoder")
 
 

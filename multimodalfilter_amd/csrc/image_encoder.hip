@@ -23,11 +23,17 @@
 //
 // Roofline: 2 * 26.12 MFLOP per image against ~0.9 MB of L2-resident activation traffic:
 // compute-bound on the f32 MFMA peak (157.3 TFLOP/s); DESIGN.md section 3.
+#include <hip/hip_fp16.h>
+
 #include "mmf_common.h"
 
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 constexpr int kImg = 32;         // images are 32 x 32
 constexpr int kBand = 16;        // output rows per workgroup
@@ -48,8 +54,12 @@ __host__ __device__ constexpr int conv_w_floats(int cin, int cout, int ks) {
 
 // ---- packed blob of one encoder (floats) -------------------------------------------------
 struct Layout {
-  int w1, b1, w2a, b2a, w2b, b2b, w3, b3, w4, b4, fcw, fcb, r1t, r1b, r2t, r2b, total;
+  int w1, b1, w2a, b2a, w2b, b2b, w3, b3, w4, b4, fcw, fcb, r1t, r1b, r2t, r2b;
+  int h2a, h2b, h3, h4;  // f16x3 fragment-ordered copies of the 3x3 convolutions' weights
+  int total;
 };
+// floats (= halves / 2) of a 3x3 conv in f16x3 fragment order [tap][kc][hi|lo][lane][8 halves]
+__host__ __device__ constexpr int conv_h_floats(int cin) { return 9 * (cin / 16) * 2 * 64 * 8 / 2; }
 __host__ __device__ constexpr Layout layout() {
   Layout L{};
   int o = 0;
@@ -69,6 +79,10 @@ __host__ __device__ constexpr Layout layout() {
   L.r1b = o; o += kFeat;
   L.r2t = o; o += kFeat * kFeat;
   L.r2b = o; o += kFeat;
+  L.h2a = o; o += conv_h_floats(32);
+  L.h2b = o; o += conv_h_floats(32);
+  L.h3 = o; o += conv_h_floats(32);
+  L.h4 = o; o += conv_h_floats(16);
   L.total = o;
   return L;
 }
@@ -134,8 +148,27 @@ __global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ o
     } else if (q0 < L.r2b) {
       const int e = q0 - L.r2t, k = e / kFeat, o = e % kFeat;
       v = d.res_w[1][o * kFeat + k];
-    } else {
+    } else if (q0 < L.h2a) {
       v = d.res_b[1][q0 - L.r2b];
+    } else {
+      // f16x3 sections: two halves per float slot
+      const int offs[5] = {L.h2a, L.h2b, L.h3, L.h4, L.total};
+      const int cins[4] = {32, 32, 32, 16}, couts[4] = {32, 32, 16, 8};
+      int c = 0;
+      while (q0 >= offs[c + 1]) ++c;
+      const float* W = d.conv_w[c + 1];
+      const int cin = cins[c], cout = couts[c], KC = cin / 16;
+      unsigned short hb[2];
+      for (int z = 0; z < 2; ++z) {
+        const int he = 2 * (q0 - offs[c]) + z;
+        const int i = he & 7, lane = (he >> 3) & 63, part = (he >> 9) & 1, rest = he >> 10;
+        const int kc = rest % KC, tap = rest / KC;
+        const int co = lane & 31, ci = 16 * kc + 8 * (lane >> 5) + i;
+        const float w = co < cout ? W[(co * cin + ci) * 9 + tap] : 0.f;
+        const __half hi = __float2half_rz(w);
+        hb[z] = part ? __half_as_ushort(__float2half_rz(w - __half2float(hi))) : __half_as_ushort(hi);
+      }
+      v = __uint_as_float(static_cast<unsigned>(hb[0]) | (static_cast<unsigned>(hb[1]) << 16));
     }
     out[q0] = v;
   }
@@ -255,6 +288,178 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(ConvArgs a) {
       }
 }
 
+// ---- 3x3 convolution, f16x3 products ---------------------------------------------------------
+// Same band decomposition, but the activations are staged ONCE per band as two f16 planes
+// (x = hi + lo exactly to 2^-22, round-toward-zero) in a channel-innermost [row][col][ci] LDS
+// image, so a B fragment of v_mfma_f32_32x32x16_f16 (8 consecutive input channels of one pixel)
+// is a single ds_read_b128; the 16-byte chunks of a pixel are XOR-swizzled with the column so
+// the 16 lanes of a b128 group fall on 16 different slots of the 256-B bank row.  GEMM view:
+// M = 32 output channels, N = the 32 pixels of an image row, K = 16 input channels of one tap;
+// each product is hi*hi + hi*lo + lo*hi (3 MFMAs at 16x the f32-MFMA rate).  Workgroups are
+// persistent: weights are staged once, and the next band's global loads are issued into
+// registers before the current band is computed (async-STAGE split), so the kernel runs at
+// the HBM / L2 rate of its activation traffic instead of load + compute + store in series.
+struct ConvHArgs {
+  const float* packed[kMaxNets];
+  const float* in;    // (nets, N, CIN, 32, 32) fp32
+  const float* skip;  // (nets, N, COUT, 32, 32) or null
+  float* out;         // (nets, N, COUT, 32, 32)
+  int* range_flag;
+  int N;
+  int hoff, boff;
+};
+
+constexpr int kWPh = 34;  // padded row of the f16 image: 1 | 32 pixels | 1
+
+template <int CIN>
+__device__ __forceinline__ int swz(int col) {
+  return CIN == 32 ? (col >> 2) & 3 : (col >> 3) & 1;
+}
+
+template <int CIN, int COUT, bool RELU, bool SKIP>
+__global__ __launch_bounds__(kConvThreads) void conv_f16x3_kernel(ConvHArgs a) {
+  constexpr int RB = kBand + 2;
+  constexpr int KC = CIN / 16;
+  constexpr int CG = CIN / 8;                      // 16-byte chunks per pixel
+  constexpr int PIX = CIN * 2;                     // bytes per pixel per plane
+  constexpr int PLANE = RB * kWPh * PIX;           // bytes per plane
+  constexpr int NW = 9 * KC * 2 * 64 * 16;         // weight bytes
+  constexpr int ITEMS = RB * CG * kWPh;            // staging items (8 channels of one pixel)
+  constexpr int IPT = (ITEMS + kConvThreads - 1) / kConvThreads;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
+  unsigned char* tile_hi = ldsb;
+  unsigned char* tile_lo = ldsb + PLANE;
+  unsigned char* wl = ldsb + 2 * PLANE;
+
+  const int net = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const float* blob = a.packed[net];
+  {
+    const float4* src = reinterpret_cast<const float4*>(blob + a.hoff);
+    float4* dst = reinterpret_cast<float4*>(wl);
+    for (int i = tid; i < NW / 16; i += kConvThreads) dst[i] = src[i];
+  }
+  const float* in_net = a.in + static_cast<size_t>(net) * a.N * CIN * kImg * kImg;
+  const int nbands = 2 * a.N;
+
+  // prefetch registers: IPT items x 8 channels
+  float pf[IPT][8];
+  auto prefetch = [&](int band) {
+    const int img = band >> 1, y0 = (band & 1) * kBand;
+    const float* in = in_net + static_cast<size_t>(img) * CIN * kImg * kImg;
+#pragma unroll
+    for (int it = 0; it < IPT; ++it) {
+      const int item = tid + it * kConvThreads;
+      const int cc = item % kWPh, rest = item / kWPh, cg = rest % CG, rr = rest / CG;
+      const int y = y0 - 1 + rr, x = cc - 1;
+      const bool ok = item < ITEMS && y >= 0 && y < kImg && x >= 0 && x < kImg;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pf[it][i] = ok ? in[((cg * 8 + i) * kImg + y) * kImg + x] : 0.f;
+    }
+  };
+  float amax = 0.f;
+  auto commit = [&]() {  // registers -> split -> swizzled LDS planes
+#pragma unroll
+    for (int it = 0; it < IPT; ++it) {
+      const int item = tid + it * kConvThreads;
+      if (item < ITEMS) {
+        const int cc = item % kWPh, rest = item / kWPh, cg = rest % CG, rr = rest / CG;
+        u32x4 hv, lv;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const float x0 = pf[it][2 * p], x1 = pf[it][2 * p + 1];
+          amax = fmaxf(amax, fmaxf(fabsf(x0), fabsf(x1)));
+          const auto hh = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+          const f32x2 xs = {x0, x1};
+          const f32x2 hf = {static_cast<float>(hh[0]), static_cast<float>(hh[1])};
+          const f32x2 r = xs - hf;
+          const auto ll = __builtin_amdgcn_cvt_pkrtz(r[0], r[1]);
+          hv[p] = __builtin_bit_cast(unsigned, hh);
+          lv[p] = __builtin_bit_cast(unsigned, ll);
+        }
+        const int off = (rr * kWPh + cc) * PIX + 16 * (cg ^ swz<CIN>(cc));
+        *reinterpret_cast<u32x4*>(tile_hi + off) = hv;
+        *reinterpret_cast<u32x4*>(tile_lo + off) = lv;
+      }
+    }
+  };
+
+  int band = blockIdx.x;
+  if (band < nbands) prefetch(band);
+  for (; band < nbands; band += gridDim.x) {
+    __syncthreads();  // everyone finished reading the previous band's planes (and the weights landed)
+    commit();
+    __syncthreads();
+    if (band + gridDim.x < nbands) prefetch(band + gridDim.x);  // in flight during the MFMAs
+
+    const int img = band >> 1, y0 = (band & 1) * kBand;
+    const int r0 = 2 * wave;
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ch = (r & 3) + 8 * (r >> 2) + 4 * h;
+      const float b = ch < COUT ? blob[a.boff + ch] : 0.f;
+      acc[0][r] = b;
+      acc[1][r] = b;
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap % 3;
+      const int col = j + kx;
+      const int sw = swz<CIN>(col);
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        const unsigned char* wp = wl + ((tap * KC + kc) * 2) * 1024 + lane * 16;
+        const half8 ahi = *reinterpret_cast<const half8*>(wp);
+        const half8 alo = *reinterpret_cast<const half8*>(wp + 1024);
+        const int chunk = (2 * kc + h) ^ sw;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          const int off = ((r0 + rr + ky) * kWPh + col) * PIX + 16 * chunk;
+          const half8 bhi = *reinterpret_cast<const half8*>(tile_hi + off);
+          const half8 blo = *reinterpret_cast<const half8*>(tile_lo + off);
+          acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[rr], 0, 0, 0);
+          acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc[rr], 0, 0, 0);
+          acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc[rr], 0, 0, 0);
+        }
+      }
+    }
+    // epilogue: lane (x = j, h), reg r -> channel (r&3) + 8(r>>2) + 4h; 128-B row segments
+    const size_t obase = (static_cast<size_t>(net) * a.N + img) * COUT * kImg * kImg;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (ch < COUT) {
+          const size_t o = obase + (static_cast<size_t>(ch) * kImg + (y0 + r0 + rr)) * kImg + j;
+          float v = acc[rr][r];
+          if (SKIP) v += a.skip[o];
+          if (RELU) v = fmaxf(v, 0.f);
+          a.out[o] = v;
+        }
+      }
+  }
+  if (a.range_flag != nullptr && !(amax < 65504.0f)) atomicOr(a.range_flag, 1);
+}
+
+template <int CIN, int COUT, bool RELU, bool SKIP>
+int launch_conv_h(const ConvHArgs& a, int nets, hipStream_t s) {
+  constexpr size_t lds = 2 * (kBand + 2) * kWPh * CIN * 2 + 9 * (CIN / 16) * 2 * 64 * 16;
+  static_assert(lds <= 160 * 1024, "f16 planes + weights must fit LDS");
+  auto k = conv_f16x3_kernel<CIN, COUT, RELU, SKIP>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+  if (e != hipSuccess) return static_cast<int>(e);
+  int gx = 2 * a.N;
+  const int cap = 256 / nets > 0 ? 256 / nets : 1;  // one persistent workgroup per CU
+  if (gx > cap) gx = cap;
+  k<<<dim3(gx, nets), kConvThreads, lds, s>>>(a);
+  MMF_CHECK_LAUNCH();
+  return 0;
+}
+
 // ---- 8192 -> 64 linear, split-K partial sums ----------------------------------------------
 struct FcArgs {
   const float* packed[kMaxNets];
@@ -351,9 +556,11 @@ extern "C" int mmf_pack_image_encoder(const MmfImageEncoderDesc* d, float* packe
 }
 
 extern "C" int mmf_image_encoder(const float* const* packed, int n_nets, const float* images,
-                                 float* feat, void* workspace, int N, void* stream) {
+                                 float* feat, void* workspace, int32_t* range_flag, int precision,
+                                 int N, void* stream) {
   if (!packed || !images || !feat || !workspace) return MMF_EINVAL;
   if (n_nets < 1 || n_nets > kMaxNets || N < 0) return MMF_EINVAL;
+  if (precision != MMF_PREC_F32 && precision != MMF_PREC_F16X3) return MMF_EINVAL;
   if (N == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   constexpr Layout L = layout();
@@ -373,6 +580,19 @@ extern "C" int mmf_image_encoder(const float* const* packed, int n_nets, const f
   // conv 1 -> 32, k5, ReLU                      images -> A
   c.in = images; c.in_net_stride = 0; c.skip = nullptr; c.out = bufA; c.woff = L.w1; c.boff = L.b1;
   if ((rc = launch_conv<1, 32, 5, true, false>(c, n_nets, s))) return rc;
+  if (precision == MMF_PREC_F16X3) {
+    ConvHArgs hcv{};
+    for (int i = 0; i < n_nets; ++i) hcv.packed[i] = packed[i];
+    hcv.N = N; hcv.range_flag = range_flag;
+    hcv.in = bufA; hcv.skip = nullptr; hcv.out = bufB; hcv.hoff = L.h2a; hcv.boff = L.b2a;
+    if ((rc = launch_conv_h<32, 32, true, false>(hcv, n_nets, s))) return rc;
+    hcv.in = bufB; hcv.skip = bufA; hcv.out = bufC; hcv.hoff = L.h2b; hcv.boff = L.b2b;
+    if ((rc = launch_conv_h<32, 32, true, true>(hcv, n_nets, s))) return rc;
+    hcv.in = bufC; hcv.skip = nullptr; hcv.out = bufA; hcv.hoff = L.h3; hcv.boff = L.b3;
+    if ((rc = launch_conv_h<32, 16, true, false>(hcv, n_nets, s))) return rc;
+    hcv.in = bufA; hcv.out = bufB; hcv.hoff = L.h4; hcv.boff = L.b4;
+    if ((rc = launch_conv_h<16, 8, false, false>(hcv, n_nets, s))) return rc;
+  } else {
   // ResConv block1: conv 32 -> 32, ReLU          A -> B
   c.in = bufA; c.in_net_stride = static_cast<long long>(N) * 32 * kImg * kImg; c.out = bufB;
   c.woff = L.w2a; c.boff = L.b2a;
@@ -387,6 +607,7 @@ extern "C" int mmf_image_encoder(const float* const* packed, int n_nets, const f
   c.in = bufA; c.in_net_stride = static_cast<long long>(N) * 16 * kImg * kImg; c.out = bufB;
   c.woff = L.w4; c.boff = L.b4;
   if ((rc = launch_conv<16, 8, 3, false, false>(c, n_nets, s))) return rc;
+  }
   // Linear 8192 -> 64 (split-K partials), then bias + ReLU + ResLinear
   FcArgs f{};
   for (int i = 0; i < n_nets; ++i) f.packed[i] = packed[i];

@@ -333,8 +333,10 @@ def encode_images(encoders, images: torch.Tensor):
             chunk = images[c0:c0 + n]
             feat = torch.empty((len(grp), n, 64), dtype=torch.float32, device=images.device)
             ws = _image_workspace(images.device, n, len(grp))
+            prec = _abi.PRECISIONS[DEFAULT_PRECISION]
+            flag = range_flag(images.device)
             _timed("image_encoder", image_encoder_flops(n) * len(grp), 0.0,
-                   lambda: _abi.image_encoder(packs, chunk, feat, ws))
+                   lambda: _abi.image_encoder(packs, chunk, feat, ws, flag, prec))
             for k in range(len(grp)):
                 feats[k][c0:c0 + n] = feat[k]
         for k, i in enumerate(grp):
