@@ -395,13 +395,20 @@ __global__ __launch_bounds__(kConvThreads) void conv_f16x3_kernel(ConvHArgs a) {
 
     const int img = band >> 1, y0 = (band & 1) * kBand;
     const int r0 = 2 * wave;
+    const size_t obase = (static_cast<size_t>(net) * a.N + img) * COUT * kImg * kImg;
     f32x16 acc[2];
+    f32x16 skipv[SKIP ? 2 : 1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ch = (r & 3) + 8 * (r >> 2) + 4 * h;
       const float b = ch < COUT ? blob[a.boff + ch] : 0.f;
       acc[0][r] = b;
       acc[1][r] = b;
+      if (SKIP) {  // issued now, consumed after the MFMAs: the load latency hides under them
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+          skipv[rr][r] = ch < COUT ? a.skip[obase + (static_cast<size_t>(ch) * kImg + (y0 + r0 + rr)) * kImg + j] : 0.f;
+      }
     }
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -426,7 +433,6 @@ __global__ __launch_bounds__(kConvThreads) void conv_f16x3_kernel(ConvHArgs a) {
       }
     }
     // epilogue: lane (x = j, h), reg r -> channel (r&3) + 8(r>>2) + 4h; 128-B row segments
-    const size_t obase = (static_cast<size_t>(net) * a.N + img) * COUT * kImg * kImg;
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
@@ -435,7 +441,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_f16x3_kernel(ConvHArgs a) {
         if (ch < COUT) {
           const size_t o = obase + (static_cast<size_t>(ch) * kImg + (y0 + r0 + rr)) * kImg + j;
           float v = acc[rr][r];
-          if (SKIP) v += a.skip[o];
+          if (SKIP) v += skipv[rr][r];
           if (RELU) v = fmaxf(v, 0.f);
           a.out[o] = v;
         }
