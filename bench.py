@@ -30,7 +30,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
 F16_MFMA_PEAK_TFLOPS = 2500.0  # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARCH.md)
 MFMA_PEAK = {"f32": FP32_MFMA_PEAK_TFLOPS, "f16x3": F16_MFMA_PEAK_TFLOPS}
-K2_KERNEL = {"f32": "particle_net_kernel<3, 2, 1, 2, 0>", "f16x3": "particle_net_kernel<3, 2, 1, 2, 1>"}
+PREC_CODE = {"f32": 0, "f16x3": 1}
+
+
+def k2_kernel_name(d: int, prec: str) -> str:
+    """<D, NRES, KIND=measure, CT=2 (64-particle tiles), PREC, WPS=2 waves/SIMD>"""
+    return f"particle_net_kernel<{d}, 2, 1, 2, {PREC_CODE[prec]}, 2>"
 
 WORKLOADS = {
     "door_pf": dict(task="door", cls="DoorCrossmodalParticleFilter", kind="pf", batch=256, particles=4096,
@@ -299,9 +304,9 @@ def main():
         dom = ks["particle_net_measure"]
         ach = dom["flops_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e12
         default_shape = (args.workload == "door_pf" and B == 256 and M == 4096)
-        r = {"kernel": K2_KERNEL[prec] + " (measurement network)", "bound": "mfma", "achieved": ach,
+        r = {"kernel": k2_kernel_name(d, prec) + " (measurement network)", "bound": "mfma", "achieved": ach,
              "peak": MFMA_PEAK[prec], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK[prec],
-             "traffic": pmc_traffic("particle_net_kernel<3, 2, 1, 2>") if default_shape else None}
+             "traffic": pmc_traffic(k2_kernel_name(d, "f16x3")) if default_shape else None}
         if prec == "f16x3":
             r["note"] = ("achieved counts ALGORITHMIC fp32 FLOPs; the kernel executes 3 f16 MFMA "
                          "products per algorithmic product (executed-MFMA fraction = 3 x frac)")
