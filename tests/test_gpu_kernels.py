@@ -426,3 +426,53 @@ def test_k2_f16x3_range_flag_reports_saturated_split():
         engine.check_range(dev)  # f32 path never raises it
     finally:
         engine.set_default_precision(old)
+
+
+# ------------------------------------------------------------------------------ K7
+@pytest.mark.parametrize("R", [1, 7, 8, 100, 4096])
+def test_k7_traj_program_matches_torch_modules(R):
+    """A hand-built program (encoders -> concat linear -> wide residual blocks -> heads with
+    sigmoid / sqrt(x^2+eps) / diagonal stores) against the same nn.Modules in torch (CPU)."""
+    from multimodalfilter_amd import _abi, layers
+    from multimodalfilter_amd.trajprog import TrajProgram
+
+    dev = _cuda()
+    torch.manual_seed(R)
+    enc_a, enc_b = layers.vector_encoder(3, 64), layers.vector_encoder(7, 64)
+    fuse = torch.nn.Linear(64 * 3, 128)
+    wide = layers.ResLinear(128)
+    head_z = torch.nn.Sequential(torch.nn.Linear(64, 3), torch.nn.ReLU(), layers.ResLinear(3), torch.nn.Linear(3, 3))
+    head_w = torch.nn.Linear(128, 6)
+    a, b, f = torch.randn(R, 3), torch.randn(R, 7), torch.randn(R, 64)
+    with torch.no_grad():
+        x = torch.relu(fuse(torch.cat([f, enc_a(a), enc_b(b)], 1)))
+        x = wide(x)
+        want_z = head_z(x[:, 64:])
+        want_w = torch.sigmoid(head_w(x))
+        want_d = torch.diag_embed(torch.sqrt(want_z ** 2 + 1e-6))
+
+    p = TrajProgram()
+    sf = p.load("f", 64)
+    ra = p.load("a", 3); ea = p.vector_encoder(enc_a, ra, 3); p.free(ra)
+    rb = p.load("b", 7); eb = p.vector_encoder(enc_b, rb, 7); p.free(rb)
+    x = p.linear([(sf, 0, 64), (ea, 0, 64), (eb, 0, 64)], fuse, _abi.ACT_RELU)
+    p.res_linear(wide, x, 128)
+    z = p.linear([(x, 64, 64)], head_z[0], _abi.ACT_RELU)
+    p.res_linear(head_z[2], z, 3)
+    zo = p.linear([(z, 0, 3)], head_z[3])
+    p.store("z", zo, 3)
+    p.store("d", zo, 3, diag=True, act=_abi.ACT_SQRT_SQ_PLUS, fparam=1e-6)
+    p.store("w", p.linear([(x, 0, 128)], head_w, _abi.ACT_SIGMOID), 6)
+    t = {"f": f.to(dev), "a": a.to(dev), "b": b.to(dev),
+         "z": torch.empty((R, 3), device=dev), "d": torch.empty((R, 3, 3), device=dev),
+         "w": torch.empty((R, 6), device=dev)}
+    p.run(t, R)
+    assert _rel_err(t["z"].cpu(), want_z) < 1e-5
+    assert _rel_err(t["w"].cpu(), want_w) < 1e-5
+    assert _rel_err(t["d"].cpu(), want_d) < 1e-5
+    # parameters updated in place -> the weight blob is rebuilt
+    with torch.no_grad():
+        head_w.weight.mul_(-1.0)
+        want_w = torch.sigmoid(head_w(x_ref := wide(torch.relu(fuse(torch.cat([f, enc_a(a), enc_b(b)], 1))))))
+    p.run(t, R)
+    assert _rel_err(t["w"].cpu(), want_w) < 1e-5
