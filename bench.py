@@ -213,8 +213,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    local_dev = local % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    device = torch.device("cuda", local_dev)
 
     wl = dict(WORKLOADS[args.workload])
     if args.batch:

@@ -21,10 +21,11 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # "nccl" is RCCL on ROCm; MMF_DIST_BACKEND=gloo lets several ranks share one GPU (tests)
+            backend = os.environ.get("MMF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -48,21 +49,24 @@ def all_gather_rows(x: torch.Tensor) -> torch.Tensor:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return x
     world = dist.get_world_size()
-    sizes = [torch.zeros(1, dtype=torch.int64, device=x.device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device))
+    # gloo moves host memory; RCCL moves device memory over xGMI
+    comm_dev = x.device if dist.get_backend() == "nccl" else torch.device("cpu")
+    sizes = [torch.zeros(1, dtype=torch.int64, device=comm_dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([x.shape[0]], dtype=torch.int64, device=comm_dev))
     sizes = [int(s) for s in sizes]
     pad = max(sizes)
-    buf = x.new_zeros((pad,) + tuple(x.shape[1:]))
-    buf[: x.shape[0]] = x
+    buf = torch.zeros((pad,) + tuple(x.shape[1:]), dtype=x.dtype, device=comm_dev)
+    buf[: x.shape[0]] = x.to(comm_dev)
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf)
-    return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
+    return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0).to(x.device)
 
 
 def max_over_ranks(value: float, device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    comm_dev = device if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([value], dtype=torch.float64, device=comm_dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t)
 
