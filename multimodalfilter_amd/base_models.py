@@ -222,12 +222,40 @@ class _FusedKalmanFilters(base.Filter, _EnabledModels):
             return self._forward_encoded(observations, controls, self._encode_step(observations),
                                          self._encode_controls(controls))
 
+    def _encode_loop(self, observations, T, N):
+        """``_encode_step`` for all ``T`` steps at once: virtual sensors (and, when the weight
+        model exposes its row-wise part as ``raw_weights``, the fusion weights) are evaluated on
+        the ``T*N`` flattened rows in one launch sequence; only the per-step, batch-coupled
+        finish of the weights (the reference's reshape quirk, Q3) stays inside the loop."""
+        on = self._enabled_models
+        flat = tree_map(observations, lambda x: x.reshape((T * N,) + tuple(x.shape[2:])))
+        sensors = [f.virtual_sensor_model if on[i] else None for i, f in enumerate(self.filter_models)]
+        wm = getattr(self, "crossmodal_weight_model", None)
+        if wm is not None and np.sum(on) < len(on):
+            wm = None
+        batched_w = wm is not None and hasattr(wm, "raw_weights")
+        feats = encode_observation_images(sensors + [wm if batched_w else None], flat)
+        outs = [None if m is None else call_with_image_feat(m, feats[i], observations=flat)
+                for i, m in enumerate(sensors)]
+        raw = call_with_image_feat(wm.raw_weights, feats[-1], observations=flat) if batched_w else None
+        encs = []
+        for t in range(T):
+            sl = slice(t * N, (t + 1) * N)
+            if wm is None:
+                w = None
+            elif batched_w:
+                w = wm.finish_weights(raw[sl])
+            else:
+                w = wm(observations=tree_index(observations, t))
+            encs.append({"sensor": [None if o is None else (o[0][sl], o[1][sl]) for o in outs], "weights": w})
+        return encs
+
     def forward_loop(self, *, observations, controls):
         """Sensors, fusion weights and control encoders do not depend on the belief: they are
-        evaluated ahead of the recursion (one time step per call, so shapes do not depend on T)."""
+        evaluated ahead of the recursion for all ``T*N`` rows at once."""
         T, N = tree_leading_shape(controls)[:2]
         with torch.no_grad():
-            encs = [self._encode_step(tree_index(observations, t)) for t in range(T)]
+            encs = self._encode_loop(observations, T, N)
             flat = tree_map(controls, lambda x: x.reshape((T * N,) + tuple(x.shape[2:])))
             ctrl_all = self._encode_controls(flat)
             out = []

@@ -420,7 +420,8 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             self.fix_weight_layout = fix_weight_layout
             self._prog = None
 
-        def forward(self, *, observations, image_feat=None):
+        def raw_weights(self, *, observations, image_feat=None):
+            """Row-wise part: encoders + fusion MLP + sigmoid -> ``(R, 2 d)`` (one K7 launch)."""
             N, _ = observations["gripper_pos"].shape
             out_dim = self.modality_count * self.state_dim
             if self._prog is None:
@@ -437,12 +438,20 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             engine.require_device(output, f"{type(self).__name__}.forward")
             t["out"] = output
             self._prog.run(t, N)
+            return output
+
+        def finish_weights(self, output):
+            """Batch-coupled part, per time step: layout (Q3) and normalisation over modality."""
+            N = output.shape[0]
             assert output.shape == (N, self.modality_count * self.state_dim)
             if self.fix_weight_layout:
                 w = output.view(N, self.modality_count, self.state_dim).permute(1, 0, 2)
             else:
                 w = output.reshape(self.modality_count, N, self.state_dim)
             return w / (torch.sum(w, dim=0) + 1e-9)
+
+        def forward(self, *, observations, image_feat=None):
+            return self.finish_weights(self.raw_weights(observations=observations, image_feat=image_feat))
 
     CrossmodalKalmanFilterWeightModel.__name__ = CrossmodalKalmanFilterWeightModel.__qualname__ = \
         f"{P}CrossmodalKalmanFilterWeightModel"
