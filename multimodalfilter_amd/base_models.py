@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _abi, base, filters
-from .engine import call_with_image_feat, encode_observation_images, require_device
+from .engine import call_with_image_feat, encode_observation_images, require_device, use_autograd
 from .utils import tree_index, tree_leading_shape, tree_map
 
 
@@ -115,7 +115,7 @@ class CrossmodalParticleFilterMeasurementModel(base.ParticleFilterMeasurementMod
 
     def forward(self, *, states, observations):
         N, M, _state_dim = states.shape
-        if self._fusable():
+        if self._fusable() and not use_autograd(self):
             with torch.no_grad():
                 return self.forward_encoded(states.contiguous(), self.encode_observations(observations))
         # user-supplied unimodal models: stock formulation (crossmodal_pf.py:106-139)
@@ -216,8 +216,16 @@ class _FusedKalmanFilters(base.Filter, _EnabledModels):
             f._belief_mean, f._belief_covariance = mu[k], Sigma[k]
         return mu_f, Sigma_f, mu, Sigma
 
+    def _autograd_unimodal(self, observations, controls):
+        live = [f for i, f in enumerate(self.filter_models) if self._enabled_models[i]]
+        means = torch.stack([f(observations=observations, controls=controls) for f in live])
+        covs = torch.stack([f._belief_covariance for f in live])
+        return means, covs
+
     def forward(self, *, observations, controls):
         N, _ = controls.shape
+        if use_autograd(self):
+            return self._forward_autograd(observations, controls)
         with torch.no_grad():
             return self._forward_encoded(observations, controls, self._encode_step(observations),
                                          self._encode_controls(controls))
@@ -254,6 +262,8 @@ class _FusedKalmanFilters(base.Filter, _EnabledModels):
         """Sensors, fusion weights and control encoders do not depend on the belief: they are
         evaluated ahead of the recursion for all ``T*N`` rows at once."""
         T, N = tree_leading_shape(controls)[:2]
+        if use_autograd(self):
+            return base.Filter.forward_loop(self, observations=observations, controls=controls)
         with torch.no_grad():
             encs = self._encode_loop(observations, T, N)
             flat = tree_map(controls, lambda x: x.reshape((T * N,) + tuple(x.shape[2:])))
@@ -308,6 +318,22 @@ class CrossmodalKalmanFilter(_FusedKalmanFilters):
             f.states_covariance_prev = Sigma_f
         return mu_f
 
+    def _forward_autograd(self, observations, controls):
+        """Differentiable torch formulation (training backend "autograd"), as the reference."""
+        N = controls.shape[0]
+        means, covs = self._autograd_unimodal(observations, controls)
+        raw = None
+        if np.sum(self._enabled_models) == len(self._enabled_models):
+            raw = self.crossmodal_weight_model(observations=observations)
+        w = self._state_weights(raw, N, means.device)
+        mu, Sigma = self.calculate_weighted_states(w, means, covs)
+        self.weighted_covariances = Sigma
+        for f in self.filter_models:
+            f.states_prev, f.states_covariance_prev = mu, Sigma
+            if self.feedback == "belief":
+                f._belief_mean, f._belief_covariance = mu, Sigma
+        return mu
+
     # kept for API parity with the reference (``crossmodal_kf.py:153-186``)
     def calculate_weighted_states(self, state_weights, unimodal_states, unimodal_covariances):
         model_dim, N, state_dim = state_weights.shape
@@ -346,6 +372,14 @@ class UnimodalKalmanFilter(_FusedKalmanFilters):
 
     def __init__(self, *, filter_models, state_dim: int):
         super().__init__(filter_models=filter_models, state_dim=state_dim)
+
+    def _forward_autograd(self, observations, controls):
+        means, covs = self._autograd_unimodal(observations, controls)
+        if means.shape[0] == 1:
+            return means[0]
+        prec = torch.inverse(covs + 1e-9)
+        Sigma = torch.inverse(torch.sum(prec, dim=0) + 1e-9)
+        return (Sigma @ torch.sum(prec @ means[..., None], dim=0)).squeeze(-1)
 
     def _forward_encoded(self, observations, controls, enc, ctrl):
         if np.sum(self._enabled_models) == 1:

@@ -74,3 +74,30 @@ def max_over_ranks(value: float, device) -> float:
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def all_reduce_gradients(module: torch.nn.Module, average: bool = True) -> int:
+    """Data-parallel gradient exchange (X2): one flat all-reduce of every parameter gradient
+    (<= 1.43 M fp32 = 5.7 MB for the largest filter; a ring over xGMI is per-link bound,
+    2(P-1)/P * S / 153 GB/s ~ 65 us at P = 8 -- nothing to overlap at this size).
+    Returns the number of elements reduced."""
+    params = [p for p in module.parameters() if p.requires_grad]
+    if not params:
+        return 0
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return sum(p.numel() for p in params)
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    comm = flat if dist.get_backend() == "nccl" else flat.cpu()
+    dist.all_reduce(comm, op=dist.ReduceOp.SUM)
+    if average:
+        comm = comm / dist.get_world_size()
+    comm = comm.to(flat.device)
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.grad.copy_(comm[off:off + n].view_as(p))
+        off += n
+    return off

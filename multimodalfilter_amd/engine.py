@@ -96,6 +96,24 @@ def set_default_precision(name: str):
     DEFAULT_PRECISION = name
 
 
+# Training: the HIP kernels are forward-only (K6, the backward kernels, are not built).  With
+# the training backend set to "autograd", modules in train() mode evaluate through ordinary
+# differentiable torch ops on the device instead, so the reference's curricula (30 particles,
+# batch 32, subsequences of 2-16 steps: launch-bound sizes) can run unchanged.  It is opt-in:
+# nothing switches paths silently, and eval() always means the HIP path.
+TRAINING_BACKEND = os.environ.get("MMF_TRAINING_BACKEND") or None
+
+
+def set_training_backend(name):
+    global TRAINING_BACKEND
+    assert name in (None, "autograd"), name
+    TRAINING_BACKEND = name
+
+
+def use_autograd(module: nn.Module) -> bool:
+    return TRAINING_BACKEND == "autograd" and module.training and torch.is_grad_enabled()
+
+
 _RANGE_FLAGS = {}
 
 

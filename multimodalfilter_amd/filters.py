@@ -16,7 +16,7 @@ from typing import Optional
 import torch
 
 from . import _abi, base
-from .engine import _timed, check_range, require_device, reserve_memory
+from .engine import _timed, check_range, require_device, reserve_memory, use_autograd
 from .utils import NoiseSource, tree_index, tree_leading_shape, tree_map
 
 _MODES = {"none": 0, "systematic": 1, "multinomial": 2}
@@ -155,7 +155,41 @@ class ParticleFilter(base.Filter):
             self.particle_log_weights = logw_out
         return estimate
 
+    def _step_autograd(self, observations, controls) -> torch.Tensor:
+        """Differentiable torch formulation of the step (training backend "autograd"): gradients
+        flow through the reparameterised noise and the log-weights; resampling, when requested,
+        runs through K1 on detached tensors (it stops gradients upstream as well)."""
+        assert self._initialized, "Particle filter not initialized!"
+        N, M, d = self.particle_states.shape
+        do_resample = (not self.training) if self.resample is None else bool(self.resample)
+        flat = self.particle_states.reshape(N * M, d)
+        rep = tree_map(controls, lambda t: torch.repeat_interleave(t, repeats=M, dim=0))
+        pred, tril = self.dynamics_model(initial_states=flat, controls=rep)
+        eps = self.noise.gaussian((N, M, d), like=pred).reshape(N * M, d)
+        states = (pred + torch.einsum("rij,rj->ri", tril, eps)).reshape(N, M, d)
+        logw = self.particle_log_weights + self.measurement_model(states=states, observations=observations)
+        logw = logw - torch.logsumexp(logw, dim=1, keepdim=True)
+        if self.estimation_method == "weighted_average":
+            estimate = torch.sum(torch.exp(logw)[:, :, None] * states, dim=1)
+        else:
+            estimate = states[torch.arange(N, device=states.device), torch.argmax(logw, dim=1)]
+        self.particle_states, self.particle_log_weights = states, logw
+        if do_resample:
+            Mo = self.num_particles
+            mode = _MODES[self.resample_mode]
+            u = self.noise.uniform((N,) if mode == 1 else (N, Mo), like=states)
+            out = torch.empty((N, Mo, d), dtype=torch.float32, device=states.device)
+            logw_out = torch.empty((N, Mo), dtype=torch.float32, device=states.device)
+            scratch = torch.empty((N, d), dtype=torch.float32, device=states.device)
+            with torch.no_grad():
+                _abi.pf_reweight_resample(torch.zeros_like(logw), logw.detach().contiguous(),
+                                          states.detach().contiguous(), u, scratch, out, logw_out, None, mode)
+            self.particle_states, self.particle_log_weights = out, logw_out
+        return estimate
+
     def forward(self, *, observations, controls) -> torch.Tensor:
+        if use_autograd(self):
+            return self._step_autograd(observations, controls)
         return self._step(observations, controls)
 
     def forward_loop(self, *, observations, controls) -> torch.Tensor:
@@ -165,6 +199,8 @@ class ParticleFilter(base.Filter):
         work costs one launch sequence per ``forward_loop`` instead of one per step."""
         T, N = tree_leading_shape(controls)[:2]
         assert tree_leading_shape(observations)[:2] == (T, N)
+        if use_autograd(self):
+            return base.Filter.forward_loop(self, observations=observations, controls=controls)
         flat = lambda x: x.reshape((T * N,) + tuple(x.shape[2:]))
         obs_all = ctrl_all = None
         with torch.no_grad():
@@ -253,10 +289,27 @@ class VirtualSensorExtendedKalmanFilter(base.Filter):
             self._belief_mean, self._belief_covariance = mu[0], Sigma[0]
         return self._belief_mean
 
+    def _step_autograd(self, observations, controls):
+        """Differentiable torch formulation (training backend "autograd")."""
+        assert self._initialized, "Kalman filter not initialized!"
+        mu, Sigma = self._belief_mean, self._belief_covariance
+        z, r_tril = self.virtual_sensor_model(observations=observations)
+        mu_pred, L = self.dynamics_model(initial_states=mu, controls=controls)
+        A = self.dynamics_model.jacobian(initial_states=mu, controls=controls)
+        Sp = A @ Sigma @ A.transpose(-1, -2) + L @ L.transpose(-1, -2)
+        K = Sp @ torch.inverse(Sp + r_tril @ r_tril.transpose(-1, -2))
+        self._belief_mean = mu_pred + (K @ (z - mu_pred)[:, :, None]).squeeze(-1)
+        self._belief_covariance = (torch.eye(K.shape[-1], device=K.device) - K) @ Sp
+        return self._belief_mean
+
     def forward(self, *, observations, controls):
+        if use_autograd(self):
+            return self._step_autograd(observations, controls)
         return self._step(observations, controls)
 
     def forward_loop(self, *, observations, controls):
+        if use_autograd(self):
+            return base.Filter.forward_loop(self, observations=observations, controls=controls)
         T, N = tree_leading_shape(controls)[:2]
         flat = lambda t: t.reshape((T * N,) + tuple(t.shape[2:]))
         with torch.no_grad():

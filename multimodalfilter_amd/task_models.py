@@ -98,6 +98,17 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
                 prog.free(raw)
             return srcs
 
+        def observation_features_autograd(self, observations) -> torch.Tensor:
+            """Differentiable torch evaluation of the encoders (training backend "autograd")."""
+            obs = []
+            if "image" in self.modalities:
+                obs.append(self.observation_image_layers(observations["image"][:, None, :, :]))
+            if "pos" in self.modalities:
+                obs.append(self.observation_pos_layers(observations["gripper_pos"]))
+            if "sensors" in self.modalities:
+                obs.append(self.observation_sensors_layers(observations["gripper_sensors"]))
+            return torch.cat(obs, dim=1)
+
         def _program_inputs(self, observations, image_feat=None):
             """Device tensors for the LOADs emitted by ``_emit_observation_sources``."""
             assert type(observations) == dict
@@ -171,12 +182,19 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
         def forward(self, *, initial_states, controls):
             N, state_dim = initial_states.shape[:2]
             assert state_dim == self.state_dim
+            if engine.use_autograd(self):
+                merged = torch.cat((self.control_layers(controls), self.state_layers(initial_states)), dim=-1)
+                out = self.shared_layers(merged)
+                new = initial_states + out[..., :state_dim] * torch.sigmoid(out[..., -1:])
+                return new, self.scale_tril()[None, :, :].expand(N, state_dim, state_dim)
             with torch.no_grad():
                 new = engine.run_dynamics(self._net, initial_states, self.encode_controls(controls)["bias"],
                                           None, None)
             return new, self.scale_tril()[None, :, :].expand(N, state_dim, state_dim)
 
         def jacobian(self, *, initial_states, controls):
+            if engine.use_autograd(self):
+                return base.DynamicsModel.jacobian(self, initial_states=initial_states, controls=controls)
             with torch.no_grad():
                 return engine.run_jacobian(self._net, initial_states, self.encode_controls(controls)["bias"])[1]
 
@@ -238,6 +256,12 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             assert type(observations) == dict
             assert len(states.shape) == 3  # (N, M, state_dim)
             assert states.shape[2] == self.state_dim
+            if engine.use_autograd(self):
+                N, M, _ = states.shape
+                obs = self.observation_features_autograd(observations)
+                obs = obs[:, None, :].expand(N, M, obs.shape[1])
+                merged = torch.cat((obs, self.state_layers(states)), dim=2)
+                return torch.squeeze(self.shared_layers(merged), dim=2)
             with torch.no_grad():
                 return self.forward_encoded(states.contiguous(), self.encode_observations(observations))
 
@@ -262,6 +286,12 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
 
         def forward(self, *, observations, image_feat=None):
             N, _ = observations["gripper_pos"].shape
+            if engine.use_autograd(self):
+                output = self.fusion_layers(self.observation_features_autograd(observations))
+                if self.know_image_blackout:
+                    output = output.clone()
+                    output[blackout_rows(observations["image"]), 0] -= np.inf
+                return output
             if self._prog is None:
                 p = TrajProgram()
                 srcs = self._emit_observation_sources(p)
@@ -356,6 +386,14 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
         def forward(self, *, observations, image_feat=None):
             assert type(observations) == dict
             N, _ = observations["gripper_pos"].shape
+            if engine.use_autograd(self):
+                shared = self.shared_layers(self.observation_features_autograd(observations))
+                z = self.z_layer(shared[:, : self.units])
+                lt_hat = self.r_layer(shared[:, self.units:]) if self.noise_R_tril is None else self.noise_R_tril
+                cov = torch.diag_embed(lt_hat) ** 2
+                if self.add_R_noise[0] > 0:
+                    cov = cov + torch.diag(self.add_R_noise).to(cov.device)
+                return z, torch.sqrt(cov)
             if self.noise_R_tril is not None:
                 raise NotImplementedError("a fixed noise_R_tril is not supported by the HIP virtual sensor")
             d, U = self.state_dim, self.units
@@ -424,6 +462,8 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             """Row-wise part: encoders + fusion MLP + sigmoid -> ``(R, 2 d)`` (one K7 launch)."""
             N, _ = observations["gripper_pos"].shape
             out_dim = self.modality_count * self.state_dim
+            if engine.use_autograd(self):
+                return self.fusion_layers(self.observation_features_autograd(observations))
             if self._prog is None:
                 p = TrajProgram()
                 srcs = self._emit_observation_sources(p)
@@ -482,6 +522,25 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
                 state_dim=D, feedback=feedback)
             self.know_image_blackout = know_image_blackout
 
+        def _blackout_weights(self, raw, dark, N):
+            keep = (~dark).to(torch.float32)[:, None]
+            drk = dark.to(torch.float32)[:, None]
+            w = torch.stack([drk * 1e-9 + keep * raw[0], drk * (1.0 - 1e-9) + keep * raw[1]])
+            assert w.shape == (np.sum(self._enabled_models), N, self.state_dim)
+            return w
+
+        def _forward_autograd(self, observations, controls):
+            on = self._enabled_models
+            dark = blackout_rows(observations["image"]) if self.know_image_blackout else None
+            if dark is None or torch.sum(dark) == 0 or np.sum(on) < len(on):
+                return super()._forward_autograd(observations, controls)
+            N = controls.shape[0]
+            means, covs = self._autograd_unimodal(observations, controls)
+            w = self._blackout_weights(self.crossmodal_weight_model(observations=observations), dark, N)
+            mu, Sigma = self.calculate_weighted_states(w, means, covs)
+            self.weighted_covariances = Sigma
+            return mu
+
         def _forward_encoded(self, observations, controls, enc, ctrl):
             if not self.know_image_blackout:
                 return super()._forward_encoded(observations, controls, enc, ctrl)
@@ -490,13 +549,7 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             on = self._enabled_models
             if torch.sum(dark) == 0 or np.sum(on) < len(on):
                 return super()._forward_encoded(observations, controls, enc, ctrl)
-            raw = enc["weights"]
-            keep = (~dark).to(torch.float32)[:, None]
-            drk = dark.to(torch.float32)[:, None]
-            image_weight = drk * 1e-9 + keep * raw[0]
-            force_weight = drk * (1.0 - 1e-9) + keep * raw[1]
-            w = torch.stack([image_weight, force_weight])
-            assert w.shape == (np.sum(on), N, self.state_dim)
+            w = self._blackout_weights(enc["weights"], dark, N)
             mu_f, Sigma_f, _, _ = self._fused_step(controls, enc, ctrl, fusion=1, fuse_w=w, feedback=0)
             self.weighted_covariances = Sigma_f
             return mu_f

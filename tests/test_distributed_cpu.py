@@ -112,3 +112,30 @@ def test_synthetic_generator_is_seeded_and_shaped():
     assert float(a["image"].abs().max()) <= 1.0
     dark = (a["image"].abs().sum((-1, -2)) == 0)
     assert 0 < int(dark.sum()) < dark.numel()
+
+
+def _grad_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    distributed.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 2))
+    x = torch.full((3, 5), float(rank + 1))
+    net(x).pow(2).sum().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    n = distributed.all_reduce_gradients(net)
+    assert n == sum(p.numel() for p in net.parameters())
+    torch.save({"local": local, "reduced": [p.grad.clone() for p in net.parameters()]},
+               os.path.join(out_dir, f"g{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gradient_all_reduce_averages_over_ranks(tmp_path):
+    """X2: flat all-reduce of the parameter gradients (data-parallel training step)."""
+    port = _free_port()
+    mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = torch.load(tmp_path / "g0.pt"), torch.load(tmp_path / "g1.pt")
+    for a, b, r0, r1 in zip(g0["local"], g1["local"], g0["reduced"], g1["reduced"]):
+        torch.testing.assert_close(r0, (a + b) / 2)
+        torch.testing.assert_close(r1, r0)
