@@ -88,7 +88,10 @@ def run_pf(f, traj_dev, noise_dev, M, mode="systematic"):
     eps0, eps, us = noise_dev
     f.num_particles = M
     f.resample_mode = mode
-    f.noise = mmf.ReplayNoise([eps0] + list(eps), list(us))
+    # contiguous (T, ...) blocks: the native step loop reads them in place
+    eps = eps if torch.is_tensor(eps) else torch.stack(list(eps))
+    us = us if torch.is_tensor(us) else torch.stack(list(us))
+    f.noise = mmf.StackedNoise(eps0, eps, us)
     return evaluation.run_filter(f, traj_dev)
 
 
@@ -239,7 +242,7 @@ def main():
             f, {k: traj[k][0] for k in ("image", "gripper_pos", "gripper_sensors")}, cal_states)
         noise_w = synthetic.draw_filter_noise(T=W, N=B, M=M, state_dim=d, seed=77 + rank)
         noise = synthetic.draw_filter_noise(T=K, N=B, M=M, state_dim=d, seed=78 + rank)
-        mv = lambda nz: (nz[0].to(device), [e.to(device) for e in nz[1]], [u.to(device) for u in nz[2]])
+        mv = lambda nz: (nz[0].to(device), torch.stack(nz[1]).to(device), torch.stack(nz[2]).to(device))
         noise_w, noise = mv(noise_w), mv(noise)
         f.reserve(steps=K, batch=B, particles=M)  # memory planned before the warm-up
         run = lambda tr, nz: run_pf(f, tr, nz, M)

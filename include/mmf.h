@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 4
+#define MMF_ABI_VERSION 5
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -188,6 +188,45 @@ int mmf_pack_image_encoder(const MmfImageEncoderDesc* desc /* host */, float* pa
  */
 int mmf_image_encoder(const float* const* packed, int n_nets, const float* images, float* feat,
                       void* workspace, int32_t* range_flag, int precision, int N, void* stream);
+
+/* ---------------------------------------------------------------- particle-filter step loop
+ * Replaces the Python loop of torchfilter's Filter.forward_loop (call site
+ * crossmodal/eval_helpers.py:139-142) for the fused models: one call enqueues the kernels of
+ * all T steps (mmf_pf_dynamics, mmf_pf_measure per modality, mmf_pf_reweight_resample) on
+ * `stream`.  Per-trajectory terms and randomness are indexed by step: row block t of every
+ * (T*N, ...) array belongs to step t.
+ */
+#define MMF_LOOP_MAX_MEAS 4
+typedef struct MmfPfLoopArgs {
+  int32_t T, N, M, d;
+  int32_t n_meas;            /* measurement networks (modalities), 1..MMF_LOOP_MAX_MEAS       */
+  int32_t resample_mode;     /* 0 none, 1 systematic, 2 multinomial                           */
+  int32_t precision;         /* MMF_PREC_*                                                    */
+  int32_t n_res_dyn, n_res_meas;
+  int32_t logw_stride;       /* row stride of the modality log-weight arrays                  */
+  const float* dyn_packed;   /* packed dynamics network                                       */
+  const float* dyn_bias;     /* (T*N, 64)                                                     */
+  const float* meas_packed[MMF_LOOP_MAX_MEAS];
+  const float* meas_bias[MMF_LOOP_MAX_MEAS];   /* (T*N, 64) each                              */
+  const float* meas_logw[MMF_LOOP_MAX_MEAS];   /* first element of modality k's log-weight    */
+                                               /* column in a (T*N, logw_stride) array, or null */
+  const float* noise;        /* (T, N, M, d) standard normal                                  */
+  const float* scale_tril;   /* (d, d)                                                        */
+  const float* uniforms;     /* (T, N) systematic / (T, N, M) multinomial / null              */
+  float* states_a;           /* (N, M, d) belief on entry                                     */
+  float* states_b;           /* (N, M, d) scratch                                             */
+  float* logw_a;             /* (N, M) log-weights on entry                                   */
+  float* logw_b;             /* (N, M) scratch                                                */
+  float* loglik;             /* (N, M) scratch                                                */
+  float* estimates;          /* (T, N, d) out                                                 */
+  int32_t* range_flag;       /* device int32 or null (see mmf_pf_dynamics)                    */
+  int32_t* final_location;   /* HOST int32 out or null: bit 0 belief states in states_b,      */
+                             /* bit 1 log-weights in logw_b                                   */
+  void* const* events;       /* HOST array of 2*(2+n_meas)*T hipEvent_t or null: recorded     */
+                             /* around every launch, [step][dynamics, measure.., resample][start,end] */
+} MmfPfLoopArgs;             /* host struct holding device pointers                           */
+
+int mmf_pf_forward_loop(const MmfPfLoopArgs* args /* host */, void* stream);
 
 /* ---------------------------------------------------------------- K7: per-trajectory MLP programs
  * The N-row networks around the filters (vector encoders layers.py:11-40,66-95; PF weight

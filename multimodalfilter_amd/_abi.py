@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmmf_hip.so")
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 PREC_F32, PREC_F16X3 = 0, 1
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}
 
@@ -48,6 +48,22 @@ class MmfTrajInstr(Structure):
                 ("fparam", c_float)]
 
 
+LOOP_MAX_MEAS = 4
+
+
+class MmfPfLoopArgs(Structure):
+    _fields_ = [("T", c_int32), ("N", c_int32), ("M", c_int32), ("d", c_int32), ("n_meas", c_int32),
+                ("resample_mode", c_int32), ("precision", c_int32), ("n_res_dyn", c_int32),
+                ("n_res_meas", c_int32), ("logw_stride", c_int32),
+                ("dyn_packed", _FP), ("dyn_bias", _FP),
+                ("meas_packed", _FP * LOOP_MAX_MEAS), ("meas_bias", _FP * LOOP_MAX_MEAS),
+                ("meas_logw", _FP * LOOP_MAX_MEAS),
+                ("noise", _FP), ("scale_tril", _FP), ("uniforms", _FP),
+                ("states_a", _FP), ("states_b", _FP), ("logw_a", _FP), ("logw_b", _FP),
+                ("loglik", _FP), ("estimates", _FP), ("range_flag", _FP),
+                ("final_location", POINTER(c_int32)), ("events", POINTER(c_void_p))]
+
+
 class MmfImageEncoderDesc(Structure):
     _fields_ = [("conv_w", _FP * 5), ("conv_b", _FP * 5), ("fc_w", _FP), ("fc_b", _FP),
                 ("res_w", _FP * 2), ("res_b", _FP * 2)]
@@ -64,6 +80,7 @@ SIGNATURES = {
     "mmf_pf_measure": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, c_int, _FP, c_int, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_dynamics_jacobian": (c_int, [_FP, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_ekf_step": (c_int, [_FP] * 10 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmf_pf_forward_loop": (c_int, [POINTER(MmfPfLoopArgs), c_void_p]),
     "mmf_traj_program": (c_int, [_FP, c_int, _FP, POINTER(c_void_p), c_int, c_void_p]),
     "mmf_image_encoder_floats": (c_size_t, []),
     "mmf_image_encoder_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -220,3 +237,16 @@ def traj_program(prog: torch.Tensor, n_instr: int, weights: torch.Tensor, io_ten
     with _on(weights):
         _check(load().mmf_traj_program(ptr(prog, dtype=torch.uint8), n_instr, ptr(weights), arr, R,
                                        stream_of(weights)), "mmf_traj_program")
+
+
+def pf_forward_loop(args: MmfPfLoopArgs, like: torch.Tensor, events=None) -> int:
+    """Enqueue T filter steps; returns the final-location bits (see include/mmf.h).
+    ``events``: optional flat list of created ``torch.cuda.Event`` (timing) recorded in C."""
+    loc = c_int32(0)
+    args.final_location = ctypes.pointer(loc)
+    if events is not None:
+        arr = (c_void_p * len(events))(*[e.cuda_event for e in events])
+        args.events = arr
+    with _on(like):
+        _check(load().mmf_pf_forward_loop(ctypes.byref(args), stream_of(like)), "mmf_pf_forward_loop")
+    return int(loc.value)

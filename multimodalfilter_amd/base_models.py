@@ -96,6 +96,21 @@ class CrossmodalParticleFilterMeasurementModel(base.ParticleFilterMeasurementMod
             ).to(torch.float32).contiguous()
         return ctx
 
+    def fused_measurements(self, ctx):
+        """Enabled unimodal networks with their hoisted biases and modality log-weight columns,
+        for the native step loop; ``None`` when a unimodal model is not a fused network."""
+        if not self._fusable() or not all(hasattr(m, "fused_measurements") for m in self.measurement_models):
+            return None
+        beta = ctx.get("modality_log_weights")
+        K = self._num_models()
+        out = []
+        for i, m in enumerate(self.measurement_models):
+            if self._enabled_models[i]:
+                sub = {k[len(f"m{i}."):]: v for k, v in ctx.items() if k.startswith(f"m{i}.")}
+                net, bias, _ = m.fused_measurements(sub)[0][0]
+                out.append((net, bias, None if beta is None else beta.view(-1)[i:]))
+        return out, K
+
     def forward_encoded(self, states: torch.Tensor, ctx) -> torch.Tensor:
         N, M, _ = states.shape
         loglik = torch.empty((N, M), dtype=torch.float32, device=states.device)

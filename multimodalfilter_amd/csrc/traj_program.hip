@@ -30,7 +30,7 @@ __device__ __forceinline__ float activate(float v, int act, float fparam) {
   switch (act) {
     case MMF_TRAJ_ACT_RELU: return fmaxf(v, 0.f);
     case MMF_TRAJ_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
-    case MMF_TRAJ_ACT_SQRT_SQ_PLUS: return sqrtf(v * v + fparam);
+    case MMF_TRAJ_ACT_SQRT_SQ_PLUS: return sqrtf(__fmaf_rn(v, v, fparam));
     default: return v;
   }
 }
@@ -81,9 +81,13 @@ __global__ __launch_bounds__(kWaves * MMF_WAVE) void traj_program_kernel(
 #pragma unroll
             for (int r = 0; r < kRows; ++r) {
               const float4 x = *reinterpret_cast<const float4*>(xs + r * kVec + k);
-              acc0[r] += w0[0] * x.x; acc0[r] += w0[1] * x.y; acc0[r] += w0[2] * x.z; acc0[r] += w0[3] * x.w;
+              // explicit fma: every row must round identically whatever its position in the
+              // batch (left to the contraction pass, rows 6-7 of a wave came out differently)
+              acc0[r] = __fmaf_rn(w0[0], x.x, acc0[r]); acc0[r] = __fmaf_rn(w0[1], x.y, acc0[r]);
+              acc0[r] = __fmaf_rn(w0[2], x.z, acc0[r]); acc0[r] = __fmaf_rn(w0[3], x.w, acc0[r]);
               if (wide) {
-                acc1[r] += w1[0] * x.x; acc1[r] += w1[1] * x.y; acc1[r] += w1[2] * x.z; acc1[r] += w1[3] * x.w;
+                acc1[r] = __fmaf_rn(w1[0], x.x, acc1[r]); acc1[r] = __fmaf_rn(w1[1], x.y, acc1[r]);
+                acc1[r] = __fmaf_rn(w1[2], x.z, acc1[r]); acc1[r] = __fmaf_rn(w1[3], x.w, acc1[r]);
               }
             }
           }
@@ -93,8 +97,8 @@ __global__ __launch_bounds__(kWaves * MMF_WAVE) void traj_program_kernel(
 #pragma unroll
             for (int r = 0; r < kRows; ++r) {
               const float x = xs[r * kVec + k];
-              acc0[r] += w0 * x;
-              if (wide) acc1[r] += w1 * x;
+              acc0[r] = __fmaf_rn(w0, x, acc0[r]);
+              if (wide) acc1[r] = __fmaf_rn(w1, x, acc1[r]);
             }
           }
           wT += dim * out_pad;
@@ -105,8 +109,8 @@ __global__ __launch_bounds__(kWaves * MMF_WAVE) void traj_program_kernel(
         float v0[kRows], v1[kRows];
 #pragma unroll
         for (int r = 0; r < kRows; ++r) {
-          v0[r] = activate(acc0[r] + (res ? res[r * kVec + lane] : 0.f), I.act, I.fparam);
-          v1[r] = wide ? activate(acc1[r] + (res ? res[r * kVec + 64 + lane] : 0.f), I.act, I.fparam) : 0.f;
+          v0[r] = activate(__fadd_rn(acc0[r], res ? res[r * kVec + lane] : 0.f), I.act, I.fparam);
+          v1[r] = wide ? activate(__fadd_rn(acc1[r], res ? res[r * kVec + 64 + lane] : 0.f), I.act, I.fparam) : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < kRows; ++r) {

@@ -42,6 +42,19 @@ class KernelTimer:
         end.record()
         self.records.setdefault(name, []).append((start, end, flops, nbytes))
 
+    def loop_events(self, count: int):
+        """``count`` created events for a native step loop to record (see ``pf_loop.hip``)."""
+        return [self._event() for _ in range(count)]
+
+    def add_loop_records(self, names, work, events):
+        """Register the (start, end) pairs a native loop recorded: ``names`` / ``work`` describe
+        one step's launches in order; ``events`` is the flat list handed to the loop."""
+        per_step = 2 * len(names)
+        for t in range(len(events) // per_step):
+            for j, (name, (flops, nbytes)) in enumerate(zip(names, work)):
+                s, e = events[t * per_step + 2 * j], events[t * per_step + 2 * j + 1]
+                self.records.setdefault(name, []).append((s, e, flops, nbytes))
+
     def summary(self):
         out = {}
         for name, recs in self.records.items():
@@ -58,6 +71,10 @@ _TIMER = None
 def set_kernel_timer(timer):
     global _TIMER
     _TIMER = timer
+
+
+def kernel_timer():
+    return _TIMER
 
 
 def _timed(name, flops, nbytes, fn):

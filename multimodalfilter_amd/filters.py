@@ -15,7 +15,9 @@ from typing import Optional
 
 import torch
 
-from . import _abi, base
+import ctypes
+
+from . import _abi, base, engine
 from .engine import _timed, check_range, require_device, reserve_memory, use_autograd
 from .utils import NoiseSource, tree_index, tree_leading_shape, tree_map
 
@@ -144,6 +146,8 @@ class ParticleFilter(base.Filter):
                 self.last_resample_indices = idx
             else:
                 out, logw_out = states, torch.empty_like(loglik)
+                if states.data_ptr() != self.particle_states.data_ptr():
+                    self._spare_states = self.particle_states  # the old belief is the next scratch
                 _abi.pf_reweight_resample(loglik, self.particle_log_weights, states, None, estimate,
                                           None, logw_out, None, 0)
             if self.estimation_method == "argmax":
@@ -187,6 +191,67 @@ class ParticleFilter(base.Filter):
             self.particle_states, self.particle_log_weights = out, logw_out
         return estimate
 
+    def _native_loop(self, obs_all, ctrl_all, T, N):
+        """All ``T`` steps through ``mmf_pf_forward_loop`` (one C call, no per-step Python) when
+        both models are fused networks; ``None`` -> the caller runs the step-by-step loop."""
+        dyn, meas = self.dynamics_model, self.measurement_model
+        if obs_all is None or ctrl_all is None or not hasattr(dyn, "_net") or not hasattr(meas, "fused_measurements"):
+            return None
+        plan = meas.fused_measurements(obs_all)
+        if plan is None or self.estimation_method != "weighted_average" or self.record_indices or T == 0:
+            return None
+        nets, stride = plan
+        Nb, M, d = self.particle_states.shape
+        do_resample = (not self.training) if self.resample is None else bool(self.resample)
+        if Nb != N or self.num_particles != M or len(nets) > _abi.LOOP_MAX_MEAS:
+            return None
+        assert self._initialized, "Particle filter not initialized!"
+        mode = _MODES[self.resample_mode] if do_resample else 0
+        like = self.particle_states
+        u_shape = None if mode == 0 else ((N,) if mode == 1 else (N, M))
+        eps, u = self.noise.draw_steps(T, (N, M, d), u_shape, like=like)
+        dev = like.device
+        states_a = like.contiguous()
+        states_b = self._spare_states if (self._spare_states is not None and self._spare_states.shape == states_a.shape
+                                          and self._spare_states.data_ptr() != states_a.data_ptr()) else torch.empty_like(states_a)
+        logw_a = self.particle_log_weights.contiguous()
+        logw_b = torch.empty_like(logw_a)
+        loglik = torch.empty_like(logw_a)
+        est = torch.empty((T, N, d), dtype=torch.float32, device=dev)
+        tril = dyn.scale_tril().contiguous()
+        keep = [nets, eps, u, tril]  # keep every operand alive until the launches are enqueued
+        P = lambda t: None if t is None else ctypes.c_void_p(_abi.ptr(t))
+        a = _abi.MmfPfLoopArgs()
+        a.T, a.N, a.M, a.d, a.n_meas, a.resample_mode = T, N, M, d, len(nets), mode
+        a.precision = dyn._net.precision_code()
+        a.n_res_dyn, a.n_res_meas, a.logw_stride = dyn._net.n_res, nets[0][0].n_res, stride
+        a.dyn_packed, a.dyn_bias = P(dyn._net.blob()), P(ctrl_all["bias"])
+        for k, (net, bias, lw) in enumerate(nets):
+            a.meas_packed[k], a.meas_bias[k], a.meas_logw[k] = P(net.blob()), P(bias), P(lw)
+        a.noise, a.scale_tril, a.uniforms = P(eps), P(tril), P(u)
+        a.states_a, a.states_b, a.logw_a, a.logw_b = P(states_a), P(states_b), P(logw_a), P(logw_b)
+        a.loglik, a.estimates = P(loglik), P(est)
+        a.range_flag = ctypes.c_void_p(engine.range_flag(dev).data_ptr())
+        timer = engine.kernel_timer()
+        events = None
+        names = ["particle_net_dynamics"] + ["particle_net_measure"] * len(nets) + ["pf_reweight_resample"]
+        if timer is not None:
+            events = timer.loop_events(2 * len(names) * T)
+        loc = _abi.pf_forward_loop(a, like, events)
+        if timer is not None:
+            R = N * M
+            dflops = 2.0 * R * engine.particle_net_macs(d, dyn._net.n_res, dyn._net.n_out)
+            work = [(dflops, R * 4.0 * 3 * d)]
+            for k, (net, _, _) in enumerate(nets):
+                work.append((2.0 * R * engine.particle_net_macs(d, net.n_res, net.n_out), R * 4.0 * (d + 1 + (k > 0))))
+            work.append((0.0, R * 4.0 * (2 + 2 * d)))
+            timer.add_loop_records(names, work, events)
+        self.particle_states = states_b if loc & 1 else states_a
+        self._spare_states = states_a if loc & 1 else states_b
+        self.particle_log_weights = logw_b if loc & 2 else logw_a
+        del keep
+        return est
+
     def forward(self, *, observations, controls) -> torch.Tensor:
         if use_autograd(self):
             return self._step_autograd(observations, controls)
@@ -208,6 +273,10 @@ class ParticleFilter(base.Filter):
                 obs_all = self.measurement_model.encode_observations(tree_map(observations, flat))
             if hasattr(self.dynamics_model, "propagate_encoded"):
                 ctrl_all = self.dynamics_model.encode_controls(tree_map(controls, flat))
+            native = self._native_loop(obs_all, ctrl_all, T, N)
+        if native is not None:
+            check_range(native.device)
+            return native
         out = []
         for t in range(T):
             sl = slice(t * N, (t + 1) * N)

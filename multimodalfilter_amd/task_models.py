@@ -244,6 +244,11 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             self._obs_prog.run(t, R)
             return {"bias": t["bias"]}
 
+        def fused_measurements(self, ctx):
+            """``([(network, bias (R, 64), modality log-weight column or None)], stride)`` for the
+            native step loop (``mmf_pf_forward_loop``)."""
+            return [(self._net, ctx["bias"], None)], 0
+
         def forward_encoded(self, states, ctx, *, loglik=None, combine=False, modality_logw=None,
                             logw_stride=0):
             N, M, _ = states.shape

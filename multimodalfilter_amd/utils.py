@@ -49,6 +49,17 @@ class NoiseSource:
         return torch.rand(shape, generator=self._gen(like.device), dtype=torch.float32,
                           device=like.device)
 
+    # T consecutive per-step draws as one contiguous (T, *shape) block, in the same order a
+    # step-by-step loop would consume them (gaussian then uniform, per step)
+    def draw_steps(self, T: int, gauss_shape, unif_shape, *, like: torch.Tensor):
+        gs, us = [], []
+        for _ in range(T):
+            gs.append(self.gaussian(gauss_shape, like=like))
+            us.append(self.uniform(unif_shape, like=like) if unif_shape is not None else None)
+        g = torch.stack(gs).contiguous()
+        u = torch.stack(us).contiguous() if unif_shape is not None else None
+        return g, u
+
 
 class ReplayNoise(NoiseSource):
     """Feeds pre-drawn tensors in call order."""
@@ -66,3 +77,39 @@ class ReplayNoise(NoiseSource):
         t = self._u.pop(0)
         assert tuple(t.shape) == tuple(shape), (tuple(t.shape), tuple(shape))
         return t.to(device=like.device, dtype=torch.float32).contiguous()
+
+
+class StackedNoise(NoiseSource):
+    """Pre-drawn randomness kept as contiguous blocks: ``eps0 (N, M, d)`` for
+    ``initialize_beliefs``, ``eps (T, N, M, d)`` and ``u (T, N[, M])`` for the steps.  The C
+    step loop consumes the blocks directly (zero copy); step-by-step use gets views."""
+
+    def __init__(self, eps0, eps, u):
+        self._eps0, self._eps, self._u = eps0, eps, u
+        self._tg = self._tu = 0
+
+    def gaussian(self, shape, *, like):
+        if self._eps0 is not None:
+            t, self._eps0 = self._eps0, None
+        else:
+            t, self._tg = self._eps[self._tg], self._tg + 1
+        assert tuple(t.shape) == tuple(shape), (tuple(t.shape), tuple(shape))
+        return t.to(device=like.device, dtype=torch.float32).contiguous()
+
+    def uniform(self, shape, *, like):
+        t, self._tu = self._u[self._tu], self._tu + 1
+        assert tuple(t.shape) == tuple(shape), (tuple(t.shape), tuple(shape))
+        return t.to(device=like.device, dtype=torch.float32).contiguous()
+
+    def draw_steps(self, T, gauss_shape, unif_shape, *, like):
+        assert self._eps0 is None, "initialize_beliefs() consumes eps0 first"
+        g = self._eps[self._tg:self._tg + T]
+        assert tuple(g.shape) == (T,) + tuple(gauss_shape)
+        self._tg += T
+        u = None
+        if unif_shape is not None:
+            u = self._u[self._tu:self._tu + T]
+            assert tuple(u.shape) == (T,) + tuple(unif_shape)
+            self._tu += T
+        return g.to(device=like.device, dtype=torch.float32).contiguous(), \
+            None if u is None else u.to(device=like.device, dtype=torch.float32).contiguous()

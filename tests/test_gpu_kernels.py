@@ -476,3 +476,40 @@ def test_k7_traj_program_matches_torch_modules(R):
         want_w = torch.sigmoid(head_w(x_ref := wide(torch.relu(fuse(torch.cat([f, enc_a(a), enc_b(b)], 1))))))
     p.run(t, R)
     assert _rel_err(t["w"].cpu(), want_w) < 1e-5
+
+
+def test_k4_k7_rows_do_not_depend_on_batch_position():
+    """A trajectory's encoder outputs are the same bits whether it is evaluated alone, in a
+    batch of N or in the T*N batch ``forward_loop`` builds (the step-by-step and the batched
+    paths of the filters must agree exactly)."""
+    from multimodalfilter_amd import _abi, engine, layers
+    from multimodalfilter_amd.trajprog import TrajProgram
+
+    dev = _cuda()
+    torch.manual_seed(0)
+    enc = layers.image_encoder(64).to(dev)
+    imgs = (torch.randn(37, 32, 32, device=dev) * 0.5).clamp(-1, 1)
+    big = engine.encode_images([enc], imgs)[0]
+    for lo, hi in [(0, 1), (5, 10), (17, 37), (36, 37)]:
+        assert torch.equal(engine.encode_images([enc], imgs[lo:hi].contiguous())[0], big[lo:hi])
+
+    ve, wide, head = layers.vector_encoder(7, 64), layers.ResLinear(128), torch.nn.Linear(128, 5)
+    up = torch.nn.Linear(64, 128)
+    p = TrajProgram()
+    s = p.load("x", 7)
+    h = p.vector_encoder(ve, s, 7)
+    x = p.linear([(h, 0, 64)], up, _abi.ACT_RELU)
+    p.res_linear(wide, x, 128)
+    p.store("y", p.linear([(x, 0, 128)], head, _abi.ACT_SIGMOID), 5)
+    for m in (ve, wide, head, up):
+        m.to(dev)
+    xs = torch.randn(37, 7, device=dev)
+
+    def run(rows):
+        y = torch.empty((rows.shape[0], 5), device=dev)
+        p.run({"x": rows.contiguous(), "y": y}, rows.shape[0])
+        return y
+
+    big = run(xs)
+    for r in range(37):
+        assert torch.equal(run(xs[r:r + 1]), big[r:r + 1]), r

@@ -178,6 +178,25 @@ def test_particle_filter_tracks_oracle(tname, kind, cls, mode):
     loop = engine.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
     torch.testing.assert_close(loop.cpu(), torch.stack(want), rtol=1e-3, atol=1e-4)
 
+    # ... and so does the native step loop (mmf_pf_forward_loop: record_indices off, zero-copy
+    # noise blocks), bit for bit against the step-by-step engine path, including the belief
+    engine.record_indices = False
+    states_ref, logw_ref = engine.particle_states.clone(), engine.particle_log_weights.clone()
+    engine.noise = mmf.StackedNoise(eps0.to(dev), torch.stack(eps).to(dev), torch.stack(us).to(dev))
+    engine.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
+    calls = []
+    from multimodalfilter_amd import _abi
+    real = _abi.pf_forward_loop
+    _abi.pf_forward_loop = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        native = engine.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
+    finally:
+        _abi.pf_forward_loop = real
+    assert calls, "fused models must take the native step loop"
+    assert torch.equal(native, loop)
+    assert torch.equal(engine.particle_states, states_ref)
+    assert torch.equal(engine.particle_log_weights, logw_ref)
+
 
 @pytest.mark.parametrize("tname,cls,okw", [
     ("door", "DoorKalmanFilter", {}),
@@ -218,3 +237,42 @@ def test_kalman_filters_track_oracle(tname, cls, okw):
     for fo, fe in zip(subs_o, subs_e):
         s = max(1.0, float(fo._belief_covariance.abs().max()))
         assert float((fe._belief_covariance.cpu() - fo._belief_covariance).abs().max()) / s < REL_TOL
+
+
+@pytest.mark.parametrize("resample,T", [(False, 3), (False, 4), (True, 1), (True, 4)])
+def test_native_step_loop_equals_stepwise(resample, T):
+    """``mmf_pf_forward_loop`` (C host loop) against T separate ``forward`` calls on the same
+    pre-drawn randomness: estimates and the final belief are identical bits, whichever of the
+    ping-pong buffers the belief ends in (odd / even T, with and without resampling)."""
+    _need_gpu()
+    import multimodalfilter_amd as mmf
+
+    dev = torch.device("cuda:0")
+    d, N, M = 3, 5, 300
+    g = torch.Generator().manual_seed(23)
+    obs = {"image": (torch.randn((T, N, 32, 32), generator=g) * 0.5).clamp(-1, 1).to(dev),
+           "gripper_pos": torch.randn((T, N, 3), generator=g).to(dev),
+           "gripper_sensors": torch.randn((T, N, 7), generator=g).to(dev)}
+    ctrl = torch.randn((T, N, 7), generator=g).to(dev)
+    x0 = torch.randn((N, d), generator=g).to(dev)
+    cov = (torch.eye(d) * 0.1)[None].expand(N, d, d).to(dev)
+    eps0 = torch.randn((N, M, d), generator=g).to(dev)
+    eps = torch.randn((T, N, M, d), generator=g).to(dev)
+    us = torch.rand((T, N), generator=g).to(dev)
+    f = mmf.door_models.DoorCrossmodalParticleFilter().to(dev).eval()
+    f.num_particles = M
+    f.resample = resample
+
+    f.noise = mmf.StackedNoise(eps0, eps, us)
+    f.initialize_beliefs(mean=x0, covariance=cov)
+    step = torch.stack([f(observations={k: v[t] for k, v in obs.items()}, controls=ctrl[t]) for t in range(T)])
+    s_ref, w_ref = f.particle_states.clone(), f.particle_log_weights.clone()
+
+    f.noise = mmf.StackedNoise(eps0, eps, us)
+    f.initialize_beliefs(mean=x0, covariance=cov)
+    loop = f.forward_loop(observations=obs, controls=ctrl)
+    assert torch.equal(loop, step)
+    assert torch.equal(f.particle_states, s_ref) and torch.equal(f.particle_log_weights, w_ref)
+    # the belief stays usable for further single steps
+    f.noise = mmf.StackedNoise(None, eps[:1], us[:1])
+    f(observations={k: v[0] for k, v in obs.items()}, controls=ctrl[0])
