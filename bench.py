@@ -187,8 +187,8 @@ def cpu_baseline_ekf(wl, engine_filter, state_dim, cores, sample_batch=256, samp
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="door_pf", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU")
     ap.add_argument("--particles", type=int, default=None)
@@ -257,7 +257,7 @@ def main():
             distributed.all_gather_rows(
                 evaluation.per_trajectory_mse(pred_w, traj_w["states"][1:], start=min(30, W // 2)))
         torch.cuda.synchronize()
-        timer = None if args.no_kernel_timers else engine.KernelTimer()
+        timer = None if args.no_kernel_timers else engine.KernelTimer(loop_stride=max(1, K // 16))
         engine.set_kernel_timer(timer)
         distributed.barrier()
         torch.cuda.synchronize()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 5
+#define MMF_ABI_VERSION 6
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -222,8 +222,10 @@ typedef struct MmfPfLoopArgs {
   int32_t* range_flag;       /* device int32 or null (see mmf_pf_dynamics)                    */
   int32_t* final_location;   /* HOST int32 out or null: bit 0 belief states in states_b,      */
                              /* bit 1 log-weights in logw_b                                   */
-  void* const* events;       /* HOST array of 2*(2+n_meas)*T hipEvent_t or null: recorded     */
-                             /* around every launch, [step][dynamics, measure.., resample][start,end] */
+  void* const* events;       /* HOST array of hipEvent_t or null: recorded around every launch */
+                             /* of the sampled steps, [sample][dynamics, measure.., resample][start,end] */
+  int32_t event_stride;      /* steps t with t % event_stride == 0 are sampled (<= 1: every    */
+                             /* step); `events` holds 2*(2+n_meas)*ceil(T/stride) entries      */
 } MmfPfLoopArgs;             /* host struct holding device pointers                           */
 
 int mmf_pf_forward_loop(const MmfPfLoopArgs* args /* host */, void* stream);

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmmf_hip.so")
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 5
+ABI_VERSION = 6
 PREC_F32, PREC_F16X3 = 0, 1
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}
 
@@ -61,7 +61,8 @@ class MmfPfLoopArgs(Structure):
                 ("noise", _FP), ("scale_tril", _FP), ("uniforms", _FP),
                 ("states_a", _FP), ("states_b", _FP), ("logw_a", _FP), ("logw_b", _FP),
                 ("loglik", _FP), ("estimates", _FP), ("range_flag", _FP),
-                ("final_location", POINTER(c_int32)), ("events", POINTER(c_void_p))]
+                ("final_location", POINTER(c_int32)), ("events", POINTER(c_void_p)),
+                ("event_stride", c_int32)]
 
 
 class MmfImageEncoderDesc(Structure):
@@ -239,14 +240,16 @@ def traj_program(prog: torch.Tensor, n_instr: int, weights: torch.Tensor, io_ten
                                        stream_of(weights)), "mmf_traj_program")
 
 
-def pf_forward_loop(args: MmfPfLoopArgs, like: torch.Tensor, events=None) -> int:
+def pf_forward_loop(args: MmfPfLoopArgs, like: torch.Tensor, events=None, event_stride: int = 1) -> int:
     """Enqueue T filter steps; returns the final-location bits (see include/mmf.h).
-    ``events``: optional flat list of created ``torch.cuda.Event`` (timing) recorded in C."""
+    ``events``: optional flat list of created ``torch.cuda.Event`` (timing) recorded in C
+    around the launches of every ``event_stride``-th step."""
     loc = c_int32(0)
     args.final_location = ctypes.pointer(loc)
     if events is not None:
         arr = (c_void_p * len(events))(*[e.cuda_event for e in events])
         args.events = arr
+        args.event_stride = event_stride
     with _on(like):
         _check(load().mmf_pf_forward_loop(ctypes.byref(args), stream_of(like)), "mmf_pf_forward_loop")
     return int(loc.value)

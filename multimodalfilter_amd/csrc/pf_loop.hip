@@ -22,9 +22,11 @@ extern "C" int mmf_pf_forward_loop(const MmfPfLoopArgs* a, void* stream) {
   float* lw_cur = a->logw_a;
   float* lw_other = a->logw_b;
   hipStream_t hs = static_cast<hipStream_t>(stream);
-  int ev = 0;  // optional timing events: [step][dynamics, measure x n_meas, resample][start, end]
+  int ev = 0;  // optional timing events: [sample][dynamics, measure x n_meas, resample][start, end]
+  const int stride = a->event_stride > 1 ? a->event_stride : 1;
+  bool sampled = false;  // an event record costs a barrier packet: long loops sample every stride-th step
   auto mark = [&]() {
-    if (a->events) {
+    if (sampled) {
       hipError_t e = hipEventRecord(static_cast<hipEvent_t>(a->events[ev++]), hs);
       if (e != hipSuccess) return static_cast<int>(e);
     }
@@ -32,6 +34,7 @@ extern "C" int mmf_pf_forward_loop(const MmfPfLoopArgs* a, void* stream) {
   };
   for (int t = 0; t < a->T; ++t) {
     int rc;
+    sampled = a->events && t % stride == 0;
     if ((rc = mark())) return rc;
     rc = mmf_pf_dynamics(a->dyn_packed, a->n_res_dyn, a->precision, cur, a->dyn_bias + t * row * MMF_UNITS,
                              a->noise + t * nm * a->d, a->scale_tril, other, a->range_flag, a->N, a->M, a->d,

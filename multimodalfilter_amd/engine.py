@@ -22,8 +22,11 @@ class KernelTimer:
     """HIP-event timing of individual kernel launches on the launching stream (used by
     ``bench.py`` for the roofline figure; off by default, no cost when off)."""
 
-    def __init__(self, prealloc: int = 512):
+    def __init__(self, prealloc: int = 512, loop_stride: int = 1):
         self.records = {}
+        # native step loops record events on every loop_stride-th step only: each record is a
+        # barrier packet between two kernels (~6 % of the headline step when taken everywhere)
+        self.loop_stride = loop_stride
         # hipEventCreate is slow the first time (~0.1 ms each): build the pool up front, outside
         # any timed region, and touch every event once
         self._pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * prealloc)]
@@ -91,7 +94,10 @@ def reserve_memory(device, nbytes: int):
     loop of the headline workload)."""
     if nbytes > 0:
         block = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        del block
+        # requests under 1 MB come from the allocator's separate pool of 2 MB segments
+        # (estimates, per-step scalars, program outputs): grow that one as well
+        small = [torch.empty(512 << 10, dtype=torch.uint8, device=device) for _ in range(32)]
+        del block, small
 
 
 def require_device(t: torch.Tensor, what: str):

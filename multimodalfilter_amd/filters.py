@@ -83,7 +83,13 @@ class ParticleFilter(base.Filter):
         dev = next(self.parameters()).device
         per_row = 64 * 4 * 12               # encoder contexts, image features, program outputs
         per_step = batch * M * 4 * (2 * d + 4)  # particle ping-pong, log-weights, log-lik, noise views
-        nbytes = steps * batch * per_row + 4 * per_step + (64 << 20)
+        # the image-encoder workspace is persistent: create it now, outside the reserved block
+        if steps * batch > 0:
+            engine._image_workspace(dev, min(steps * batch, engine._IMAGE_CHUNK), 2)
+        # 8 steps' worth of particle buffers: initialize_beliefs() builds the new belief while the
+        # previous run's belief and scratch are still alive (measured: 4x left the first loop at
+        # a new length one 12 MB segment short = one stream-draining hipMalloc)
+        nbytes = steps * batch * per_row + 8 * per_step + (64 << 20)
         reserve_memory(dev, nbytes)
         return nbytes
 
@@ -235,9 +241,11 @@ class ParticleFilter(base.Filter):
         timer = engine.kernel_timer()
         events = None
         names = ["particle_net_dynamics"] + ["particle_net_measure"] * len(nets) + ["pf_reweight_resample"]
+        stride = 1
         if timer is not None:
-            events = timer.loop_events(2 * len(names) * T)
-        loc = _abi.pf_forward_loop(a, like, events)
+            stride = max(1, int(timer.loop_stride))
+            events = timer.loop_events(2 * len(names) * ((T + stride - 1) // stride))
+        loc = _abi.pf_forward_loop(a, like, events, stride)
         if timer is not None:
             R = N * M
             dflops = 2.0 * R * engine.particle_net_macs(d, dyn._net.n_res, dyn._net.n_out)
