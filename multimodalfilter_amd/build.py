@@ -13,14 +13,23 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmf_hip.so")
 SOURCES = ["abi.hip", "pf_resample.hip", "ekf.hip", "particle_net.hip", "image_encoder.hip", "traj_program.hip", "pf_loop.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# particle_net.hip: with the SLP vectoriser on, the f16x3 operand split (x - float(hi) -> f16)
+# becomes cvt + cvt + v_pk_add_f32 + cvt; without it the same source selects
+# v_fma_mixlo_f16 / v_fma_mixhi_f16 (2 instructions per pair fewer; K2 is VALU-issue bound)
+EXTRA_FLAGS = {"particle_net.hip": ["-fno-slp-vectorize"]}
+OBJ = os.path.join(CSRC, "_obj")
+
+
+def _headers():
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    files.append(os.path.join(os.path.dirname(HERE), "include", "mmf.h"))
+    files.append(os.path.abspath(__file__))
+    return files
 
 
 def _deps():
-    files = [os.path.join(CSRC, s) for s in SOURCES]
-    files += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    files.append(os.path.join(os.path.dirname(HERE), "include", "mmf.h"))
-    return files
+    return [os.path.join(CSRC, s) for s in SOURCES] + _headers()
 
 
 def is_stale() -> bool:
@@ -30,11 +39,31 @@ def is_stale() -> bool:
     return any(os.path.getmtime(f) > built for f in _deps())
 
 
+def _compile(hipcc, src, verbose):
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    deps = [os.path.join(CSRC, src)] + _headers()
+    if os.path.exists(obj) and all(os.path.getmtime(f) <= os.path.getmtime(obj) for f in deps):
+        return obj
+    cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", "-o", obj, os.path.join(CSRC, src)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return obj
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
+
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *FLAGS, "-o", LIB + ".tmp", *[os.path.join(CSRC, s) for s in SOURCES]]
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        objs = list(pool.map(lambda src: _compile(hipcc, src, verbose), SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp", *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

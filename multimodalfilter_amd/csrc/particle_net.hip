@@ -30,6 +30,8 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half2v = __attribute__((ext_vector_type(2))) _Float16;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 constexpr int kUnits = MMF_UNITS;
@@ -162,6 +164,26 @@ __device__ __forceinline__ void add_bias(const float* __restrict__ bl, Act<CT>& 
     }
 }
 
+// acc += bias two elements at a time (v_pk_add_f32): the f16x3 path's skip accumulators
+template <int CT>
+__device__ __forceinline__ void add_bias_packed(const float* __restrict__ bl, Act<CT>& acc, int h) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bl + 32 * t + 8 * g + 4 * h);
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          f32x2 v = {acc.v[t][c][4 * g + e], acc.v[t][c][4 * g + e + 1]};
+          v += f32x2{b[e], b[e + 1]};
+          acc.v[t][c][4 * g + e] = v[0];
+          acc.v[t][c][4 * g + e + 1] = v[1];
+        }
+    }
+}
+
 // max(v, 0) as ONE instruction: on accumulator outputs hipcc adds a canonicalising v_max in
 // front of fmaxf (2 ops per element).  On the raw bits, max((int)v, 0) is the same function
 // for every non-NaN float (negative floats are negative ints; -0.0 -> +0.0) and is a single
@@ -213,22 +235,33 @@ struct SplitAct {
   half8 hi[4][CT], lo[4][CT];  // [k-step][col tile]
 };
 
-using f32x2 = __attribute__((ext_vector_type(2))) float;
 
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+// hi = RTZ_f16(x); lo = RTZ_f16(x - hi).  `neg_one` is -1.0f held in an SGPR the optimiser
+// cannot see through, so that fma(float(hi), neg_one, x) selects v_fma_mix_f32 (f16 source read
+// straight from the packed register, f32 arithmetic): 4 instructions per pair instead of
+// cvt_pkrtz + 2 cvt_f32_f16 + pk_add + cvt_pkrtz.  (v_fma_mixlo/hi_f16 would fold the final
+// conversion as well but issue at half rate on gfx950: scripts/ubench/valu_rate.hip.)
+// x - hi is exact in fp32 (the residual has <= 13 significant bits).
+__device__ __forceinline__ void split_pair(float x0, float x1, float neg_one, unsigned& hi, unsigned& lo) {
   const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-  const f32x2 x = {x0, x1};
-  const f32x2 hf = {static_cast<float>(h[0]), static_cast<float>(h[1])};
-  const f32x2 r = x - hf;  // one v_pk_add_f32; exact (the residual has <= 13 significant bits)
-  const auto l = __builtin_amdgcn_cvt_pkrtz(r[0], r[1]);
+  const float r0 = __builtin_fmaf(static_cast<float>(h[0]), neg_one, x0);
+  const float r1 = __builtin_fmaf(static_cast<float>(h[1]), neg_one, x1);
+  const auto l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
   hi = __builtin_bit_cast(unsigned, h);
   lo = __builtin_bit_cast(unsigned, l);
 }
 
-// Every activation that reaches a split is a ReLU output (>= 0): its magnitude is tracked
-// with a plain max (no abs).
-template <int CT>
-__device__ __forceinline__ void split_act(const Act<CT>& x, SplitAct<CT>& o, float& amax) {
+// Range tracking on the packed hi halves: RTZ saturates at the largest finite f16 (0x7BFF) for
+// every |x| >= 65504, and for non-negative halves the i16 order is the f16 order, so ONE
+// v_pk_max_i16 per pair keeps the running maximum (fmaxf on the fp32 values costs 3 ops per
+// pair once canonicalisation is counted).  Negative halves compare below zero and are ignored,
+// which is right after a ReLU; the one split that sees signed values (dynamics trunk entry, no
+// ReLU after the join layer) passes SIGNED and masks the sign bits first.
+using short2v = __attribute__((ext_vector_type(2))) short;
+constexpr short kF16Saturated = 0x7BFF;  // also below +inf (0x7C00) and every NaN pattern
+
+template <int CT, bool SIGNED = false>
+__device__ __forceinline__ void split_act(const Act<CT>& x, SplitAct<CT>& o, float neg_one, short2v& amax) {
 #pragma unroll
   for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
@@ -239,15 +272,26 @@ __device__ __forceinline__ void split_act(const Act<CT>& x, SplitAct<CT>& o, flo
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           unsigned hh, ll;
-          const float x0 = x.v[tp][c][8 * u + 2 * p], x1 = x.v[tp][c][8 * u + 2 * p + 1];
-          amax = __builtin_fmaxf(amax, __builtin_fmaxf(x0, x1));
-          split_pair(x0, x1, hh, ll);
+          split_pair(x.v[tp][c][8 * u + 2 * p], x.v[tp][c][8 * u + 2 * p + 1], neg_one, hh, ll);
           h[p] = hh;
           l[p] = ll;
         }
+        // a short tree per fragment, then one link of the running chain
+        constexpr unsigned kMask = SIGNED ? 0x7fff7fffu : 0xffffffffu;
+        const short2v m01 = __builtin_elementwise_max(__builtin_bit_cast(short2v, h[0] & kMask),
+                                                      __builtin_bit_cast(short2v, h[1] & kMask));
+        const short2v m23 = __builtin_elementwise_max(__builtin_bit_cast(short2v, h[2] & kMask),
+                                                      __builtin_bit_cast(short2v, h[3] & kMask));
+        amax = __builtin_elementwise_max(amax, __builtin_elementwise_max(m01, m23));
         o.hi[2 * tp + u][c] = __builtin_bit_cast(half8, h);
         o.lo[2 * tp + u][c] = __builtin_bit_cast(half8, l);
       }
+  // Pin the running maximum here (no instruction is emitted): left alone, the compiler sinks
+  // every v_pk_max_i16 to the flag test at the end of the tile and keeps the hi fragments of
+  // all seven layers alive for it -- in scratch.
+  unsigned pin = __builtin_bit_cast(unsigned, amax);
+  asm volatile("" : "+v"(pin));
+  amax = __builtin_bit_cast(short2v, pin);
 }
 
 template <int CT>
@@ -270,17 +314,17 @@ __device__ __forceinline__ void mfma_layer_f16(const float* __restrict__ Wl, con
     }
 }
 
-template <int CT>
+template <int CT, bool SIGNED = false>
 __device__ __forceinline__ void res_block_f16(const float* __restrict__ lds, int n_res, int l1,
                                               Act<CT>& x, Act<CT>& hbuf, SplitAct<CT>& sp, int lane,
-                                              float& amax) {
+                                              float neg_one, short2v& amax) {
   const int h = lane >> 5;
-  split_act<CT>(x, sp, amax);
+  split_act<CT, SIGNED>(x, sp, neg_one, amax);
   add_bias<CT, false>(lds + off_bias(n_res) + l1 * kUnits, hbuf, h, 1.f);
   mfma_layer_f16<CT>(lds + off_layers() + l1 * kLayerFloats, sp, hbuf, lane);
   relu<CT, false>(hbuf, true);
-  split_act<CT>(hbuf, sp, amax);
-  add_bias<CT, true>(lds + off_bias(n_res) + (l1 + 1) * kUnits, x, h, 1.f);
+  split_act<CT>(hbuf, sp, neg_one, amax);
+  add_bias_packed<CT>(lds + off_bias(n_res) + (l1 + 1) * kUnits, x, h);
   mfma_layer_f16<CT>(lds + off_layers() + (l1 + 1) * kLayerFloats, sp, x, lane);
   relu<CT, false>(x, true);
 }
@@ -323,6 +367,10 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgs a)
     for (int i = threadIdx.x; i < blob_floats(NRES) / 4; i += kThreads) dst[i] = src[i];
   }
   __syncthreads();
+
+  // -1.0f in an SGPR, opaque to the optimiser (see split_pair); the asm emits no instruction
+  float neg_one = -1.0f;
+  asm volatile("" : "+s"(neg_one));
 
   const int lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
@@ -382,8 +430,8 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgs a)
 
     // ---- encoder residual block (layers 0, 1)
     SplitAct<F16 ? CT : 0> SP;
-    float amax = 0.f;  // f16x3: largest (non-negative) value handed to the split in this tile
-    if constexpr (F16) res_block_f16<CT>(lds, NRES, 0, X, H, SP, lane, amax);
+    short2v amax = {0, 0};  // f16x3: largest hi halves handed to the MFMAs in this tile
+    if constexpr (F16) res_block_f16<CT>(lds, NRES, 0, X, H, SP, lane, neg_one, amax);
     else res_block<CT, JAC>(lds, NRES, 0, X, H, lane, primal);
 
     // ---- join layer (2): per-trajectory hoisted half arrives as the accumulator init
@@ -400,7 +448,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgs a)
         }
       }
     if constexpr (F16) {
-      split_act<CT>(X, SP, amax);
+      split_act<CT>(X, SP, neg_one, amax);
       mfma_layer_f16<CT>(lds + off_layers() + 2 * kLayerFloats, SP, H, lane);
     } else {
       mfma_layer<CT>(lds + off_layers() + 2 * kLayerFloats, X, H, lane);
@@ -410,13 +458,18 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgs a)
     // ---- residual trunk: activations now live in H, X is scratch
 #pragma unroll
     for (int i = 0; i < NRES; ++i) {
-      if constexpr (F16) res_block_f16<CT>(lds, NRES, 3 + 2 * i, H, X, SP, lane, amax);
+      // without a ReLU after the join layer (dynamics) the trunk's first split sees signed values
+      if constexpr (F16) {
+        if (i == 0 && KIND != kMeasure) res_block_f16<CT, true>(lds, NRES, 3, H, X, SP, lane, neg_one, amax);
+        else res_block_f16<CT>(lds, NRES, 3 + 2 * i, H, X, SP, lane, neg_one, amax);
+      }
       else res_block<CT, JAC>(lds, NRES, 3 + 2 * i, H, X, lane, primal);
     }
 
     if constexpr (F16) {
       // an operand beyond the f16 range saturates the split (finite but wrong): report it
-      if (a.range_flag != nullptr && !(amax < kF16SplitMax)) atomicOr(a.range_flag, 1);
+      if (a.range_flag != nullptr && (amax[0] >= kF16Saturated || amax[1] >= kF16Saturated))
+        atomicOr(a.range_flag, 1);
     }
 
     // ---- head (64 -> NOUT) on the VALU: each lane holds 32 of the 64 features of its columns
