@@ -330,6 +330,18 @@ def main():
                                       "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": gbs / HBM_PEAK_GBS,
                                       "traffic": pmc_traffic("pf_reweight_resample_kernel<3>") if default_shape else None}
+        if wl["kind"] != "pf" and "image_encoder" in ks:
+            # EKF steps are > 99 % image-encoder MACs: the K4 launch sequence
+            # (stem + four 3x3 convolutions + linear tail) is the dominant "kernel"
+            dom = ks["image_encoder"]
+            ach = dom["flops_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "image encoder launch sequence (conv_kernel<1,32,5>, 4 x conv_f16x3_kernel, "
+                                         "fc_partial_kernel, fc_tail_kernel) per chunk of images",
+                               "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK["f16x3"], "unit": "TFLOP/s",
+                               "frac": ach / MFMA_PEAK["f16x3"], "traffic": None,
+                               "note": "ALGORITHMIC fp32 FLOPs (26.12 MMAC per image per encoder); the 3x3 convolutions "
+                                       "execute 3 f16 MFMA products per product and move fp32 activations between "
+                                       "layers through HBM/L2, which is what bounds them today (DESIGN.md K4)"}
     if "roofline" not in out:
         out["roofline"] = None
 

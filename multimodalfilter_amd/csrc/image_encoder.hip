@@ -316,16 +316,37 @@ __device__ __forceinline__ int swz(int col) {
   return CIN == 32 ? (col >> 2) & 3 : (col >> 3) & 1;
 }
 
-template <int CIN, int COUT, bool RELU, bool SKIP>
-__global__ __launch_bounds__(kConvThreads) void conv_f16x3_kernel(ConvHArgs a) {
-  constexpr int RB = kBand + 2;
+// Phase clocks for scripts/ubench/k4_phases.hip (compiled out of the library).
+#ifdef MMF_K4_PHASE_CLOCKS
+__device__ long long g_phase[4][8];  // [3x3 layer][phase]
+#define K4_CLOCK(i)                                                     \
+  do {                                                                  \
+    const long long now_ = wall_clock64();                              \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_phase[kLayerId][i] += now_ - tprev_; \
+    tprev_ = now_;                                                      \
+  } while (0)
+#else
+#define K4_CLOCK(i)
+#endif
+
+// BAND output rows per workgroup, one wave per two rows.  BAND = 8 keeps two workgroups resident
+// per CU (2 x (planes 43.5 KB + weights 36.9 KB) <= 160 KB): while one is in its MFMA phase
+// the other stages / stores, which a single lock-stepped workgroup per CU cannot overlap
+// (measured per 16-row band, one workgroup per CU: stage 3.6 us + MFMA 4.0 us + store 2.2 us in
+// series; scripts/ubench/k4_phases.hip).
+template <int CIN, int COUT, bool RELU, bool SKIP, int BAND>
+__global__ __launch_bounds__(BAND * 32) void conv_f16x3_kernel(ConvHArgs a) {
+  constexpr int THREADS = BAND * 32;
+  constexpr int RB = BAND + 2;
   constexpr int KC = CIN / 16;
   constexpr int CG = CIN / 8;                      // 16-byte chunks per pixel
   constexpr int PIX = CIN * 2;                     // bytes per pixel per plane
   constexpr int PLANE = RB * kWPh * PIX;           // bytes per plane
   constexpr int NW = 9 * KC * 2 * 64 * 16;         // weight bytes
-  constexpr int ITEMS = RB * CG * kWPh;            // staging items (8 channels of one pixel)
-  constexpr int IPT = (ITEMS + kConvThreads - 1) / kConvThreads;
+  constexpr int XG = kImg / 4;                     // groups of 4 pixels per row
+  constexpr int ITEMS = RB * CG * XG;              // staging items: 8 channels x 4 pixels
+  constexpr int IPT = (ITEMS + THREADS - 1) / THREADS;
+  constexpr int BPI = kImg / BAND;                 // bands per image
   extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
   unsigned char* tile_hi = ldsb;
   unsigned char* tile_lo = ldsb + PLANE;
@@ -338,62 +359,89 @@ __global__ __launch_bounds__(kConvThreads) void conv_f16x3_kernel(ConvHArgs a) {
   {
     const float4* src = reinterpret_cast<const float4*>(blob + a.hoff);
     float4* dst = reinterpret_cast<float4*>(wl);
-    for (int i = tid; i < NW / 16; i += kConvThreads) dst[i] = src[i];
+    for (int i = tid; i < NW / 16; i += THREADS) dst[i] = src[i];
+    // the two padding columns of every row are zero for the whole kernel
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int i = tid; i < RB * 2 * CG; i += THREADS) {
+      const int cg = i % CG, side = (i / CG) & 1, rr = i / (2 * CG);
+      const int off = (rr * kWPh + (side ? kWPh - 1 : 0)) * PIX + 16 * cg;
+      *reinterpret_cast<u32x4*>(tile_hi + off) = z;
+      *reinterpret_cast<u32x4*>(tile_lo + off) = z;
+    }
   }
   const float* in_net = a.in + static_cast<size_t>(net) * a.N * CIN * kImg * kImg;
-  const int nbands = 2 * a.N;
+  const int nbands = BPI * a.N;
 
-  // prefetch registers: IPT items x 8 channels
-  float pf[IPT][8];
+  // staging item -> (row rr of the band, channel chunk cg, pixel group xg): lanes run along a
+  // row first, so one wave-instruction reads 128-B contiguous segments of the NCHW planes
+  const int it_xg[2] = {tid % XG, (tid + THREADS) % XG};
+  const int it_cg[2] = {(tid / XG) % CG, ((tid + THREADS) / XG) % CG};
+  const int it_rr[2] = {tid / (XG * CG), (tid + THREADS) / (XG * CG)};
+  static_assert(IPT <= 2, "staging indices are precomputed for two rounds");
+
+  // prefetch registers: IPT items x 8 channels x 4 pixels
+  f32x4 pf[IPT][8];
   auto prefetch = [&](int band) {
-    const int img = band >> 1, y0 = (band & 1) * kBand;
+    const int img = band / BPI, y0 = (band % BPI) * BAND;
     const float* in = in_net + static_cast<size_t>(img) * CIN * kImg * kImg;
 #pragma unroll
     for (int it = 0; it < IPT; ++it) {
-      const int item = tid + it * kConvThreads;
-      const int cc = item % kWPh, rest = item / kWPh, cg = rest % CG, rr = rest / CG;
-      const int y = y0 - 1 + rr, x = cc - 1;
-      const bool ok = item < ITEMS && y >= 0 && y < kImg && x >= 0 && x < kImg;
+      const int y = y0 - 1 + it_rr[it];
+      const bool ok = tid + it * THREADS < ITEMS && y >= 0 && y < kImg;
+      const float* p = in + ((it_cg[it] * 8) * kImg + (ok ? y : 0)) * kImg + 4 * it_xg[it];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) pf[it][i] = ok ? in[((cg * 8 + i) * kImg + y) * kImg + x] : 0.f;
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        pf[it][i] = ok ? *reinterpret_cast<const f32x4*>(p + i * kImg * kImg) : zero;
+      }
     }
   };
   float amax = 0.f;
   auto commit = [&]() {  // registers -> split -> swizzled LDS planes
 #pragma unroll
     for (int it = 0; it < IPT; ++it) {
-      const int item = tid + it * kConvThreads;
-      if (item < ITEMS) {
-        const int cc = item % kWPh, rest = item / kWPh, cg = rest % CG, rr = rest / CG;
-        u32x4 hv, lv;
+      if (tid + it * THREADS < ITEMS) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const float x0 = pf[it][2 * p], x1 = pf[it][2 * p + 1];
-          amax = fmaxf(amax, fmaxf(fabsf(x0), fabsf(x1)));
-          const auto hh = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-          const f32x2 xs = {x0, x1};
-          const f32x2 hf = {static_cast<float>(hh[0]), static_cast<float>(hh[1])};
-          const f32x2 r = xs - hf;
-          const auto ll = __builtin_amdgcn_cvt_pkrtz(r[0], r[1]);
-          hv[p] = __builtin_bit_cast(unsigned, hh);
-          lv[p] = __builtin_bit_cast(unsigned, ll);
+        for (int px = 0; px < 4; ++px) {
+          u32x4 hv, lv;
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const float x0 = pf[it][2 * p][px], x1 = pf[it][2 * p + 1][px];
+            amax = fmaxf(amax, fmaxf(fabsf(x0), fabsf(x1)));
+            const auto hh = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+            const f32x2 xs = {x0, x1};
+            const f32x2 hf = {static_cast<float>(hh[0]), static_cast<float>(hh[1])};
+            const f32x2 r = xs - hf;
+            const auto ll = __builtin_amdgcn_cvt_pkrtz(r[0], r[1]);
+            hv[p] = __builtin_bit_cast(unsigned, hh);
+            lv[p] = __builtin_bit_cast(unsigned, ll);
+          }
+          const int cc = 4 * it_xg[it] + px + 1;
+          const int off = (it_rr[it] * kWPh + cc) * PIX + 16 * (it_cg[it] ^ swz<CIN>(cc));
+          *reinterpret_cast<u32x4*>(tile_hi + off) = hv;
+          *reinterpret_cast<u32x4*>(tile_lo + off) = lv;
         }
-        const int off = (rr * kWPh + cc) * PIX + 16 * (cg ^ swz<CIN>(cc));
-        *reinterpret_cast<u32x4*>(tile_hi + off) = hv;
-        *reinterpret_cast<u32x4*>(tile_lo + off) = lv;
       }
     }
   };
 
   int band = blockIdx.x;
   if (band < nbands) prefetch(band);
+#ifdef MMF_K4_PHASE_CLOCKS
+  constexpr int kLayerId = CIN == 16 ? 3 : (COUT == 16 ? 2 : (SKIP ? 1 : 0));
+  long long tprev_ = wall_clock64();
+#endif
   for (; band < nbands; band += gridDim.x) {
     __syncthreads();  // everyone finished reading the previous band's planes (and the weights landed)
+    K4_CLOCK(0);
     commit();
+    K4_CLOCK(1);
     __syncthreads();
+    K4_CLOCK(2);
     if (band + gridDim.x < nbands) prefetch(band + gridDim.x);  // in flight during the MFMAs
+    K4_CLOCK(3);
 
-    const int img = band >> 1, y0 = (band & 1) * kBand;
+    const int img = band / BPI, y0 = (band % BPI) * BAND;
     const int r0 = 2 * wave;
     const size_t obase = (static_cast<size_t>(net) * a.N + img) * COUT * kImg * kImg;
     f32x16 acc[2];
@@ -432,6 +480,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_f16x3_kernel(ConvHArgs a) {
         }
       }
     }
+    K4_CLOCK(4);
     // epilogue: lane (x = j, h), reg r -> channel (r&3) + 8(r>>2) + 4h; 128-B row segments
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr)
@@ -446,22 +495,25 @@ __global__ __launch_bounds__(kConvThreads) void conv_f16x3_kernel(ConvHArgs a) {
           a.out[o] = v;
         }
       }
+    K4_CLOCK(5);
   }
   if (a.range_flag != nullptr && !(amax < 65504.0f)) atomicOr(a.range_flag, 1);
 }
 
 template <int CIN, int COUT, bool RELU, bool SKIP>
 int launch_conv_h(const ConvHArgs& a, int nets, hipStream_t s) {
-  constexpr size_t lds = 2 * (kBand + 2) * kWPh * CIN * 2 + 9 * (CIN / 16) * 2 * 64 * 16;
+  constexpr int BAND = 8;
+  constexpr size_t lds = 2 * (BAND + 2) * kWPh * CIN * 2 + 9 * (CIN / 16) * 2 * 64 * 16;
+  constexpr int per_cu = static_cast<int>(160 * 1024 / lds) < 2 ? 1 : 2;  // co-resident workgroups
   static_assert(lds <= 160 * 1024, "f16 planes + weights must fit LDS");
-  auto k = conv_f16x3_kernel<CIN, COUT, RELU, SKIP>;
+  auto k = conv_f16x3_kernel<CIN, COUT, RELU, SKIP, BAND>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   if (e != hipSuccess) return static_cast<int>(e);
-  int gx = 2 * a.N;
-  const int cap = 256 / nets > 0 ? 256 / nets : 1;  // one persistent workgroup per CU
+  int gx = (kImg / BAND) * a.N;
+  const int cap = 256 * per_cu / nets > 0 ? 256 * per_cu / nets : 1;  // persistent workgroups
   if (gx > cap) gx = cap;
-  k<<<dim3(gx, nets), kConvThreads, lds, s>>>(a);
+  k<<<dim3(gx, nets), BAND * 32, lds, s>>>(a);
   MMF_CHECK_LAUNCH();
   return 0;
 }

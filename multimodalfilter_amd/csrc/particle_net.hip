@@ -23,6 +23,8 @@
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 
+#include <utility>
+
 #include "mmf_common.h"
 
 namespace {
@@ -329,6 +331,119 @@ __device__ __forceinline__ void res_block_f16(const float* __restrict__ lds, int
   relu<CT, false>(x, true);
 }
 
+// ------------------------------------------------------------------ f16x3, pipelined halves
+// The 64-particle tile is processed as two 32-particle halves whose layers are offset by half
+// a layer: while the matrix pipe runs the 24 MFMAs of one half's layer, the wave issues the
+// other half's ReLU / operand split / range tracking in their shadow.  An MFMA holds the
+// SIMD's vector issue for 8 of its 32 cycles; up to six of these VALU instructions per MFMA
+// are free when they are placed between independent MFMAs (scripts/ubench/mfma_fill.hip), and
+// the split needs 4.7.  The order is pinned with sched_group_barrier; left to the scheduler
+// (and in the unpipelined kernel, where a layer's VALU depends on its own MFMAs) the two kinds
+// of work run back to back.
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+template <int C>
+__device__ __forceinline__ void relu_half(Act<2>& a) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a.v[t][C][r] = relu1(a.v[t][C][r]);
+}
+
+template <int C, bool SIGNED>
+__device__ __forceinline__ void split_half(const Act<2>& x, SplitAct<2>& o, float neg_one, short2v& amax) {
+#pragma unroll
+  for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      u32x4 h, l;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        unsigned hh, ll;
+        split_pair(x.v[tp][C][8 * u + 2 * p], x.v[tp][C][8 * u + 2 * p + 1], neg_one, hh, ll);
+        h[p] = hh;
+        l[p] = ll;
+      }
+      constexpr unsigned kMask = SIGNED ? 0x7fff7fffu : 0xffffffffu;
+      const short2v m01 = __builtin_elementwise_max(__builtin_bit_cast(short2v, h[0] & kMask),
+                                                    __builtin_bit_cast(short2v, h[1] & kMask));
+      const short2v m23 = __builtin_elementwise_max(__builtin_bit_cast(short2v, h[2] & kMask),
+                                                    __builtin_bit_cast(short2v, h[3] & kMask));
+      amax = __builtin_elementwise_max(amax, __builtin_elementwise_max(m01, m23));
+      o.hi[2 * tp + u][C] = __builtin_bit_cast(half8, h);
+      o.lo[2 * tp + u][C] = __builtin_bit_cast(half8, l);
+    }
+  unsigned pin = __builtin_bit_cast(unsigned, amax);  // see split_act
+  asm volatile("" : "+v"(pin));
+  amax = __builtin_bit_cast(short2v, pin);
+}
+
+template <int C, bool ADD>
+__device__ __forceinline__ void bias_half(const float* __restrict__ bl, Act<2>& acc, int h) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bl + 32 * t + 8 * g + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (ADD) acc.v[t][C][4 * g + e] += b[e];
+        else acc.v[t][C][4 * g + e] = b[e];
+      }
+    }
+}
+
+// The A fragments (weights) of fragment group g + 1 are read from LDS while group g's MFMAs
+// run; the last group of a stage reads the first group of the NEXT stage (`next`), so no stage
+// opens with an exposed LDS round trip.
+struct FragPair {
+  half8 hi, lo;
+};
+__device__ __forceinline__ FragPair load_frag(const float* __restrict__ Wl, int lane, int g) {
+  const unsigned char* base = reinterpret_cast<const unsigned char*>(Wl) + lane * 16 + g * 2048;
+  FragPair f;
+  f.hi = *reinterpret_cast<const half8*>(base);
+  f.lo = *reinterpret_cast<const half8*>(base + 1024);
+  return f;
+}
+
+template <int C>
+__device__ __forceinline__ void mfma_half(const float* __restrict__ Wl, const float* __restrict__ next,
+                                          FragPair& cur, const SplitAct<2>& in, Act<2>& acc, int lane) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int g = t * 4 + s;
+      const FragPair nxt = g < 7 ? load_frag(Wl, lane, g + 1) : load_frag(next, lane, 0);
+      acc.v[t][C] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.hi, in.hi[s][C], acc.v[t][C], 0, 0, 0);
+      acc.v[t][C] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.hi, in.lo[s][C], acc.v[t][C], 0, 0, 0);
+      acc.v[t][C] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.lo, in.hi[s][C], acc.v[t][C], 0, 0, 0);
+      cur = nxt;
+    }
+}
+
+// One region's issue order: 8 fragment groups of {2 LDS reads, 3 x (1 MFMA, VPM VALU)}.
+template <int VPM>
+__device__ __forceinline__ void pin_mfma_valu_interleave() {
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);  // VALU
+    }
+  }
+}
+
 enum Kind { kDynamics = 0, kMeasure = 1, kJacobian = 2 };
 
 struct NetArgs {
@@ -348,8 +463,9 @@ struct NetArgs {
   int* range_flag;          // f16x3: set to 1 when an activation left the f16-split range
 };
 
-template <int D, int NRES, int KIND, int CT, int PREC, int WPS>
+template <int D, int NRES, int KIND, int CT, int PREC, int WPS, bool PIPE = false>
 __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgs a) {
+  static_assert(!PIPE || (CT == 2 && PREC == MMF_PREC_F16X3 && KIND != kJacobian), "pipelined halves: f16x3, 64-particle tiles");
   constexpr int kThreads = WPS * 256;           // WPS waves per SIMD, one workgroup per CU (LDS)
   constexpr int kWavesPerBlock = kThreads / MMF_WAVE;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -428,9 +544,79 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgs a)
     }
     relu<CT, JAC>(X, primal);
 
-    // ---- encoder residual block (layers 0, 1)
     SplitAct<F16 ? CT : 0> SP;
     short2v amax = {0, 0};  // f16x3: largest hi halves handed to the MFMAs in this tile
+    if constexpr (PIPE) {
+      constexpr int NL = 3 + 2 * NRES;  // 64x64 layers: encoder block, join, NRES trunk blocks
+      FragPair frag;                    // weight fragments of the next MFMA group, in flight
+      // V(C, l): everything half C needs before layer l's MFMAs -- the ReLU that ends layer
+      // l - 1, the operand split of layer l's input, the initial value of its accumulator.
+      // Layers 0, 2, 3, 5, .. read X-or-H alternately: even position in a block reads the block
+      // input, odd position reads the hidden activation and accumulates onto the skip.
+      auto vstage = [&](auto half, auto layer) {
+        constexpr int C = decltype(half)::value;
+        constexpr int l = decltype(layer)::value;
+        const float* bl = lds + off_bias(NRES) + l * kUnits;
+        if constexpr (l == 0) {            // X (ReLU'd by the encoder's first layer) -> H = b + W X
+          split_half<C, false>(X, SP, neg_one, amax);
+          bias_half<C, false>(bl, H, h);
+        } else if constexpr (l == 1) {     // X += b + W relu(H)
+          relu_half<C>(H);
+          split_half<C, false>(H, SP, neg_one, amax);
+          bias_half<C, true>(bl, X, h);
+        } else if constexpr (l == 2) {     // join: H = traj_bias + W relu(X)
+          relu_half<C>(X);
+          split_half<C, false>(X, SP, neg_one, amax);
+          const float* tb = a.traj_bias + static_cast<size_t>(col_traj[C]) * kUnits + 4 * h;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 b = *reinterpret_cast<const f32x4*>(tb + 32 * t + 8 * g);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) H.v[t][C][4 * g + e] = b[e];
+            }
+        } else if constexpr ((l - 3) % 2 == 0) {  // trunk block, first layer: X = b + W H
+          constexpr bool kSigned = (l == 3 && KIND != kMeasure);  // no ReLU after the join (dynamics)
+          if constexpr (!kSigned) relu_half<C>(H);
+          split_half<C, kSigned>(H, SP, neg_one, amax);
+          bias_half<C, false>(bl, X, h);
+        } else {                                  // trunk block, second layer: H += b + W relu(X)
+          relu_half<C>(X);
+          split_half<C, false>(X, SP, neg_one, amax);
+          bias_half<C, true>(bl, H, h);
+        }
+      };
+      auto mstage = [&](auto half, auto layer) {
+        constexpr int C = decltype(half)::value;
+        constexpr int l = decltype(layer)::value;
+        constexpr bool to_h = (l == 0 || l == 2 || (l > 2 && (l - 3) % 2 == 1));
+        // the stage after (C, l) is (1, l) for C == 0 and (0, l + 1) for C == 1
+        constexpr int ln = (C == 0) ? l : (l + 1 < NL ? l + 1 : l);
+        mfma_half<C>(lds + off_layers() + l * kLayerFloats, lds + off_layers() + ln * kLayerFloats, frag, SP,
+                     to_h ? H : X, lane);
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      asm volatile("" ::: "memory");  // keep the LDS fragment reads inside the tile loop (see mfma_layer)
+      frag = load_frag(lds + off_layers(), lane, 0);
+      vstage(I0{}, I0{});
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<NL>([&](auto layer) {
+        constexpr int l = decltype(layer)::value;
+        mstage(I0{}, layer);
+        vstage(I1{}, layer);
+        pin_mfma_valu_interleave<5>();
+        __builtin_amdgcn_sched_barrier(0);
+        mstage(I1{}, layer);
+        if constexpr (l + 1 < NL) vstage(I0{}, std::integral_constant<int, l + 1>{});
+        else relu_half<0>(H);
+        pin_mfma_valu_interleave<5>();
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      relu_half<1>(H);
+    } else {
+    // ---- encoder residual block (layers 0, 1)
     if constexpr (F16) res_block_f16<CT>(lds, NRES, 0, X, H, SP, lane, neg_one, amax);
     else res_block<CT, JAC>(lds, NRES, 0, X, H, lane, primal);
 
@@ -466,6 +652,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgs a)
       else res_block<CT, JAC>(lds, NRES, 3 + 2 * i, H, X, lane, primal);
     }
 
+    }
     if constexpr (F16) {
       // an operand beyond the f16 range saturates the split (finite but wrong): report it
       if (a.range_flag != nullptr && (amax[0] >= kF16Saturated || amax[1] >= kF16Saturated))
@@ -563,7 +750,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgs a)
   }
 }
 
-template <int D, int NRES, int KIND, int PREC, int CT, int WPS>
+template <int D, int NRES, int KIND, int PREC, int CT, int WPS, bool PIPE = false>
 int launch_variant(const NetArgs& a, hipStream_t s) {
   const size_t lds = static_cast<size_t>(blob_floats(NRES)) * sizeof(float);
   constexpr int waves = WPS * 4, tile = 32 * CT;
@@ -571,7 +758,7 @@ int launch_variant(const NetArgs& a, hipStream_t s) {
   int grid = (ntiles + waves - 1) / waves;
   if (grid > 256) grid = 256;
   if (grid < 1) grid = 1;
-  auto k = particle_net_kernel<D, NRES, KIND, CT, PREC, WPS>;
+  auto k = particle_net_kernel<D, NRES, KIND, CT, PREC, WPS, PIPE>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   if (e != hipSuccess) return static_cast<int>(e);
@@ -588,6 +775,8 @@ int launch_ct(const NetArgs& a, hipStream_t s) {
   if constexpr (PREC == MMF_PREC_F16X3 && KIND != kJacobian) {
     if (big && variant == 1) return launch_variant<D, NRES, KIND, PREC, 1, 3>(a, s);  // 32-particle tiles, 3 waves/SIMD
     if (big && variant == 2) return launch_variant<D, NRES, KIND, PREC, 1, 2>(a, s);
+    if (big && variant == 3) return launch_variant<D, NRES, KIND, PREC, 2, 2, false>(a, s);  // unpipelined
+    if (big) return launch_variant<D, NRES, KIND, PREC, 2, 2, true>(a, s);
   }
   if (big) return launch_variant<D, NRES, KIND, PREC, 2, 2>(a, s);
   return launch_variant<D, NRES, KIND, PREC, 1, 2>(a, s);

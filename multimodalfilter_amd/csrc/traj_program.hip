@@ -71,6 +71,29 @@ __global__ __launch_bounds__(kWaves * MMF_WAVE) void traj_program_kernel(
           const float* xs = slots + I.src[s] * (kRows * kVec) + I.src_off[s];
           const int dim = I.src_dim[s];
           int k = 0;
+          // 16 k per step: all 16 (or 32) coalesced weight-row loads are issued before the first
+          // FMA, so a 64-wide source costs 4 L2 round trips instead of 16 (rows are few: the
+          // program is latency-, not throughput-bound)
+          for (; k + 16 <= dim; k += 16) {
+            float w0[16], w1[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              w0[e] = wT[(k + e) * out_pad];
+              w1[e] = wide ? wT[(k + e) * out_pad + 64] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int r = 0; r < kRows; ++r) {
+                const float4 x = *reinterpret_cast<const float4*>(xs + r * kVec + k + 4 * q);
+                acc0[r] = __fmaf_rn(w0[4 * q + 0], x.x, acc0[r]); acc0[r] = __fmaf_rn(w0[4 * q + 1], x.y, acc0[r]);
+                acc0[r] = __fmaf_rn(w0[4 * q + 2], x.z, acc0[r]); acc0[r] = __fmaf_rn(w0[4 * q + 3], x.w, acc0[r]);
+                if (wide) {
+                  acc1[r] = __fmaf_rn(w1[4 * q + 0], x.x, acc1[r]); acc1[r] = __fmaf_rn(w1[4 * q + 1], x.y, acc1[r]);
+                  acc1[r] = __fmaf_rn(w1[4 * q + 2], x.z, acc1[r]); acc1[r] = __fmaf_rn(w1[4 * q + 3], x.w, acc1[r]);
+                }
+              }
+          }
           for (; k + 4 <= dim; k += 4) {  // 4 k per step: b128 broadcast reads of the inputs
             float w0[4], w1[4];
 #pragma unroll

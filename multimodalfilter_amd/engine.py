@@ -326,7 +326,7 @@ class PackedImageEncoder:
 
 _IMAGE_WORKSPACES = {}
 _MAX_NETS = 4
-_IMAGE_CHUNK = 2048  # images per K4 launch sequence (workspace ~0.8 GB per encoder)
+_IMAGE_CHUNK = int(os.environ.get("MMF_IMAGE_CHUNK", "2048"))  # images per K4 launch sequence (workspace ~0.8 GB per encoder)
 
 
 def _image_workspace(device, n_images: int, n_nets: int) -> torch.Tensor:

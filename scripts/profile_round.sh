@@ -1,0 +1,13 @@
+# Round profile: kernel-trace stats + HBM traffic counters of the default bench (run on the GPU box)
+R=/root/repo
+OUT=$R/gpurun_out/prof_final
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 32 --warmup 4 --no-cpu-baseline --no-f32-mode > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_FETCH_SIZE -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-f32-mode > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_WRITE_SIZE -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-f32-mode > /dev/null 2>&1
+cd $R
+python bench.py > $OUT/bench_door_pf_n1.json 2> $OUT/bench.err
+python bench.py --workload push_pf > $OUT/bench_push_pf_n1.json 2>> $OUT/bench.err
+python bench.py --workload door_ekf > $OUT/bench_door_ekf_n1.json 2>> $OUT/bench.err
+find $OUT -name "*.csv" | head -20
