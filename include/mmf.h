@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 6
+#define MMF_ABI_VERSION 7
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -170,7 +170,13 @@ typedef struct MmfImageEncoderDesc {
   const float* fc_b;        /* (64) */
   const float* res_w[2];    /* ResLinear(64): block1, block2 (64,64) */
   const float* res_b[2];
+  int32_t variant;          /* MMF_ENCODER_DEFAULT, or MMF_ENCODER_SPANNING_POOL (the push virtual   */
+                            /* sensor's stack, push_models/layers.py:43-65,77-90): conv_w[4] is     */
+                            /* (2,16,3,3), then a full-height and a full-width average pool (2-wide) */
+                            /* give 64 values and fc_w is (64, 64)                                   */
 } MmfImageEncoderDesc;      /* host struct holding device pointers */
+#define MMF_ENCODER_DEFAULT 0
+#define MMF_ENCODER_SPANNING_POOL 1
 
 size_t mmf_image_encoder_floats(void);                 /* floats of one packed encoder blob */
 size_t mmf_image_encoder_workspace_bytes(int n_images, int n_nets);
@@ -182,12 +188,14 @@ int mmf_pack_image_encoder(const MmfImageEncoderDesc* desc /* host */, float* pa
  *  workspace  >= mmf_image_encoder_workspace_bytes(N, n_nets) bytes of device memory
  *  range_flag int32 on the device or null: MMF_PREC_F16X3 ORs 1 into it when an activation
  *             left the f16-split range (see mmf_pf_dynamics)
+ *  variant    MMF_ENCODER_*: the architecture every blob of this call was packed for
  *  precision  MMF_PREC_F32: every layer on the f32 MFMA.  MMF_PREC_F16X3: the four 3x3
  *             convolutions (97 % of the MACs) as split-f16 products in persistent, register-
  *             prefetching workgroups; the 5x5 stem and the linear tail stay f32.
  */
 int mmf_image_encoder(const float* const* packed, int n_nets, const float* images, float* feat,
-                      void* workspace, int32_t* range_flag, int precision, int N, void* stream);
+                      void* workspace, int32_t* range_flag, int precision, int variant, int N,
+                      void* stream);
 
 /* ---------------------------------------------------------------- particle-filter step loop
  * Replaces the Python loop of torchfilter's Filter.forward_loop (call site

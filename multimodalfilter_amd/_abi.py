@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmmf_hip.so")
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 PREC_F32, PREC_F16X3 = 0, 1
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}
 
@@ -67,7 +67,7 @@ class MmfPfLoopArgs(Structure):
 
 class MmfImageEncoderDesc(Structure):
     _fields_ = [("conv_w", _FP * 5), ("conv_b", _FP * 5), ("fc_w", _FP), ("fc_b", _FP),
-                ("res_w", _FP * 2), ("res_b", _FP * 2)]
+                ("res_w", _FP * 2), ("res_b", _FP * 2), ("variant", c_int32)]
 
 
 SIGNATURES = {
@@ -86,7 +86,7 @@ SIGNATURES = {
     "mmf_image_encoder_floats": (c_size_t, []),
     "mmf_image_encoder_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mmf_pack_image_encoder": (c_int, [POINTER(MmfImageEncoderDesc), _FP, c_void_p]),
-    "mmf_image_encoder": (c_int, [POINTER(c_void_p), c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
+    "mmf_image_encoder": (c_int, [POINTER(c_void_p), c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
 }
 
 _lib = None
@@ -217,8 +217,11 @@ def pack_image_encoder(desc: MmfImageEncoderDesc, packed: torch.Tensor):
                "mmf_pack_image_encoder")
 
 
+ENCODER_DEFAULT, ENCODER_SPANNING_POOL = 0, 1
+
+
 def image_encoder(blobs, images: torch.Tensor, feat: torch.Tensor, workspace: torch.Tensor,
-                  range_flag, precision: int):
+                  range_flag, precision: int, variant: int = ENCODER_DEFAULT):
     n = len(blobs)
     arr = (c_void_p * n)(*[ptr(b) for b in blobs])
     N = images.shape[0]
@@ -226,7 +229,7 @@ def image_encoder(blobs, images: torch.Tensor, feat: torch.Tensor, workspace: to
     with _on(images):
         _check(load().mmf_image_encoder(arr, n, ptr(images), ptr(feat),
                                         ptr(workspace, dtype=torch.uint8),
-                                        ptr(range_flag, dtype=torch.int32), precision, N,
+                                        ptr(range_flag, dtype=torch.int32), precision, variant, N,
                                         stream_of(images)),
                "mmf_image_encoder")
 

@@ -114,6 +114,10 @@ __global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ o
       {d.conv_w[0], d.conv_b[0], 1, 32, 5, L.w1, L.b1}, {d.conv_w[1], d.conv_b[1], 32, 32, 3, L.w2a, L.b2a},
       {d.conv_w[2], d.conv_b[2], 32, 32, 3, L.w2b, L.b2b}, {d.conv_w[3], d.conv_b[3], 32, 16, 3, L.w3, L.b3},
       {d.conv_w[4], d.conv_b[4], 16, 8, 3, L.w4, L.b4}};
+  // spanning-pool variant: the last convolution has 2 output channels (the other 6 of the 8-wide
+  // tile get zero weights and bias) and the linear layer is (64, 64)
+  const int cout4 = d.variant == MMF_ENCODER_SPANNING_POOL ? 2 : 8;
+  const int fc_in = d.variant == MMF_ENCODER_SPANNING_POOL ? kFeat : kFcK;
   for (int q0 = blockIdx.x * blockDim.x + threadIdx.x; q0 < L.total; q0 += gridDim.x * blockDim.x) {
     float v = 0.f;
     if (q0 < L.fcw) {
@@ -128,16 +132,17 @@ __global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ o
           const int s4 = rest % S4, mt = rest / S4;
           const int s = 4 * s4 + ksub, i = lane & 15, q = lane >> 4;
           const int co = 16 * mt + i;
+          const int cout = c == 4 ? cout4 : p.cout;
           int ci, ky, kx;
-          if (co < p.cout && kdecode(p.cin, p.ks, s, q, &ci, &ky, &kx))
+          if (co < cout && kdecode(p.cin, p.ks, s, q, &ci, &ky, &kx))
             v = p.w[((co * p.cin + ci) * p.ks + ky) * p.ks + kx];
         } else if (q0 >= p.boff && q0 < p.boff + (p.cout < 16 ? 16 : p.cout)) {
           const int co = q0 - p.boff;
-          if (co < p.cout) v = p.b[co];
+          if (co < (c == 4 ? cout4 : p.cout)) v = p.b[co];
         }
       }
     } else if (q0 < L.fcb) {
-      v = d.fc_w[q0 - L.fcw];
+      v = (q0 - L.fcw) < kFeat * fc_in ? d.fc_w[q0 - L.fcw] : 0.f;
     } else if (q0 < L.r1t) {
       v = d.fc_b[q0 - L.fcb];
     } else if (q0 < L.r1b) {  // transposed: [k][o]
@@ -153,7 +158,7 @@ __global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ o
     } else {
       // f16x3 sections: two halves per float slot
       const int offs[5] = {L.h2a, L.h2b, L.h3, L.h4, L.total};
-      const int cins[4] = {32, 32, 32, 16}, couts[4] = {32, 32, 16, 8};
+      const int cins[4] = {32, 32, 32, 16}, couts[4] = {32, 32, 16, cout4};
       int c = 0;
       while (q0 >= offs[c + 1]) ++c;
       const float* W = d.conv_w[c + 1];
@@ -553,7 +558,11 @@ __global__ __launch_bounds__(256) void fc_partial_kernel(FcArgs a) {
   }
 }
 
-// one wave per (image, net): bias + ReLU, then ResLinear(64)
+// one wave per (image, net): bias + ReLU, then ResLinear(64).  SPAN: the linear layer's input is
+// the 64 values of the two spanning average pools over the 2-channel map in `act`
+// (push_models/layers.py:43-65: pool_h = mean over all rows x 2 columns -> [c][16], pool_w = mean
+// over 2 rows x all columns -> [c][16], concatenated), computed here instead of the split-K sums.
+template <bool SPAN>
 __global__ __launch_bounds__(256) void fc_tail_kernel(FcArgs a) {
   constexpr Layout L = layout();
   const int lane = threadIdx.x & 63;
@@ -561,8 +570,23 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcArgs a) {
   if (img >= a.N) return;
   const float* blob = a.packed[net];
   float h = blob[L.fcb + lane];
-  for (int s = 0; s < kFcSplit; ++s)
-    h += a.partial[((static_cast<size_t>(net) * kFcSplit + s) * a.N + img) * kFeat + lane];
+  if (SPAN) {
+    const float* map = a.act + (static_cast<size_t>(net) * a.N + img) * kFcK;  // (8, 32, 32), channels 0-1 live
+    const int c = (lane & 31) >> 4, g = lane & 15;
+    const float* m = map + c * kImg * kImg;
+    float sum = 0.f;
+    if (lane < 32) {
+      for (int y = 0; y < kImg; ++y) sum += m[y * kImg + 2 * g] + m[y * kImg + 2 * g + 1];
+    } else {
+      for (int x = 0; x < kImg; ++x) sum += m[(2 * g) * kImg + x] + m[(2 * g + 1) * kImg + x];
+    }
+    const float pooled = sum * (1.0f / 64.0f);
+#pragma unroll 8
+    for (int k = 0; k < kFeat; ++k) h += blob[L.fcw + lane * kFeat + k] * __shfl(pooled, k);
+  } else {
+    for (int s = 0; s < kFcSplit; ++s)
+      h += a.partial[((static_cast<size_t>(net) * kFcSplit + s) * a.N + img) * kFeat + lane];
+  }
   h = fmaxf(h, 0.f);
   float t = blob[L.r1b + lane];
 #pragma unroll 8
@@ -615,10 +639,11 @@ extern "C" int mmf_pack_image_encoder(const MmfImageEncoderDesc* d, float* packe
 
 extern "C" int mmf_image_encoder(const float* const* packed, int n_nets, const float* images,
                                  float* feat, void* workspace, int32_t* range_flag, int precision,
-                                 int N, void* stream) {
+                                 int variant, int N, void* stream) {
   if (!packed || !images || !feat || !workspace) return MMF_EINVAL;
   if (n_nets < 1 || n_nets > kMaxNets || N < 0) return MMF_EINVAL;
   if (precision != MMF_PREC_F32 && precision != MMF_PREC_F16X3) return MMF_EINVAL;
+  if (variant != MMF_ENCODER_DEFAULT && variant != MMF_ENCODER_SPANNING_POOL) return MMF_EINVAL;
   if (N == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   constexpr Layout L = layout();
@@ -670,9 +695,14 @@ extern "C" int mmf_image_encoder(const float* const* packed, int n_nets, const f
   FcArgs f{};
   for (int i = 0; i < n_nets; ++i) f.packed[i] = packed[i];
   f.act = bufB; f.partial = partial; f.feat = feat; f.N = N;
+  if (variant == MMF_ENCODER_SPANNING_POOL) {
+    fc_tail_kernel<true><<<dim3((N + 3) / 4, n_nets), 256, 0, s>>>(f);
+    MMF_CHECK_LAUNCH();
+    return 0;
+  }
   fc_partial_kernel<<<dim3((N + 15) / 16, kFcSplit, n_nets), 256, 0, s>>>(f);
   MMF_CHECK_LAUNCH();
-  fc_tail_kernel<<<dim3((N + 3) / 4, n_nets), 256, 0, s>>>(f);
+  fc_tail_kernel<false><<<dim3((N + 3) / 4, n_nets), 256, 0, s>>>(f);
   MMF_CHECK_LAUNCH();
   return 0;
 }

@@ -275,17 +275,28 @@ def run_jacobian(net: PackedParticleNet, states: torch.Tensor, traj_bias: torch.
 
 
 # ------------------------------------------------------------------------------ K4 image encoders
-def _is_default_image_encoder(seq) -> bool:
-    from .layers import ResConv2d
+def _image_encoder_variant(seq):
+    """``_abi.ENCODER_*`` of an ``observation_image_layers`` stack K4 implements, else ``None``."""
+    from .layers import DualSpanningAvgPool, ResConv2d
 
     try:
-        return (len(seq) == 10 and isinstance(seq[0], nn.Conv2d) and seq[0].weight.shape == (32, 1, 5, 5)
+        if not (len(seq) == 10 and isinstance(seq[0], nn.Conv2d) and seq[0].weight.shape == (32, 1, 5, 5)
                 and isinstance(seq[2], ResConv2d) and seq[3].weight.shape == (16, 32, 3, 3)
-                and isinstance(seq[5], nn.Conv2d) and seq[5].weight.shape == (8, 16, 3, 3)
-                and isinstance(seq[7], nn.Linear) and seq[7].weight.shape == (64, 8192)
-                and isinstance(seq[9], ResLinear))
+                and isinstance(seq[5], nn.Conv2d) and isinstance(seq[7], nn.Linear)
+                and isinstance(seq[9], ResLinear)):
+            return None
+        if seq[5].weight.shape == (8, 16, 3, 3) and seq[7].weight.shape == (64, 8192):
+            return _abi.ENCODER_DEFAULT
+        if (seq[5].weight.shape == (2, 16, 3, 3) and isinstance(seq[6], DualSpanningAvgPool)
+                and seq[7].weight.shape == (64, 64)):
+            return _abi.ENCODER_SPANNING_POOL
     except (TypeError, AttributeError, IndexError):
-        return False
+        pass
+    return None
+
+
+def _is_default_image_encoder(seq) -> bool:
+    return _image_encoder_variant(seq) is not None
 
 
 class PackedImageEncoder:
@@ -293,7 +304,8 @@ class PackedImageEncoder:
     (``layers.image_encoder``), rebuilt lazily when a source parameter changes."""
 
     def __init__(self, seq: nn.Sequential):
-        assert _is_default_image_encoder(seq)
+        self.variant = _image_encoder_variant(seq)
+        assert self.variant is not None
         self.seq = seq
         self._blob = None
         self._stamp = None
@@ -318,6 +330,7 @@ class PackedImageEncoder:
             d.conv_w[i], d.conv_b[i] = P(keep[i]), P(keep[5 + i])
         d.fc_w, d.fc_b = P(keep[10]), P(keep[11])
         d.res_w[0], d.res_w[1], d.res_b[0], d.res_b[1] = P(keep[12]), P(keep[13]), P(keep[14]), P(keep[15])
+        d.variant = self.variant
         blob = torch.empty(_abi.image_encoder_floats(), dtype=torch.float32, device=src[0].device)
         _abi.pack_image_encoder(d, blob)
         self._blob, self._stamp = blob, stamp
@@ -349,18 +362,22 @@ def image_encoder_flops(n_images: int) -> float:
 
 def encode_images(encoders, images: torch.Tensor):
     """Run several image encoders on the same ``(N, 32, 32)`` batch: default stacks go
-    through K4 in one batched launch sequence, any other architecture (the push virtual
-    sensor's spanning-pool tail) through its torch module.  Returns one ``(N, 64)`` per encoder."""
+    (``door_models/layers.py:43-63``) and the push virtual sensor's spanning-pool stacks
+    (``push_models/layers.py:77-90``) go through K4, one batched launch sequence per
+    architecture; anything else runs its own torch module.  Returns one ``(N, 64)`` per encoder."""
     require_device(images, "encode_images")
     images = images.to(torch.float32).contiguous()
     N = images.shape[0]
     out = [None] * len(encoders)
-    fused = [i for i, e in enumerate(encoders) if _is_default_image_encoder(e)]
+    variants = [_image_encoder_variant(e) for e in encoders]
     for i, e in enumerate(encoders):
-        if i not in fused:
+        if variants[i] is None:  # a user-defined architecture: its own torch module
             out[i] = e(images[:, None, :, :])
-    for lo in range(0, len(fused), _MAX_NETS):
-        grp = fused[lo:lo + _MAX_NETS]
+    groups = []  # encoders of one architecture share a launch sequence, _MAX_NETS at a time
+    for v in (_abi.ENCODER_DEFAULT, _abi.ENCODER_SPANNING_POOL):
+        same = [i for i, vi in enumerate(variants) if vi == v]
+        groups += [(v, same[lo:lo + _MAX_NETS]) for lo in range(0, len(same), _MAX_NETS)]
+    for variant, grp in groups:
         packs = []
         for i in grp:
             e = encoders[i]
@@ -377,7 +394,7 @@ def encode_images(encoders, images: torch.Tensor):
             prec = _abi.PRECISIONS[DEFAULT_PRECISION]
             flag = range_flag(images.device)
             _timed("image_encoder", image_encoder_flops(n) * len(grp), 0.0,
-                   lambda: _abi.image_encoder(packs, chunk, feat, ws, flag, prec))
+                   lambda: _abi.image_encoder(packs, chunk, feat, ws, flag, prec, variant))
             for k in range(len(grp)):
                 feats[k][c0:c0 + n] = feat[k]
         for k, i in enumerate(grp):

@@ -366,6 +366,32 @@ def test_k4_image_encoders_match_oracle(N, nets):
     assert _rel_err(engine.encode_images(encs[:1], img.to(dev))[0].cpu(), want) < 1e-4
 
 
+@pytest.mark.parametrize("N", [1, 5, 64])
+def test_k4_spanning_pool_variant_and_mixed_batches(N):
+    """The push virtual sensor's stack (16->2 convolution, full-height / full-width average
+    pools, Linear 64->64; push_models/layers.py:43-65,77-90) runs in K4 too; a call mixing
+    both architectures returns each encoder's own features, and no torch module is called."""
+    from multimodalfilter_amd import engine, layers
+
+    dev = _cuda()
+    g = torch.Generator().manual_seed(7 + N)
+    img = (torch.randn((N, 32, 32), generator=g) * 0.5).clamp(-1, 1)
+    spans = [True, False, True]
+    oracles = [_seeded(om.image_encoder(64, sp), seed=20 + k) for k, sp in enumerate(spans)]
+    encs = []
+    for o, sp in zip(oracles, spans):
+        e = layers.image_encoder(64, sp)
+        e.load_state_dict(o.state_dict())
+        e.forward = None  # the torch module must not be used
+        encs.append(e.to(dev))
+    got = engine.encode_images(encs, img.to(dev))
+    for o, gk in zip(oracles, got):
+        with torch.no_grad():
+            want = o(img[:, None])
+        assert gk.shape == want.shape
+        assert _rel_err(gk.cpu(), want) < 1e-4
+
+
 @pytest.mark.parametrize("task", ["door", "push"])
 def test_k2_f16x3_error_against_fp64(task):
     """The split-f16 path vs the f32-MFMA path, both measured against an fp64 evaluation of

@@ -34,8 +34,8 @@ def _product(case_name: str, task: om.TaskSpec):
 
             return engine.encode_images([self], x[:, 0])[0]
 
-    def k4_encoder():
-        seq = layers.image_encoder(64)
+    def k4_encoder(spanning=False):
+        seq = layers.image_encoder(64, spanning)
         seq.__class__ = K4Sequential
         return seq
 
@@ -49,7 +49,7 @@ def _product(case_name: str, task: om.TaskSpec):
         "dynamics_jacobian": lambda: g("DynamicsModel")(),
         "state_encoder": lambda: layers.vector_encoder(task.state_dim, 64),
         "image_encoder": k4_encoder,
-        "image_encoder_spanning": lambda: layers.image_encoder(64, True),
+        "image_encoder_spanning": lambda: k4_encoder(True),
         "pf_weight_model": lambda: g("CrossmodalWeightModel")(know_image_blackout=False),
         "pf_weight_model_blackout": lambda: g("CrossmodalWeightModel")(know_image_blackout=True),
         "pf_crossmodal_measurement": lambda: g("CrossmodalParticleFilter")().measurement_model,
