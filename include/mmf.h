@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 7
+#define MMF_ABI_VERSION 8
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -306,6 +306,31 @@ int mmf_ekf_step(const float* A, const float* mu_pred, const float* q_tril, cons
                  const float* r_tril, const float* fuse_w, float* mu, float* Sigma,
                  float* mu_f, float* Sigma_f, int N, int d, int K, int fusion, int feedback,
                  void* stream);
+
+/* All T steps of a fused EKF in one call (host loop; replaces torchfilter's Filter.forward_loop
+ * over crossmodal_kf.py:88-151 / unimodal_kf.py:162-250): per step, mmf_dynamics_jacobian for
+ * each of the K sub-filters at its current belief mean, then mmf_ekf_step.  Step-indexed
+ * arrays are laid out (T, K, N, ...) so that step t's block is what mmf_ekf_step takes.
+ */
+typedef struct MmfEkfLoopArgs {
+  int32_t T, N, d, K;
+  int32_t fusion, feedback;  /* as mmf_ekf_step                                              */
+  int32_t n_res_dyn;
+  const float* dyn_packed[MMF_LOOP_MAX_MEAS];  /* MMF_PREC_F32 blobs of the dynamics networks   */
+  const float* dyn_bias[MMF_LOOP_MAX_MEAS];    /* (T*N, 64) hoisted control terms               */
+  const float* q_tril;       /* (K, d, d)                                                      */
+  const float* z;            /* (T, K, N, d)      virtual-sensor observations                  */
+  const float* r_tril;       /* (T, K, N, d, d)   virtual-sensor scale matrices                */
+  const float* fuse_w;       /* (T, K, N, d) crossmodal weights (fusion 1) or null             */
+  float* mu;                 /* (K, N, d)     sub-filter means, in/out                          */
+  float* Sigma;              /* (K, N, d, d)  sub-filter covariances, in/out                    */
+  float* mu_pred;            /* (K, N, d)     scratch                                           */
+  float* A;                  /* (K, N, d, d)  scratch                                           */
+  float* Sigma_f;            /* (N, d, d)     fused covariance of the last step (fusion != 0)   */
+  float* estimates;          /* (T, N, d) out: fused mean, or sub-filter 0's mean for fusion 0  */
+} MmfEkfLoopArgs;            /* host struct holding device pointers                            */
+
+int mmf_ekf_forward_loop(const MmfEkfLoopArgs* args /* host */, void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmmf_hip.so")
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 PREC_F32, PREC_F16X3 = 0, 1
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}
 
@@ -65,6 +65,15 @@ class MmfPfLoopArgs(Structure):
                 ("event_stride", c_int32)]
 
 
+class MmfEkfLoopArgs(Structure):
+    _fields_ = [("T", c_int32), ("N", c_int32), ("d", c_int32), ("K", c_int32),
+                ("fusion", c_int32), ("feedback", c_int32), ("n_res_dyn", c_int32),
+                ("dyn_packed", _FP * LOOP_MAX_MEAS), ("dyn_bias", _FP * LOOP_MAX_MEAS),
+                ("q_tril", _FP), ("z", _FP), ("r_tril", _FP), ("fuse_w", _FP),
+                ("mu", _FP), ("Sigma", _FP), ("mu_pred", _FP), ("A", _FP), ("Sigma_f", _FP),
+                ("estimates", _FP)]
+
+
 class MmfImageEncoderDesc(Structure):
     _fields_ = [("conv_w", _FP * 5), ("conv_b", _FP * 5), ("fc_w", _FP), ("fc_b", _FP),
                 ("res_w", _FP * 2), ("res_b", _FP * 2), ("variant", c_int32)]
@@ -83,6 +92,7 @@ SIGNATURES = {
     "mmf_ekf_step": (c_int, [_FP] * 10 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_forward_loop": (c_int, [POINTER(MmfPfLoopArgs), c_void_p]),
     "mmf_traj_program": (c_int, [_FP, c_int, _FP, POINTER(c_void_p), c_int, c_void_p]),
+    "mmf_ekf_forward_loop": (c_int, [POINTER(MmfEkfLoopArgs), c_void_p]),
     "mmf_image_encoder_floats": (c_size_t, []),
     "mmf_image_encoder_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mmf_pack_image_encoder": (c_int, [POINTER(MmfImageEncoderDesc), _FP, c_void_p]),
@@ -201,6 +211,12 @@ def ekf_step(A, mu_pred, q_tril, z, r_tril, fuse_w, mu, Sigma, mu_f, Sigma_f, fu
         _check(load().mmf_ekf_step(ptr(A), ptr(mu_pred), ptr(q_tril), ptr(z), ptr(r_tril),
                                    ptr(fuse_w), ptr(mu), ptr(Sigma), ptr(mu_f), ptr(Sigma_f),
                                    N, d, K, fusion, feedback, stream_of(mu_pred)), "mmf_ekf_step")
+
+
+def ekf_forward_loop(args: MmfEkfLoopArgs, like: torch.Tensor):
+    """Enqueue T fused-EKF steps (see include/mmf.h)."""
+    with _on(like):
+        _check(load().mmf_ekf_forward_loop(ctypes.byref(args), stream_of(like)), "mmf_ekf_forward_loop")
 
 
 def image_encoder_floats() -> int:

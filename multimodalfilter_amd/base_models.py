@@ -14,6 +14,7 @@ fusion arithmetic in HIP.
 Reference quirks that change numbers are preserved and flag-gated.
 """
 import abc
+import ctypes
 from typing import List, Optional
 
 import numpy as np
@@ -261,17 +262,69 @@ class _FusedKalmanFilters(base.Filter, _EnabledModels):
         outs = [None if m is None else call_with_image_feat(m, feats[i], observations=flat)
                 for i, m in enumerate(sensors)]
         raw = call_with_image_feat(wm.raw_weights, feats[-1], observations=flat) if batched_w else None
+        w_all = wm.finish_weights_steps(raw, T) if batched_w and hasattr(wm, "finish_weights_steps") else None
         encs = []
         for t in range(T):
             sl = slice(t * N, (t + 1) * N)
             if wm is None:
                 w = None
+            elif w_all is not None:
+                w = w_all[t]
             elif batched_w:
                 w = wm.finish_weights(raw[sl])
             else:
                 w = wm(observations=tree_index(observations, t))
             encs.append({"sensor": [None if o is None else (o[0][sl], o[1][sl]) for o in outs], "weights": w})
+        self._loop_sensor_outputs = outs  # (T*N, ...) blocks, for the native step loop
         return encs
+
+    def _native_plan(self, encs, T, N):
+        """``(fusion, feedback, fuse_w (T, K, N, d) | None)`` for ``mmf_ekf_forward_loop``, or
+        ``None`` when this filter's step is not a plain K5 + K3 sequence."""
+        return None
+
+    def _native_loop(self, encs, ctrl_all, T, N):
+        """All ``T`` steps through ``mmf_ekf_forward_loop`` (one C call); ``None`` -> Python loop."""
+        plan = self._native_plan(encs, T, N)
+        live_idx = [i for i, on in enumerate(self._enabled_models) if on]
+        live = [self.filter_models[i] for i in live_idx]
+        if plan is None or T == 0 or len(live) > _abi.LOOP_MAX_MEAS:
+            return None
+        dyns = [f.dynamics_model for f in live]
+        if not all(hasattr(m, "_net") and hasattr(m, "predict_with_jacobian") for m in dyns):
+            return None
+        if any(ctrl_all[i] is None for i in live_idx) or len({m._net.n_res for m in dyns}) != 1:
+            return None
+        fusion, feedback, fuse_w = plan
+        outs = self._loop_sensor_outputs
+        d, K = self.state_dim, len(live)
+        dev = live[0]._belief_mean.device
+        for f in live:
+            assert f._initialized, "Kalman filter not initialized!"
+        f32 = lambda x: x.to(torch.float32)
+        z = torch.stack([f32(outs[i][0]).view(T, N, d) for i in live_idx], dim=1).contiguous()
+        r = torch.stack([f32(outs[i][1]).view(T, N, d, d) for i in live_idx], dim=1).contiguous()
+        mu = torch.stack([f._belief_mean for f in live]).contiguous()
+        Sigma = torch.stack([f._belief_covariance for f in live]).contiguous()
+        q = torch.stack([m.scale_tril() for m in dyns]).to(torch.float32).contiguous()
+        mu_pred, A = torch.empty_like(mu), torch.empty_like(Sigma)
+        Sigma_f = torch.empty((N, d, d), dtype=torch.float32, device=dev)
+        est = torch.empty((T, N, d), dtype=torch.float32, device=dev)
+        blobs = [m._net.blob(_abi.PREC_F32) for m in dyns]
+        biases = [ctrl_all[i]["bias"] for i in live_idx]
+        fw = None if fuse_w is None else f32(fuse_w).contiguous()
+        P = lambda t: None if t is None else ctypes.c_void_p(_abi.ptr(t))
+        a = _abi.MmfEkfLoopArgs()
+        a.T, a.N, a.d, a.K, a.fusion, a.feedback = T, N, d, K, fusion, feedback
+        a.n_res_dyn = dyns[0]._net.n_res
+        for k in range(K):
+            a.dyn_packed[k], a.dyn_bias[k] = P(blobs[k]), P(biases[k])
+        a.q_tril, a.z, a.r_tril, a.fuse_w = P(q), P(z), P(r), P(fw)
+        a.mu, a.Sigma, a.mu_pred, a.A, a.Sigma_f, a.estimates = P(mu), P(Sigma), P(mu_pred), P(A), P(Sigma_f), P(est)
+        _abi.ekf_forward_loop(a, mu)
+        for k, f in enumerate(live):
+            f._belief_mean, f._belief_covariance = mu[k], Sigma[k]
+        return est, (Sigma_f if fusion else None)
 
     def forward_loop(self, *, observations, controls):
         """Sensors, fusion weights and control encoders do not depend on the belief: they are
@@ -283,6 +336,9 @@ class _FusedKalmanFilters(base.Filter, _EnabledModels):
             encs = self._encode_loop(observations, T, N)
             flat = tree_map(controls, lambda x: x.reshape((T * N,) + tuple(x.shape[2:])))
             ctrl_all = self._encode_controls(flat)
+            native = self._native_loop(encs, ctrl_all, T, N)
+            if native is not None:
+                return self._after_native_loop(*native)
             out = []
             for t in range(T):
                 sl = slice(t * N, (t + 1) * N)
@@ -320,6 +376,18 @@ class CrossmodalKalmanFilter(_FusedKalmanFilters):
         w = w[on]
         assert w.shape == (np.sum(on), N, self.state_dim)
         return w
+
+    def _native_plan(self, encs, T, N):
+        dev = self.filter_models[0]._belief_mean.device
+        w = torch.stack([self._state_weights(e["weights"], N, dev) for e in encs])
+        return 1, (1 if self.feedback == "belief" else 0), w
+
+    def _after_native_loop(self, estimates, Sigma_f):
+        self.weighted_covariances = Sigma_f
+        for f in self.filter_models:  # inert attributes, exactly as the reference sets them
+            f.states_prev = estimates[-1]
+            f.states_covariance_prev = Sigma_f
+        return estimates
 
     def _forward_encoded(self, observations, controls, enc, ctrl):
         N = tree_leading_shape(controls)[0]
@@ -395,6 +463,12 @@ class UnimodalKalmanFilter(_FusedKalmanFilters):
         prec = torch.inverse(covs + 1e-9)
         Sigma = torch.inverse(torch.sum(prec, dim=0) + 1e-9)
         return (Sigma @ torch.sum(prec @ means[..., None], dim=0)).squeeze(-1)
+
+    def _native_plan(self, encs, T, N):
+        return (0 if np.sum(self._enabled_models) == 1 else 2), 0, None
+
+    def _after_native_loop(self, estimates, Sigma_f):
+        return estimates
 
     def _forward_encoded(self, observations, controls, enc, ctrl):
         if np.sum(self._enabled_models) == 1:

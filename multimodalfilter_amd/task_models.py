@@ -495,6 +495,15 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
                 w = output.reshape(self.modality_count, N, self.state_dim)
             return w / (torch.sum(w, dim=0) + 1e-9)
 
+        def finish_weights_steps(self, output, T):
+            """``finish_weights`` of ``T`` consecutive steps' rows ``(T*N, 2d)`` -> ``(T, 2, N, d)``."""
+            N = output.shape[0] // T
+            if self.fix_weight_layout:
+                w = output.view(T, N, self.modality_count, self.state_dim).permute(0, 2, 1, 3)
+            else:  # the per-step reshape of an (N, 2d) block is a row-major reinterpretation
+                w = output.view(T, self.modality_count, N, self.state_dim)
+            return w / (torch.sum(w, dim=1, keepdim=True) + 1e-9)
+
         def forward(self, *, observations, image_feat=None):
             return self.finish_weights(self.raw_weights(observations=observations, image_feat=image_feat))
 
@@ -545,6 +554,10 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             mu, Sigma = self.calculate_weighted_states(w, means, covs)
             self.weighted_covariances = Sigma
             return mu
+
+        def _native_plan(self, encs, T, N):
+            # the blackout branch is chosen per step by a batch-global test on the data (Q2)
+            return None if self.know_image_blackout else super()._native_plan(encs, T, N)
 
         def _forward_encoded(self, observations, controls, enc, ctrl):
             if not self.know_image_blackout:

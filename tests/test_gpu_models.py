@@ -276,3 +276,53 @@ def test_native_step_loop_equals_stepwise(resample, T):
     # the belief stays usable for further single steps
     f.noise = mmf.StackedNoise(None, eps[:1], us[:1])
     f(observations={k: v[0] for k, v in obs.items()}, controls=ctrl[0])
+
+
+@pytest.mark.parametrize("cls,kw,masked", [
+    ("DoorCrossmodalKalmanFilter", {}, False),
+    ("DoorCrossmodalKalmanFilter", {"feedback": "belief", "fix_weight_layout": True}, False),
+    ("PushCrossmodalKalmanFilter", {}, True),
+    ("DoorUnimodalKalmanFilter", {}, False),
+    ("PushUnimodalKalmanFilter", {}, True),
+])
+def test_native_ekf_loop_equals_stepwise(cls, kw, masked):
+    """``mmf_ekf_forward_loop`` (C host loop over K5 + K3) against T separate ``forward``
+    calls: estimates, sub-filter beliefs and the fused covariance are identical bits."""
+    _need_gpu()
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import _abi
+
+    dev = torch.device("cuda:0")
+    tname = "door" if cls.startswith("Door") else "push"
+    d, N, T = om.TASKS[tname].state_dim, 7, 5
+    g = torch.Generator().manual_seed(31)
+    obs = {"image": (torch.randn((T, N, 32, 32), generator=g) * 0.5).clamp(-1, 1).to(dev),
+           "gripper_pos": torch.randn((T, N, 3), generator=g).to(dev),
+           "gripper_sensors": torch.randn((T, N, 7), generator=g).to(dev)}
+    ctrl = torch.randn((T, N, 7), generator=g).to(dev)
+    x0 = torch.randn((N, d), generator=g).to(dev)
+    cov = (torch.eye(d) * 0.1)[None].expand(N, d, d).to(dev)
+    f = mmf.model_types(tname)[cls](**kw).to(dev).eval()
+    if masked:
+        f.enabled_models = [False, True]
+
+    f.initialize_beliefs(mean=x0, covariance=cov)
+    step = torch.stack([f(observations={k: v[t] for k, v in obs.items()}, controls=ctrl[t]) for t in range(T)])
+    beliefs = [(m._belief_mean.clone(), m._belief_covariance.clone()) for m in f.filter_models]
+    wc = None if f.weighted_covariances is None else f.weighted_covariances.clone()
+
+    calls = []
+    real = _abi.ekf_forward_loop
+    _abi.ekf_forward_loop = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        f.initialize_beliefs(mean=x0, covariance=cov)
+        loop = f.forward_loop(observations=obs, controls=ctrl)
+    finally:
+        _abi.ekf_forward_loop = real
+    assert calls, "fused Kalman filters must take the native step loop"
+    assert torch.equal(loop, step)
+    for m, (mu, S) in zip(f.filter_models, beliefs):
+        if m._initialized:
+            assert torch.equal(m._belief_mean, mu) and torch.equal(m._belief_covariance, S)
+    if wc is not None:
+        assert torch.equal(f.weighted_covariances, wc)
