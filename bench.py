@@ -34,8 +34,10 @@ PREC_CODE = {"f32": 0, "f16x3": 1}
 
 
 def k2_kernel_name(d: int, prec: str) -> str:
-    """<D, NRES, KIND=measure, CT=2 (64-particle tiles), PREC, WPS=2 waves/SIMD>"""
-    return f"particle_net_kernel<{d}, 2, 1, 2, {PREC_CODE[prec]}, 2>"
+    """<D, NRES, KIND=measure, CT=2 (64-particle tiles), PREC, WPS=2 waves/SIMD, PIPE (f16x3:
+    the two 32-particle halves run half a layer apart)>"""
+    pipe = "true" if prec == "f16x3" and os.environ.get("MMF_K2_VARIANT", "0") == "0" else "false"
+    return f"particle_net_kernel<{d}, 2, 1, 2, {PREC_CODE[prec]}, 2, {pipe}>"
 
 WORKLOADS = {
     "door_pf": dict(task="door", cls="DoorCrossmodalParticleFilter", kind="pf", batch=256, particles=4096,

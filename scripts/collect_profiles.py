@@ -1,0 +1,84 @@
+"""Copy the judged summaries of a `scripts/profile_round.sh` run from gpurun_out/ into profiles/<round>/.
+
+    python scripts/collect_profiles.py gpurun_out/prof_final profiles/r01
+
+Keeps: rocprofv3 kernel stats / domain stats, the kernel-trace and PMC rows of this repo's
+kernels, the per-kernel HBM traffic derived from the two PMC passes (FETCH_SIZE doubled as
+MI355X_MICROARCH.md prescribes for gfx950), and the bench JSON lines.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+OURS = ("particle_net_kernel", "pf_reweight_resample_kernel", "ekf_step_kernel", "conv_kernel",
+        "conv_f16x3_kernel", "fc_partial_kernel", "fc_tail_kernel", "traj_program_kernel",
+        "pack_particle_net_kernel", "pack_encoder_kernel")
+
+
+def short(name: str) -> str:
+    name = re.sub(r"^void ", "", name)
+    name = name.replace("(anonymous namespace)::", "")
+    return re.sub(r"\(.*$", "", name).strip()
+
+
+def one(pattern):
+    hits = glob.glob(pattern, recursive=True)
+    if not hits:
+        raise SystemExit(f"missing {pattern}")
+    return hits[0]
+
+
+def main(src, dst):
+    os.makedirs(dst, exist_ok=True)
+    shutil.copy(one(f"{src}/stats/**/*_kernel_stats.csv"), f"{dst}/door_pf_kernel_stats.csv")
+    shutil.copy(one(f"{src}/stats/**/*_domain_stats.csv"), f"{dst}/door_pf_domain_stats.csv")
+    with open(one(f"{src}/stats/**/*_kernel_trace.csv")) as fh, open(f"{dst}/door_pf_kernel_trace_mmf_kernels.csv", "w") as out:
+        rd = csv.reader(fh)
+        wr = csv.writer(out)
+        header = next(rd)
+        wr.writerow(header)
+        col = header.index("Kernel_Name")
+        for row in rd:
+            if any(k in row[col] for k in OURS):
+                wr.writerow(row)
+    per = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with open(one(f"{src}/pmc_{counter}/**/*_counter_collection.csv")) as fh, \
+                open(f"{dst}/pmc_{counter}_mmf_kernels.csv", "w") as out:
+            rd = csv.DictReader(fh)
+            wr = csv.DictWriter(out, fieldnames=rd.fieldnames)
+            wr.writeheader()
+            for row in rd:
+                if any(k in row["Kernel_Name"] for k in OURS) and row["Counter_Name"] == counter:
+                    wr.writerow(row)
+                    per.setdefault(short(row["Kernel_Name"]), {}).setdefault(counter, []).append(float(row["Counter_Value"]))
+    kernels = {}
+    for name, c in sorted(per.items()):
+        if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+            continue
+        f = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
+        w = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
+        kernels[name] = {"FETCH_SIZE": f, "launches_FETCH_SIZE": len(c["FETCH_SIZE"]),
+                         "WRITE_SIZE": w, "launches_WRITE_SIZE": len(c["WRITE_SIZE"]),
+                         "hbm_bytes_raw": (f + w) * 1024.0, "hbm_bytes_corrected": (2.0 * f + w) * 1024.0}
+    with open(f"{dst}/pmc_hbm_traffic.json", "w") as fh:
+        json.dump({
+            "workload": "door crossmodal PF, N=256, M=4096 (bench.py default, f16x3), 1x MI355X",
+            "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- python3 bench.py "
+                       "--steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-f32-mode (one counter per pass)",
+            "unit": "KB per launch (rocprofv3 derived metric), averaged over the launches of the run",
+            "note": "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide coalesced streaming "
+                    "read; 'hbm_bytes_corrected' doubles FETCH_SIZE. Image-encoder and K7 kernels: launches over the "
+                    "warm-up (256 images) and the timed chunk (1024 images) are averaged together.",
+            "kernels": kernels}, fh, indent=1)
+    for f in glob.glob(f"{src}/bench_*.json") + glob.glob(f"{src}/pytest_*.txt"):
+        shutil.copy(f, dst)
+    print("kept", sorted(os.listdir(dst)))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

@@ -11,3 +11,8 @@ python bench.py > $OUT/bench_door_pf_n1.json 2> $OUT/bench.err
 python bench.py --workload push_pf > $OUT/bench_push_pf_n1.json 2>> $OUT/bench.err
 python bench.py --workload door_ekf > $OUT/bench_door_ekf_n1.json 2>> $OUT/bench.err
 find $OUT -name "*.csv" | head -20
+# other SURVEY 8d configurations, for the record (C2: door PF N=256 M=1024; C3: push PF N=1024 M=4096; reference-sized eval)
+python bench.py --workload door_pf --particles 1024 --no-f32-mode --no-cpu-baseline > $OUT/bench_c2_door_pf_n256_m1024.json 2>> $OUT/bench.err
+python bench.py --workload push_pf --batch 1024 --steps 64 --no-f32-mode --no-cpu-baseline > $OUT/bench_c3_push_pf_n1024_m4096.json 2>> $OUT/bench.err
+python bench.py --workload door_pf --batch 32 --particles 300 --steps 200 --no-f32-mode > $OUT/bench_door_pf_n32_m300.json 2>> $OUT/bench.err
+MMF_PRECISION=f32 python -m pytest tests -m gpu -x -q 2>&1 | tail -2 > $OUT/pytest_gpu_f32_mode.txt
