@@ -384,16 +384,48 @@ class VirtualSensorExtendedKalmanFilter(base.Filter):
             return self._step_autograd(observations, controls)
         return self._step(observations, controls)
 
+    def _native_loop(self, observations, ctrl_all, T, N, flat):
+        """All ``T`` steps through ``mmf_ekf_forward_loop`` (K = 1, no fusion) when the virtual
+        sensor is row-wise (so it can be evaluated on the ``T*N`` flattened rows at once) and
+        the dynamics model is a fused network; ``None`` -> Python loop."""
+        dyn, vs = self.dynamics_model, self.virtual_sensor_model
+        if ctrl_all is None or T == 0 or not hasattr(dyn, "_net") or not getattr(vs, "row_wise", False):
+            return None
+        assert self._initialized, "Kalman filter not initialized!"
+        d = self.state_dim
+        z, r = vs(observations=tree_map(observations, flat))
+        z = z.to(torch.float32).reshape(T, 1, N, d).contiguous()
+        r = r.to(torch.float32).reshape(T, 1, N, d, d).contiguous()
+        mu = self._belief_mean.reshape(1, N, d).contiguous().clone()
+        Sigma = self._belief_covariance.reshape(1, N, d, d).contiguous().clone()
+        q = dyn.scale_tril().to(torch.float32).reshape(1, d, d).contiguous()
+        mu_pred, A = torch.empty_like(mu), torch.empty_like(Sigma)
+        est = torch.empty((T, N, d), dtype=torch.float32, device=mu.device)
+        blob = dyn._net.blob(_abi.PREC_F32)
+        P = lambda t: ctypes.c_void_p(_abi.ptr(t))
+        a = _abi.MmfEkfLoopArgs()
+        a.T, a.N, a.d, a.K, a.fusion, a.feedback = T, N, d, 1, 0, 0
+        a.n_res_dyn = dyn._net.n_res
+        a.dyn_packed[0], a.dyn_bias[0] = P(blob), P(ctrl_all["bias"])
+        a.q_tril, a.z, a.r_tril = P(q), P(z), P(r)
+        a.mu, a.Sigma, a.mu_pred, a.A, a.estimates = P(mu), P(Sigma), P(mu_pred), P(A), P(est)
+        _abi.ekf_forward_loop(a, mu)
+        self._belief_mean, self._belief_covariance = mu[0], Sigma[0]
+        return est
+
     def forward_loop(self, *, observations, controls):
         if use_autograd(self):
             return base.Filter.forward_loop(self, observations=observations, controls=controls)
         T, N = tree_leading_shape(controls)[:2]
         flat = lambda t: t.reshape((T * N,) + tuple(t.shape[2:]))
         with torch.no_grad():
-            sensors = [self.virtual_sensor_model(observations=tree_index(observations, t)) for t in range(T)]
             ctrl_all = None
             if hasattr(self.dynamics_model, "predict_with_jacobian"):
                 ctrl_all = self.dynamics_model.encode_controls(tree_map(controls, flat))
+            native = self._native_loop(observations, ctrl_all, T, N, flat)
+            if native is not None:
+                return native
+            sensors = [self.virtual_sensor_model(observations=tree_index(observations, t)) for t in range(T)]
         out = []
         for t in range(T):
             sl = slice(t * N, (t + 1) * N)

@@ -369,6 +369,8 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
         """obs -> ``(z, sqrt(diag(r)^2 + 1e-6 I))`` (``door_models/kf.py:31-126``;
         ``push_models/kf.py:31-128``)."""
 
+        row_wise = True  # no coupling between trajectories: a forward_loop may evaluate T*N rows at once
+
         def __init__(self, units: int = 64, modalities: Set[str] = {"image", "pos", "sensors"},
                      add_R_noise: float = 1e-6, noise_R_tril: torch.Tensor = None):
             super().__init__(state_dim=D)

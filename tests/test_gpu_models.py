@@ -279,6 +279,8 @@ def test_native_step_loop_equals_stepwise(resample, T):
 
 
 @pytest.mark.parametrize("cls,kw,masked", [
+    ("DoorKalmanFilter", {}, False),
+    ("PushKalmanFilter", {}, False),
     ("DoorCrossmodalKalmanFilter", {}, False),
     ("DoorCrossmodalKalmanFilter", {"feedback": "belief", "fix_weight_layout": True}, False),
     ("PushCrossmodalKalmanFilter", {}, True),
@@ -308,8 +310,10 @@ def test_native_ekf_loop_equals_stepwise(cls, kw, masked):
 
     f.initialize_beliefs(mean=x0, covariance=cov)
     step = torch.stack([f(observations={k: v[t] for k, v in obs.items()}, controls=ctrl[t]) for t in range(T)])
-    beliefs = [(m._belief_mean.clone(), m._belief_covariance.clone()) for m in f.filter_models]
-    wc = None if f.weighted_covariances is None else f.weighted_covariances.clone()
+    subs = list(f.filter_models) if hasattr(f, "filter_models") else [f]
+    beliefs = [(m._belief_mean.clone(), m._belief_covariance.clone()) for m in subs]
+    wc = getattr(f, "weighted_covariances", None)
+    wc = None if wc is None else wc.clone()
 
     calls = []
     real = _abi.ekf_forward_loop
@@ -321,7 +325,7 @@ def test_native_ekf_loop_equals_stepwise(cls, kw, masked):
         _abi.ekf_forward_loop = real
     assert calls, "fused Kalman filters must take the native step loop"
     assert torch.equal(loop, step)
-    for m, (mu, S) in zip(f.filter_models, beliefs):
+    for m, (mu, S) in zip(subs, beliefs):
         if m._initialized:
             assert torch.equal(m._belief_mean, mu) and torch.equal(m._belief_covariance, S)
     if wc is not None:
