@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 8
+#define MMF_ABI_VERSION 9
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -155,6 +155,30 @@ int mmf_pf_measure(const float* packed, int n_res, int precision, const float* s
 int mmf_dynamics_jacobian(const float* packed, int n_res, const float* states_in,
                           const float* traj_bias, float* states_out, float* jac, int N, int d,
                           void* stream);
+
+/* ---------------------------------------------------------------- K6: training through the per-particle networks
+ * Replaces autograd through DoorDynamicsModel*.forward / DoorMeasurementModel.forward over N*M
+ * rows (door_models/dynamics.py:102-134, door_models/pf.py:63-107; callers train_helpers.py via
+ * torchfilter.train.*).  Exact fp32 (MMF_PREC_F32 blobs).
+ *
+ * forward:  out (R, NOUT) = head(network(states, traj_bias)) including the head bias, BEFORE the
+ *           gate / noise / log-weight epilogue of mmf_pf_dynamics / mmf_pf_measure (NOUT = d + 1
+ *           for kind 0 = dynamics, 1 for kind 1 = measurement), and
+ *           stash (NL + 1, R, 64), NL = 3 + 2 n_res: [l] = input of 64x64 layer l, [NL] = head input.
+ * backward: packed_t is a blob packed from the TRANSPOSED 64x64 layer weights (the state part of
+ *           the join layer as a (64, 64) matrix; biases / first layer / head are ignored);
+ *           head_w (NOUT, 64).  Writes dz (NL + 1, R, 64): [l] = gradient w.r.t. layer l's
+ *           pre-activation output, [NL] = w.r.t. the first (d -> 64) layer's pre-activation.
+ * Every reduction over particles is then a GEMM / column sum over the two stashes:
+ *   dW_l = dz[l]^T stash[l], db_l = sum_rows dz[l], d traj_bias[n] = sum_m dz[2][n, m],
+ *   dW_in = dz[NL]^T [states, 1], d states = dz[NL] W_in, dW_head = d_out^T stash[NL].
+ */
+int mmf_particle_net_train_forward(const float* packed, int n_res, int kind, const float* states,
+                                   const float* traj_bias, float* stash, float* out, int N, int M,
+                                   int d, void* stream);
+int mmf_particle_net_train_backward(const float* packed_t, const float* head_w, int n_res, int kind,
+                                    const float* stash, const float* d_out, float* dz, int R, int d,
+                                    void* stream);
 
 /* ---------------------------------------------------------------- K4: image encoder
  * Replaces observation_image_layers (crossmodal/door_models/layers.py:43-63;

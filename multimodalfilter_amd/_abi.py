@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmmf_hip.so")
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 8
+ABI_VERSION = 9
 PREC_F32, PREC_F16X3 = 0, 1
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}
 
@@ -93,6 +93,8 @@ SIGNATURES = {
     "mmf_pf_forward_loop": (c_int, [POINTER(MmfPfLoopArgs), c_void_p]),
     "mmf_traj_program": (c_int, [_FP, c_int, _FP, POINTER(c_void_p), c_int, c_void_p]),
     "mmf_ekf_forward_loop": (c_int, [POINTER(MmfEkfLoopArgs), c_void_p]),
+    "mmf_particle_net_train_forward": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
+    "mmf_particle_net_train_backward": (c_int, [_FP, _FP, c_int, c_int, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_image_encoder_floats": (c_size_t, []),
     "mmf_image_encoder_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mmf_pack_image_encoder": (c_int, [POINTER(MmfImageEncoderDesc), _FP, c_void_p]),
@@ -211,6 +213,20 @@ def ekf_step(A, mu_pred, q_tril, z, r_tril, fuse_w, mu, Sigma, mu_f, Sigma_f, fu
         _check(load().mmf_ekf_step(ptr(A), ptr(mu_pred), ptr(q_tril), ptr(z), ptr(r_tril),
                                    ptr(fuse_w), ptr(mu), ptr(Sigma), ptr(mu_f), ptr(Sigma_f),
                                    N, d, K, fusion, feedback, stream_of(mu_pred)), "mmf_ekf_step")
+
+
+def particle_net_train_forward(packed, n_res: int, kind: int, states, traj_bias, stash, out, N: int, M: int, d: int):
+    with _on(states):
+        _check(load().mmf_particle_net_train_forward(ptr(packed), n_res, kind, ptr(states), ptr(traj_bias),
+                                                     ptr(stash), ptr(out), N, M, d, stream_of(states)),
+               "mmf_particle_net_train_forward")
+
+
+def particle_net_train_backward(packed_t, head_w, n_res: int, kind: int, stash, d_out, dz, R: int, d: int):
+    with _on(stash):
+        _check(load().mmf_particle_net_train_backward(ptr(packed_t), ptr(head_w), n_res, kind, ptr(stash),
+                                                      ptr(d_out), ptr(dz), R, d, stream_of(stash)),
+               "mmf_particle_net_train_backward")
 
 
 def ekf_forward_loop(args: MmfEkfLoopArgs, like: torch.Tensor):

@@ -22,7 +22,7 @@ OBJ = os.path.join(CSRC, "_obj")
 
 
 def _headers():
-    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     files.append(os.path.join(os.path.dirname(HERE), "include", "mmf.h"))
     files.append(os.path.abspath(__file__))
     return files

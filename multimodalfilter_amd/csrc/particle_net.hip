@@ -866,3 +866,5 @@ extern "C" int mmf_dynamics_jacobian(const float* packed, int n_res, const float
   a.states_out = states_out; a.jac = jac; a.R = 4 * N; a.M = 4;
   return launch<kJacobian>(a, d, n_res, MMF_PREC_F32, static_cast<hipStream_t>(stream));
 }
+
+#include "particle_net_train.inc"

@@ -226,6 +226,98 @@ class PackedParticleNet:
         return blob
 
 
+def _transposed_blob(net: PackedParticleNet) -> torch.Tensor:
+    """Blob of the TRANSPOSED 64x64 layers (K6 backward data path: ``dx = W^T dz`` is a forward
+    layer with ``W^T``); cached like the forward blobs."""
+    src = net._sources()
+    stamp = tuple((t.data_ptr(), t._version, str(t.device)) for t in src)
+    cached = net._blobs.get("transposed")
+    if cached is not None and cached[0] == stamp:
+        return cached[1]
+    dev = src[0].device
+    f32 = lambda t: t.detach().to(torch.float32)
+    T = lambda t: f32(t).t().contiguous()
+    zeros = torch.zeros(_abi.MMF_UNITS, dtype=torch.float32, device=dev)
+    off = net.join_state_off
+    keep = [f32(src[0]).contiguous(), f32(src[1]).contiguous(), T(src[2]), T(src[4]),
+            f32(src[6])[:, off:off + _abi.MMF_UNITS].t().contiguous()]
+    for i in range(net.n_res):
+        keep += [T(src[7 + 4 * i]), T(src[9 + 4 * i])]
+    keep += [f32(src[-2]).contiguous(), f32(src[-1]).contiguous(), zeros]
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    d = _abi.MmfParticleNetDesc()
+    d.d_in, d.n_res, d.relu_after_join, d.n_out = net.d_in, net.n_res, int(net.relu_after_join), net.n_out
+    d.join_in, d.join_state_off = _abi.MMF_UNITS, 0
+    d.w_in, d.b_in = P(keep[0]), P(keep[1])
+    d.w_enc[0], d.b_enc[0], d.w_enc[1], d.b_enc[1] = P(keep[2]), P(zeros), P(keep[3]), P(zeros)
+    d.w_join = P(keep[4])
+    for i in range(2 * net.n_res):
+        d.w_res[i], d.b_res[i] = P(keep[5 + i]), P(zeros)
+    d.w_head, d.b_head = P(keep[-3]), P(keep[-2])
+    blob = torch.empty(_abi.particle_net_floats(net.n_res), dtype=torch.float32, device=dev)
+    _abi.pack_particle_net(d, blob, _abi.PREC_F32)
+    net._blobs["transposed"] = (stamp, blob)
+    return blob
+
+
+class ParticleNetFunction(torch.autograd.Function):
+    """K6: differentiable evaluation of a per-particle network on ``N*M`` rows.
+
+    ``apply(net, kind, N, M, states (R, d), traj_bias (N, 64), *net._sources())`` returns the
+    head outputs ``(R, n_out)`` (bias included, before the gate / log-weight epilogue).  The
+    forward kernel stashes every layer's input; the backward kernel runs the transposed
+    residual network over the masks and writes the pre-activation gradients; the reductions
+    over particles (weight, bias, per-trajectory-bias and state gradients) are GEMMs over the
+    two stashes.  Exact fp32 (f32 MFMA)."""
+
+    @staticmethod
+    def forward(ctx, net, kind, N, M, states, traj_bias, *params):
+        require_device(states, "ParticleNetFunction")
+        R, d = states.shape
+        assert R == N * M and traj_bias.shape == (N, _abi.MMF_UNITS)
+        NL = 3 + 2 * net.n_res
+        st = states.detach().to(torch.float32).contiguous()
+        tb = traj_bias.detach().to(torch.float32).contiguous()
+        stash = torch.empty((NL + 1, R, _abi.MMF_UNITS), dtype=torch.float32, device=states.device)
+        out = torch.empty((R, net.n_out), dtype=torch.float32, device=states.device)
+        _abi.particle_net_train_forward(net.blob(_abi.PREC_F32), net.n_res, kind, st, tb, stash, out, N, M, d)
+        ctx.net, ctx.kind, ctx.N, ctx.M = net, kind, N, M
+        ctx.save_for_backward(st, stash, *[p.detach() for p in params])
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        net, kind, N, M = ctx.net, ctx.kind, ctx.N, ctx.M
+        st, stash, *params = ctx.saved_tensors
+        R, d = st.shape
+        NL = 3 + 2 * net.n_res
+        d_out = d_out.to(torch.float32).contiguous()
+        head_w = params[-2].to(torch.float32).contiguous()
+        dz = torch.empty_like(stash)
+        _abi.particle_net_train_backward(_transposed_blob(net), head_w, net.n_res, kind, stash, d_out, dz, R, d)
+        grads = [None] * len(params)
+        w_in = params[0].to(torch.float32)
+        grads[0] = dz[NL].t() @ st                      # first layer (64, d)
+        grads[1] = dz[NL].sum(0)
+        d_states = dz[NL] @ w_in
+        for layer, (wi, bi) in ((0, (2, 3)), (1, (4, 5))):  # encoder residual block
+            grads[wi] = dz[layer].t() @ stash[layer]
+            grads[bi] = dz[layer].sum(0)
+        gj = torch.zeros_like(params[6], dtype=torch.float32)  # join: only the state columns are ours
+        off = net.join_state_off
+        gj[:, off:off + _abi.MMF_UNITS] = dz[2].t() @ stash[2]
+        grads[6] = gj
+        d_traj_bias = dz[2].view(N, M, _abi.MMF_UNITS).sum(1)
+        for i in range(net.n_res):
+            for k in range(2):
+                layer = 3 + 2 * i + k
+                grads[7 + 4 * i + 2 * k] = dz[layer].t() @ stash[layer]
+                grads[8 + 4 * i + 2 * k] = dz[layer].sum(0)
+        grads[-2] = d_out.t() @ stash[NL]
+        grads[-1] = d_out.sum(0)
+        return (None, None, None, None, d_states, d_traj_bias, *grads)
+
+
 def run_dynamics(net: PackedParticleNet, states: torch.Tensor, traj_bias: torch.Tensor,
                  noise, scale_tril, out: torch.Tensor = None) -> torch.Tensor:
     """``states`` ``(N, M, d)`` or ``(R, d)`` with ``traj_bias`` ``(N, 64)``."""

@@ -113,3 +113,59 @@ def test_eval_mode_stays_on_the_hip_path(autograd_backend):
     out = f(observations={"image": torch.zeros((2, 32, 32), device=dev), "gripper_pos": torch.zeros((2, 3), device=dev),
                           "gripper_sensors": torch.zeros((2, 7), device=dev)}, controls=torch.zeros((2, 7), device=dev))
     assert not out.requires_grad and f.particle_states.shape == (2, 300, 3)
+
+
+@pytest.mark.parametrize("task,kind", [("door", "dynamics"), ("door", "measure"), ("push", "dynamics"), ("push", "measure")])
+@pytest.mark.parametrize("N,M", [(3, 40), (2, 64), (5, 7)])
+def test_k6_particle_net_function_matches_autograd(task, kind, N, M):
+    """K6: head outputs and every gradient (states, per-trajectory bias, all weights and biases)
+    of ``engine.ParticleNetFunction`` against torch autograd through the same layers (fp64
+    reference), 1e-4 relative."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine
+
+    dev = torch.device("cuda:0")
+    assert torch.cuda.is_available()
+    ns = mmf.door_models if task == "door" else mmf.push_models
+    P = task.capitalize()
+    torch.manual_seed(N * 100 + M)
+    if kind == "dynamics":
+        model = ns.DoorDynamicsModelBrent() if task == "door" else getattr(ns, P + "DynamicsModel")()
+    else:
+        model = getattr(ns, P + "MeasurementModel")(modalities={"pos", "sensors"})
+    model.to(dev)
+    net = model._net
+    d = net.d_in
+    R = N * M
+    g = torch.Generator().manual_seed(5)
+    states = torch.randn((R, d), generator=g).to(dev).requires_grad_(True)
+    tbias = torch.randn((N, 64), generator=g).to(dev).requires_grad_(True)
+    gout = torch.randn((R, net.n_out), generator=g).to(dev)
+    params = net._sources()
+    out = engine.ParticleNetFunction.apply(net, 0 if kind == "dynamics" else 1, N, M, states, tbias, *params)
+    got = torch.autograd.grad(out, [states, tbias] + params, gout)
+
+    # reference: the same network in fp64 torch ops
+    p64 = [p.detach().double().requires_grad_(True) for p in params]
+    s64 = states.detach().double().requires_grad_(True)
+    t64 = tbias.detach().double().requires_grad_(True)
+    relu = torch.relu
+    a = relu(s64 @ p64[0].t() + p64[1])
+    a = relu(a + relu(a @ p64[2].t() + p64[3]) @ p64[4].t() + p64[5])
+    off = net.join_state_off
+    jn = a @ p64[6][:, off:off + 64].t() + t64.repeat_interleave(M, dim=0)
+    a = relu(jn) if net.relu_after_join else jn
+    for i in range(net.n_res):
+        w1, b1, w2, b2 = p64[7 + 4 * i: 11 + 4 * i]
+        a = relu(a + relu(a @ w1.t() + b1) @ w2.t() + b2)
+    want_out = a @ p64[-2].t() + p64[-1]
+    want = torch.autograd.grad(want_out, [s64, t64] + p64, gout.double())
+
+    def rel(x, y):
+            return float((x.detach().double() - y.detach()).abs().max()) / max(1e-6, float(y.detach().abs().max()))
+
+    assert rel(out, want_out) < 1e-4
+    names = ["states", "traj_bias"] + [f"param{i}" for i in range(len(params))]
+    for n, x, y in zip(names, got, want):
+        assert x.shape == y.shape, n
+        assert rel(x, y) < 1e-4, f"{n}: {rel(x, y):.2e}"
