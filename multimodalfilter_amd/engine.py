@@ -128,13 +128,21 @@ TRAINING_BACKEND = os.environ.get("MMF_TRAINING_BACKEND") or None
 
 
 def set_training_backend(name):
+    """``None``: forward-only HIP path everywhere.  ``"autograd"``: modules in ``train()`` mode
+    evaluate through differentiable torch ops.  ``"hip"``: as ``"autograd"``, but the per-particle
+    networks (the ``N*M``-row work) go through ``ParticleNetFunction`` (K6: HIP forward with
+    stash + HIP backward data path)."""
     global TRAINING_BACKEND
-    assert name in (None, "autograd"), name
+    assert name in (None, "autograd", "hip"), name
     TRAINING_BACKEND = name
 
 
 def use_autograd(module: nn.Module) -> bool:
-    return TRAINING_BACKEND == "autograd" and module.training and torch.is_grad_enabled()
+    return TRAINING_BACKEND in ("autograd", "hip") and module.training and torch.is_grad_enabled()
+
+
+def use_hip_backward() -> bool:
+    return TRAINING_BACKEND == "hip"
 
 
 _RANGE_FLAGS = {}

@@ -172,11 +172,17 @@ class ParticleFilter(base.Filter):
         assert self._initialized, "Particle filter not initialized!"
         N, M, d = self.particle_states.shape
         do_resample = (not self.training) if self.resample is None else bool(self.resample)
-        flat = self.particle_states.reshape(N * M, d)
-        rep = tree_map(controls, lambda t: torch.repeat_interleave(t, repeats=M, dim=0))
-        pred, tril = self.dynamics_model(initial_states=flat, controls=rep)
-        eps = self.noise.gaussian((N, M, d), like=pred).reshape(N * M, d)
-        states = (pred + torch.einsum("rij,rj->ri", tril, eps)).reshape(N, M, d)
+        if engine.use_hip_backward() and hasattr(self.dynamics_model, "forward_particles"):
+            # K6: the N*M-row network evaluates and differentiates in HIP
+            pred = self.dynamics_model.forward_particles(states=self.particle_states, controls=controls)
+            eps = self.noise.gaussian((N, M, d), like=pred)
+            states = pred + eps @ self.dynamics_model.scale_tril().t()
+        else:
+            flat = self.particle_states.reshape(N * M, d)
+            rep = tree_map(controls, lambda t: torch.repeat_interleave(t, repeats=M, dim=0))
+            pred, tril = self.dynamics_model(initial_states=flat, controls=rep)
+            eps = self.noise.gaussian((N, M, d), like=pred).reshape(N * M, d)
+            states = (pred + torch.einsum("rij,rj->ri", tril, eps)).reshape(N, M, d)
         logw = self.particle_log_weights + self.measurement_model(states=states, observations=observations)
         logw = logw - torch.logsumexp(logw, dim=1, keepdim=True)
         if self.estimation_method == "weighted_average":

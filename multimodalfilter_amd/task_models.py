@@ -179,6 +179,17 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             mu_pred, A = engine.run_jacobian(self._net, mean, ctx["bias"])
             return mu_pred, A, self.scale_tril().contiguous()
 
+        def forward_particles(self, *, states, controls):
+            """Differentiable one-step prediction (no noise) of ``(N, M, d)`` particles under
+            per-trajectory ``controls (N, 7)`` with the ``N*M``-row work in HIP (K6): the control
+            encoder and the control half of the join layer stay torch ops on ``N`` rows."""
+            N, M, d = states.shape
+            join = self.shared_layers[0]
+            bias = self.control_layers(controls) @ join.weight[:, :self.units].t() + join.bias
+            flat = states.reshape(N * M, d)
+            out = engine.ParticleNetFunction.apply(self._net, 0, N, M, flat, bias, *self._net._sources())
+            return (flat + out[:, :d] * torch.sigmoid(out[:, d:])).reshape(N, M, d)
+
         def forward(self, *, initial_states, controls):
             N, state_dim = initial_states.shape[:2]
             assert state_dim == self.state_dim
@@ -261,6 +272,16 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             assert type(observations) == dict
             assert len(states.shape) == 3  # (N, M, state_dim)
             assert states.shape[2] == self.state_dim
+            if engine.use_autograd(self) and engine.use_hip_backward():
+                # K6: observation encoders and the observation half of the join layer are torch
+                # ops on N rows; the per-particle network runs (and differentiates) in HIP
+                N, M, d = states.shape
+                obs = self.observation_features_autograd(observations)
+                join = self.shared_layers[0]
+                bias = obs @ join.weight[:, :obs.shape[1]].t() + join.bias
+                out = engine.ParticleNetFunction.apply(self._net, 1, N, M, states.reshape(N * M, d), bias,
+                                                       *self._net._sources())
+                return out[:, 0].reshape(N, M)
             if engine.use_autograd(self):
                 N, M, _ = states.shape
                 obs = self.observation_features_autograd(observations)

@@ -19,6 +19,16 @@ def autograd_backend():
     engine.set_training_backend(None)
 
 
+@pytest.fixture(params=["autograd", "hip"])
+def training_backend(request):
+    """"autograd": torch ops throughout; "hip": per-particle networks through K6."""
+    from multimodalfilter_amd import engine
+
+    engine.set_training_backend(request.param)
+    yield request.param
+    engine.set_training_backend(None)
+
+
 def _data(task, T, N, seed):
     g = torch.Generator().manual_seed(seed)
     d = task.state_dim
@@ -48,8 +58,12 @@ def _compare_grads(oracle, engine_model, loss_o, loss_e):
 
 @pytest.mark.parametrize("tname,cls,kind", [("door", "DoorCrossmodalParticleFilter", "crossmodal"),
                                             ("push", "PushUnimodalParticleFilter", "unimodal")])
-def test_particle_filter_training_step_matches_oracle(autograd_backend, tname, cls, kind):
+def test_particle_filter_training_step_matches_oracle(training_backend, tname, cls, kind):
     import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine
+
+    calls = []
+    real = engine.ParticleNetFunction.apply
 
     dev = torch.device("cuda:0")
     task = om.TASKS[tname]
@@ -72,8 +86,14 @@ def test_particle_filter_training_step_matches_oracle(autograd_backend, tname, c
     assert eng.num_particles == 30
     eng.noise = mmf.ReplayNoise([eps0] + eps, [])
     eng.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
-    pred = eng.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
+    engine.ParticleNetFunction.apply = lambda *a: (calls.append(1), real(*a))[1]
+    try:
+        pred = eng.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
+    finally:
+        engine.ParticleNetFunction.apply = real
     assert pred.requires_grad
+    # "hip": dynamics + every enabled measurement network, each step, went through K6
+    assert (len(calls) >= 2 * T) == (training_backend == "hip")
     loss_e = torch.mean((pred - target.to(dev)) ** 2)
     _compare_grads(oracle, eng, loss_o, loss_e)
 
@@ -162,7 +182,7 @@ def test_k6_particle_net_function_matches_autograd(task, kind, N, M):
     want = torch.autograd.grad(want_out, [s64, t64] + p64, gout.double())
 
     def rel(x, y):
-            return float((x.detach().double() - y.detach()).abs().max()) / max(1e-6, float(y.detach().abs().max()))
+        return float((x.detach().double() - y.detach()).abs().max()) / max(1e-6, float(y.detach().abs().max()))
 
     assert rel(out, want_out) < 1e-4
     names = ["states", "traj_bias"] + [f"param{i}" for i in range(len(params))]
