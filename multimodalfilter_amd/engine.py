@@ -304,23 +304,26 @@ class ParticleNetFunction(torch.autograd.Function):
         dz = torch.empty_like(stash)
         _abi.particle_net_train_backward(_transposed_blob(net), head_w, net.n_res, kind, stash, d_out, dz, R, d)
         grads = [None] * len(params)
+        U = _abi.MMF_UNITS
+        # every reduction over the R particles in two batched launches: dW_l = dz_l^T stash_l for
+        # all layers at once (slot NL pairs unrelated tensors and is ignored), db_l = column sums
+        dW = torch.bmm(dz.transpose(1, 2), stash)        # (NL + 1, 64, 64)
+        db = dz.sum(1)                                   # (NL + 1, 64)
         w_in = params[0].to(torch.float32)
-        grads[0] = dz[NL].t() @ st                      # first layer (64, d)
-        grads[1] = dz[NL].sum(0)
+        grads[0] = dz[NL].t() @ st                       # first layer (64, d)
+        grads[1] = db[NL]
         d_states = dz[NL] @ w_in
-        for layer, (wi, bi) in ((0, (2, 3)), (1, (4, 5))):  # encoder residual block
-            grads[wi] = dz[layer].t() @ stash[layer]
-            grads[bi] = dz[layer].sum(0)
+        grads[2], grads[3], grads[4], grads[5] = dW[0], db[0], dW[1], db[1]  # encoder residual block
         gj = torch.zeros_like(params[6], dtype=torch.float32)  # join: only the state columns are ours
         off = net.join_state_off
-        gj[:, off:off + _abi.MMF_UNITS] = dz[2].t() @ stash[2]
+        gj[:, off:off + U] = dW[2]
         grads[6] = gj
-        d_traj_bias = dz[2].view(N, M, _abi.MMF_UNITS).sum(1)
+        d_traj_bias = dz[2].view(N, M, U).sum(1)
         for i in range(net.n_res):
             for k in range(2):
                 layer = 3 + 2 * i + k
-                grads[7 + 4 * i + 2 * k] = dz[layer].t() @ stash[layer]
-                grads[8 + 4 * i + 2 * k] = dz[layer].sum(0)
+                grads[7 + 4 * i + 2 * k] = dW[layer]
+                grads[8 + 4 * i + 2 * k] = db[layer]
         grads[-2] = d_out.t() @ stash[NL]
         grads[-1] = d_out.sum(0)
         return (None, None, None, None, d_states, d_traj_bias, *grads)

@@ -16,3 +16,5 @@ python bench.py --workload door_pf --particles 1024 --no-f32-mode --no-cpu-basel
 python bench.py --workload push_pf --batch 1024 --steps 64 --no-f32-mode --no-cpu-baseline > $OUT/bench_c3_push_pf_n1024_m4096.json 2>> $OUT/bench.err
 python bench.py --workload door_pf --batch 32 --particles 300 --steps 200 --no-f32-mode > $OUT/bench_door_pf_n32_m300.json 2>> $OUT/bench.err
 MMF_PRECISION=f32 python -m pytest tests -m gpu -x -q 2>&1 | tail -2 > $OUT/pytest_gpu_f32_mode.txt
+# training step (K6 vs torch autograd), SURVEY 8d config C5 shape scaled to N*M = 2^18 per step
+python scripts/bench_train.py > $OUT/bench_train_push_unimodal_pf.json 2>> $OUT/bench.err
