@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 9
+#define MMF_ABI_VERSION 11
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -168,17 +168,26 @@ int mmf_dynamics_jacobian(const float* packed, int n_res, const float* states_in
  * backward: packed_t is a blob packed from the TRANSPOSED 64x64 layer weights (the state part of
  *           the join layer as a (64, 64) matrix; biases / first layer / head are ignored);
  *           head_w (NOUT, 64).  Writes dz (NL + 1, R, 64): [l] = gradient w.r.t. layer l's
- *           pre-activation output, [NL] = w.r.t. the first (d -> 64) layer's pre-activation.
+ *           pre-activation output, [NL] = w.r.t. the first (d -> 64) layer's pre-activation,
+ *           and d_states (R, d) = dz[NL] W_in (W_in is read from packed_t's first-layer section,
+ *           which must hold the untransposed (64, d) weight).
  * Every reduction over particles is then a GEMM / column sum over the two stashes:
  *   dW_l = dz[l]^T stash[l], db_l = sum_rows dz[l], d traj_bias[n] = sum_m dz[2][n, m],
- *   dW_in = dz[NL]^T [states, 1], d states = dz[NL] W_in, dW_head = d_out^T stash[NL].
+ *   dW_in = dz[NL]^T [states, 1], dW_head = d_out^T stash[NL].
  */
 int mmf_particle_net_train_forward(const float* packed, int n_res, int kind, const float* states,
                                    const float* traj_bias, float* stash, float* out, int N, int M,
                                    int d, void* stream);
 int mmf_particle_net_train_backward(const float* packed_t, const float* head_w, int n_res, int kind,
-                                    const float* stash, const float* d_out, float* dz, int R, int d,
-                                    void* stream);
+                                    const float* stash, const float* d_out, float* dz, float* d_states,
+                                    int R, int d, void* stream);
+
+/* dW_l = dz[l]^T stash[l] and db_l = column sums of dz[l] for l < n_layers, as per-slice partial
+ * sums: partial_w (n_layers, n_splits, 64, 64), partial_b (n_layers, n_splits, 64); the caller
+ * adds the n_splits slices (no float atomics).  dz, stash: (>= n_layers, R, 64).
+ */
+int mmf_particle_net_weight_grads(const float* dz, const float* stash, float* partial_w,
+                                  float* partial_b, int n_layers, int R, int n_splits, void* stream);
 
 /* ---------------------------------------------------------------- K4: image encoder
  * Replaces observation_image_layers (crossmodal/door_models/layers.py:43-63;

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmmf_hip.so")
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 9
+ABI_VERSION = 11
 PREC_F32, PREC_F16X3 = 0, 1
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}
 
@@ -94,7 +94,8 @@ SIGNATURES = {
     "mmf_traj_program": (c_int, [_FP, c_int, _FP, POINTER(c_void_p), c_int, c_void_p]),
     "mmf_ekf_forward_loop": (c_int, [POINTER(MmfEkfLoopArgs), c_void_p]),
     "mmf_particle_net_train_forward": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
-    "mmf_particle_net_train_backward": (c_int, [_FP, _FP, c_int, c_int, _FP, _FP, _FP, c_int, c_int, c_void_p]),
+    "mmf_particle_net_weight_grads": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
+    "mmf_particle_net_train_backward": (c_int, [_FP, _FP, c_int, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_image_encoder_floats": (c_size_t, []),
     "mmf_image_encoder_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mmf_pack_image_encoder": (c_int, [POINTER(MmfImageEncoderDesc), _FP, c_void_p]),
@@ -222,11 +223,18 @@ def particle_net_train_forward(packed, n_res: int, kind: int, states, traj_bias,
                "mmf_particle_net_train_forward")
 
 
-def particle_net_train_backward(packed_t, head_w, n_res: int, kind: int, stash, d_out, dz, R: int, d: int):
+def particle_net_train_backward(packed_t, head_w, n_res: int, kind: int, stash, d_out, dz, d_states, R: int, d: int):
     with _on(stash):
         _check(load().mmf_particle_net_train_backward(ptr(packed_t), ptr(head_w), n_res, kind, ptr(stash),
-                                                      ptr(d_out), ptr(dz), R, d, stream_of(stash)),
+                                                      ptr(d_out), ptr(dz), ptr(d_states), R, d, stream_of(stash)),
                "mmf_particle_net_train_backward")
+
+
+def particle_net_weight_grads(dz, stash, partial_w, partial_b, n_layers: int, R: int, n_splits: int):
+    with _on(dz):
+        _check(load().mmf_particle_net_weight_grads(ptr(dz), ptr(stash), ptr(partial_w), ptr(partial_b),
+                                                    n_layers, R, n_splits, stream_of(dz)),
+               "mmf_particle_net_weight_grads")
 
 
 def ekf_forward_loop(args: MmfEkfLoopArgs, like: torch.Tensor):

@@ -302,17 +302,23 @@ class ParticleNetFunction(torch.autograd.Function):
         d_out = d_out.to(torch.float32).contiguous()
         head_w = params[-2].to(torch.float32).contiguous()
         dz = torch.empty_like(stash)
-        _abi.particle_net_train_backward(_transposed_blob(net), head_w, net.n_res, kind, stash, d_out, dz, R, d)
+        d_states = torch.empty_like(st)
+        _abi.particle_net_train_backward(_transposed_blob(net), head_w, net.n_res, kind, stash, d_out, dz,
+                                         d_states, R, d)
         grads = [None] * len(params)
         U = _abi.MMF_UNITS
-        # every reduction over the R particles in two batched launches: dW_l = dz_l^T stash_l for
-        # all layers at once (slot NL pairs unrelated tensors and is ignored), db_l = column sums
-        dW = torch.bmm(dz.transpose(1, 2), stash)        # (NL + 1, 64, 64)
-        db = dz.sum(1)                                   # (NL + 1, 64)
-        w_in = params[0].to(torch.float32)
-        grads[0] = dz[NL].t() @ st                       # first layer (64, d)
+        # every reduction over the R particles of the 64x64 layers in one launch: dW_l = dz_l^T
+        # stash_l and db_l = column sums, as per-slice partials (slot NL of dW pairs unrelated
+        # tensors and is ignored; its db is the first layer's bias gradient)
+        S = max(1, min(256, R // 512))
+        pw = torch.empty((NL + 1, S, U, U), dtype=torch.float32, device=st.device)
+        pb = torch.empty((NL + 1, S, U), dtype=torch.float32, device=st.device)
+        _abi.particle_net_weight_grads(dz, stash, pw, pb, NL + 1, R, S)
+        dW, db = pw.sum(1), pb.sum(1)                    # (NL + 1, 64, 64), (NL + 1, 64)
+        # (64 x R) @ (R x d) and (n_out x R) @ (R x 64) with d, n_out <= 4 are column-scaled sums;
+        # as GEMMs they are the library's worst shapes (0.6-2 ms each at R = 262k)
+        grads[0] = torch.stack([(dz[NL] * st[:, i:i + 1]).sum(0) for i in range(d)], dim=1)  # first layer (64, d)
         grads[1] = db[NL]
-        d_states = dz[NL] @ w_in
         grads[2], grads[3], grads[4], grads[5] = dW[0], db[0], dW[1], db[1]  # encoder residual block
         gj = torch.zeros_like(params[6], dtype=torch.float32)  # join: only the state columns are ours
         off = net.join_state_off
@@ -324,7 +330,7 @@ class ParticleNetFunction(torch.autograd.Function):
                 layer = 3 + 2 * i + k
                 grads[7 + 4 * i + 2 * k] = dW[layer]
                 grads[8 + 4 * i + 2 * k] = db[layer]
-        grads[-2] = d_out.t() @ stash[NL]
+        grads[-2] = torch.stack([(stash[NL] * d_out[:, o:o + 1]).sum(0) for o in range(d_out.shape[1])], dim=0)
         grads[-1] = d_out.sum(0)
         return (None, None, None, None, d_states, d_traj_bias, *grads)
 

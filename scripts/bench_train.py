@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--length", type=int, default=16)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--model", default="PushUnimodalParticleFilter")
+    ap.add_argument("--backends", default="hip,autograd")
     args = ap.parse_args()
 
     import multimodalfilter_amd as mmf
@@ -35,7 +36,7 @@ def main():
     N, M, L = args.batch, args.particles, args.length
     batch = {k: v.to(dev) for k, v in synthetic.make_trajectories(state_dim=d, T=L - 1, N=N, seed=11).items()}
     cov = torch.eye(d, device=dev) * 0.1
-    for backend in ("hip", "autograd"):
+    for backend in args.backends.split(","):
         torch.manual_seed(0)
         f = mmf.model_types(task)[args.model]().to(dev).train()
         f.num_particles = M
