@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_train -- python3 /root/repo/scripts/bench_train.py --steps 1 --backends hip > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_train -- python3 /root/repo/scripts/bench_train.py --steps 4 --backends hip > /dev/null 2>&1
 cd /root/repo
 python3 - <<'PY'
 import csv, glob
