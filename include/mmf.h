@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 11
+#define MMF_ABI_VERSION 12
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -74,6 +74,14 @@ int mmf_pf_reweight_resample(const float* loglik, const float* logw_in, const fl
                              int d, int mode, void* stream);
 
 /* Dynamic LDS bytes K1 will request for (M, mode) -- for occupancy planning / tests. */
+/* Belief initialisation (replaces torchfilter's ParticleFilter.initialize_beliefs; call site
+ * eval_helpers.py:125-131): states[n][m] = mean[n] + chol(covariance[n]) eps[n][m], logw = -log M.
+ *  mean (N, d), covariance (N, d, d), eps (N, M, d) standard normal -> states (N, M, d), logw (N, M)
+ *  not_pd   device int32 or null: OR-ed with 1 when a covariance is not positive definite
+ */
+int mmf_pf_init_particles(const float* mean, const float* covariance, const float* eps, float* states,
+                          float* logw, int32_t* not_pd, int N, int M, int d, void* stream);
+
 size_t mmf_pf_reweight_resample_lds_bytes(int M, int mode);
 
 /* ---------------------------------------------------------------- K2: per-particle networks

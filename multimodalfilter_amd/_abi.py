@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmmf_hip.so")
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 11
+ABI_VERSION = 12
 PREC_F32, PREC_F16X3 = 0, 1
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}
 
@@ -90,6 +90,7 @@ SIGNATURES = {
     "mmf_pf_measure": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, c_int, _FP, c_int, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_dynamics_jacobian": (c_int, [_FP, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_ekf_step": (c_int, [_FP] * 10 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmf_pf_init_particles": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_forward_loop": (c_int, [POINTER(MmfPfLoopArgs), c_void_p]),
     "mmf_traj_program": (c_int, [_FP, c_int, _FP, POINTER(c_void_p), c_int, c_void_p]),
     "mmf_ekf_forward_loop": (c_int, [POINTER(MmfEkfLoopArgs), c_void_p]),
@@ -281,6 +282,14 @@ def traj_program(prog: torch.Tensor, n_instr: int, weights: torch.Tensor, io_ten
     with _on(weights):
         _check(load().mmf_traj_program(ptr(prog, dtype=torch.uint8), n_instr, ptr(weights), arr, R,
                                        stream_of(weights)), "mmf_traj_program")
+
+
+def pf_init_particles(mean, covariance, eps, states, logw, not_pd):
+    N, M, d = eps.shape
+    with _on(eps):
+        _check(load().mmf_pf_init_particles(ptr(mean), ptr(covariance), ptr(eps), ptr(states), ptr(logw),
+                                            ptr(not_pd, dtype=torch.int32), N, M, d, stream_of(eps)),
+               "mmf_pf_init_particles")
 
 
 def pf_forward_loop(args: MmfPfLoopArgs, like: torch.Tensor, events=None, event_stride: int = 1) -> int:

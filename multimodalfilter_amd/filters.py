@@ -69,9 +69,21 @@ class ParticleFilter(base.Filter):
         require_device(mean, "ParticleFilter.initialize_beliefs")
         M = self.num_particles
         eps = self.noise.gaussian((N, M, d), like=mean)
-        L = torch.linalg.cholesky(covariance.to(torch.float32))
-        self.particle_states = (mean[:, None, :] + torch.einsum("nij,nmj->nmi", L, eps)).contiguous()
-        self.particle_log_weights = mean.new_full((N, M), -math.log(M))
+        if use_autograd(self) and (mean.requires_grad or covariance.requires_grad):
+            # differentiable initialisation (training): torch ops
+            L = torch.linalg.cholesky(covariance.to(torch.float32))
+            self.particle_states = (mean[:, None, :] + torch.einsum("nij,nmj->nmi", L, eps)).contiguous()
+            self.particle_log_weights = mean.new_full((N, M), -math.log(M))
+        else:
+            states = torch.empty((N, M, d), dtype=torch.float32, device=mean.device)
+            logw = torch.empty((N, M), dtype=torch.float32, device=mean.device)
+            not_pd = torch.zeros(1, dtype=torch.int32, device=mean.device)
+            _abi.pf_init_particles(mean.detach().to(torch.float32).contiguous(),
+                                   covariance.detach().to(torch.float32).contiguous(),
+                                   eps.to(torch.float32).contiguous(), states, logw, not_pd)
+            if int(not_pd.item()):
+                raise ValueError("initialize_beliefs: covariance is not positive definite")
+            self.particle_states, self.particle_log_weights = states, logw
         self._spare_states = None
         self._initialized = True
 

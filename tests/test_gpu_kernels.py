@@ -539,3 +539,32 @@ def test_k4_k7_rows_do_not_depend_on_batch_position():
     big = run(xs)
     for r in range(37):
         assert torch.equal(run(xs[r:r + 1]), big[r:r + 1]), r
+
+
+@pytest.mark.parametrize("d", [2, 3])
+@pytest.mark.parametrize("N,M", [(1, 1), (5, 300), (3, 4096)])
+def test_pf_init_particles_matches_cholesky_sampling(N, M, d):
+    """``mmf_pf_init_particles`` against ``mean + cholesky(cov) eps`` (torch, CPU fp32) on full
+    (non-diagonal) covariances; uniform log-weights; a non-PD covariance raises."""
+    import math
+
+    import multimodalfilter_amd as mmf
+
+    dev = _cuda()
+    g = torch.Generator().manual_seed(N * 7 + M + d)
+    A = torch.randn((N, d, d), generator=g)
+    cov = A @ A.transpose(-1, -2) + 0.1 * torch.eye(d)
+    mean = torch.randn((N, d), generator=g)
+    eps = torch.randn((N, M, d), generator=g)
+    want = mean[:, None, :] + torch.einsum("nij,nmj->nmi", torch.linalg.cholesky(cov), eps)
+    f = (mmf.door_models.DoorParticleFilter() if d == 3 else mmf.push_models.PushParticleFilter()).to(dev).eval()
+    f.num_particles = M
+    f.noise = mmf.ReplayNoise([eps], [])
+    f.initialize_beliefs(mean=mean.to(dev), covariance=cov.to(dev))
+    assert _rel_err(f.particle_states.cpu(), want) < 1e-5
+    assert torch.equal(f.particle_log_weights.cpu(), torch.full((N, M), -math.log(M), dtype=torch.float32))
+    bad = cov.clone()
+    bad[0] = -torch.eye(d)
+    f.noise = mmf.ReplayNoise([eps], [])
+    with pytest.raises(ValueError):
+        f.initialize_beliefs(mean=mean.to(dev), covariance=bad.to(dev))
