@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 12
+#define MMF_ABI_VERSION 13
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -347,6 +347,13 @@ int mmf_ekf_step(const float* A, const float* mu_pred, const float* q_tril, cons
                  const float* r_tril, const float* fuse_w, float* mu, float* Sigma,
                  float* mu_f, float* Sigma_f, int N, int d, int K, int fusion, int feedback,
                  void* stream);
+
+/* R11: fusion of K virtual sensors before a single EKF (crossmodal_kf.py:291-359 mode 1;
+ * unimodal_kf.py:56-115 mode 2, quirk Q5 preserved: see csrc/ekf.hip).
+ *  z (K, N, d), tril (K, N, d, d), w (K, N, d) (mode 1) -> z_out (N, d), tril_out (N, d, d)
+ */
+int mmf_fuse_virtual_sensors(const float* z, const float* tril, const float* w, float* z_out,
+                             float* tril_out, int N, int d, int K, int mode, void* stream);
 
 /* All T steps of a fused EKF in one call (host loop; replaces torchfilter's Filter.forward_loop
  * over crossmodal_kf.py:88-151 / unimodal_kf.py:162-250): per step, mmf_dynamics_jacobian for

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmmf_hip.so")
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 12
+ABI_VERSION = 13
 PREC_F32, PREC_F16X3 = 0, 1
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}
 
@@ -93,6 +93,7 @@ SIGNATURES = {
     "mmf_pf_init_particles": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_forward_loop": (c_int, [POINTER(MmfPfLoopArgs), c_void_p]),
     "mmf_traj_program": (c_int, [_FP, c_int, _FP, POINTER(c_void_p), c_int, c_void_p]),
+    "mmf_fuse_virtual_sensors": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_ekf_forward_loop": (c_int, [POINTER(MmfEkfLoopArgs), c_void_p]),
     "mmf_particle_net_train_forward": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_particle_net_weight_grads": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
@@ -236,6 +237,13 @@ def particle_net_weight_grads(dz, stash, partial_w, partial_b, n_layers: int, R:
         _check(load().mmf_particle_net_weight_grads(ptr(dz), ptr(stash), ptr(partial_w), ptr(partial_b),
                                                     n_layers, R, n_splits, stream_of(dz)),
                "mmf_particle_net_weight_grads")
+
+
+def fuse_virtual_sensors(z, tril, w, z_out, tril_out, mode: int):
+    K, N, d = z.shape
+    with _on(z):
+        _check(load().mmf_fuse_virtual_sensors(ptr(z), ptr(tril), ptr(w), ptr(z_out), ptr(tril_out), N, d, K, mode,
+                                               stream_of(z)), "mmf_fuse_virtual_sensors")
 
 
 def ekf_forward_loop(args: MmfEkfLoopArgs, like: torch.Tensor):

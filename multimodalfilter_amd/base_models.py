@@ -479,6 +479,16 @@ class UnimodalKalmanFilter(_FusedKalmanFilters):
 
 
 # ===================================================================== fused virtual sensors
+def _fuse_sensors(means, trils, w, *, mode: int):
+    """R11 algebra in one launch (``mmf_fuse_virtual_sensors``)."""
+    K, N, d = means.shape
+    f32 = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+    z_out = torch.empty((N, d), dtype=torch.float32, device=means.device)
+    t_out = torch.empty((N, d, d), dtype=torch.float32, device=means.device)
+    _abi.fuse_virtual_sensors(f32(means), f32(trils), f32(w), z_out, t_out, mode)
+    return z_out, t_out
+
+
 class CrossmodalVirtualSensorModel(base.VirtualSensorModel, _EnabledModels):
     """``base_models/crossmodal_kf.py:243-359``: fuse K virtual sensors *before* one EKF;
     ``Sigma = (prod_k prod_i w_ki) sum_k Sigma_k``; returns a Cholesky factor."""
@@ -498,7 +508,6 @@ class CrossmodalVirtualSensorModel(base.VirtualSensorModel, _EnabledModels):
         outs = [m(observations=observations) for i, m in enumerate(self.virtual_sensor_model) if on[i]]
         means = torch.stack([x[0] for x in outs])
         trils = torch.stack([x[1] for x in outs])
-        covs = trils @ trils.transpose(-1, -2)
         N = means.shape[1]
         if np.sum(on) < len(on):
             w = torch.tensor(on, dtype=torch.float32, device=means.device)
@@ -507,6 +516,9 @@ class CrossmodalVirtualSensorModel(base.VirtualSensorModel, _EnabledModels):
             w = self.crossmodal_weight_model(observations=observations)
         w = w[on]
         assert w.shape == (np.sum(on), N, self.state_dim)
+        if not use_autograd(self):
+            return _fuse_sensors(means, trils, w, mode=1)
+        covs = trils @ trils.transpose(-1, -2)
         mu = weighted_average(means, w)
         mult = torch.prod(torch.prod(w, dim=-1), dim=0).unsqueeze(-1).unsqueeze(-1)
         assert mult.shape == (N, 1, 1)
@@ -531,6 +543,8 @@ class UnimodalVirtualSensorModel(base.VirtualSensorModel, _EnabledModels):
         outs = [m(observations=observations) for i, m in enumerate(self.virtual_sensor_model) if on[i]]
         means = torch.stack([x[0] for x in outs])
         trils = torch.stack([x[1] for x in outs])
+        if not use_autograd(self):
+            return _fuse_sensors(means, trils, None, mode=2)
         if np.sum(on) == 1:
             return means[0], (trils @ trils.transpose(-1, -2))[0]
         prec = 1.0 / (trils + 1e-9)

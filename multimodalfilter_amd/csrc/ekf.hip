@@ -258,7 +258,112 @@ __global__ __launch_bounds__(256) void ekf_step_kernel(
   }
 }
 
+// R11: fusion of K virtual sensors BEFORE a single EKF, one trajectory per lane.
+//   mode 1  /root/reference/crossmodal/base_models/crossmodal_kf.py:291-359
+//           mu = sum_k w_k z_k / (sum_k w_k + 1e-9);  Sigma = (prod_k prod_i w_ki) sum_k T_k T_k^T;
+//           returns chol(Sigma)
+//   mode 2  /root/reference/crossmodal/base_models/unimodal_kf.py:56-115, quirk Q5 included:
+//           "precision" = 1 / (T_k + 1e-9) ELEMENT-WISE, weights = its diagonal,
+//           mu = sum_k w_k z_k / (sum_k w_k + 1e-9), returns inverse(sum_k P_k + 1e-9) (a
+//           covariance where a scale matrix is expected); K == 1: z_0 and T_0 T_0^T
+template <int D>
+__global__ __launch_bounds__(256) void fuse_sensors_kernel(const float* __restrict__ z, const float* __restrict__ tril,
+                                                           const float* __restrict__ w, float* __restrict__ z_out,
+                                                           float* __restrict__ tril_out, int N, int K, int mode) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float num[D], den[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) num[i] = den[i] = 0.f;
+  Mat<D> acc;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) acc.a[i][j] = 0.f;
+  float mult = 1.f;
+  for (int k = 0; k < K; ++k) {
+    const size_t row = static_cast<size_t>(k) * N + n;
+    const Mat<D> T = load_mat<D>(tril + row * D * D);
+    if (mode == 1) {
+      const Mat<D> C = matmul_nt<D>(T, T);
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        const float wk = w[row * D + i];
+        num[i] += wk * z[row * D + i];
+        den[i] += wk;
+        mult *= wk;
+#pragma unroll
+        for (int j = 0; j < D; ++j) acc.a[i][j] += C.a[i][j];
+      }
+    } else if (K == 1) {
+      acc = matmul_nt<D>(T, T);
+#pragma unroll
+      for (int i = 0; i < D; ++i) { num[i] = z[row * D + i]; den[i] = 1.f - 1e-9f; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) acc.a[i][j] += 1.0f / (T.a[i][j] + 1e-9f);
+        const float wk = 1.0f / (T.a[i][i] + 1e-9f);
+        num[i] += wk * z[row * D + i];
+        den[i] += wk;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+    z_out[static_cast<size_t>(n) * D + i] = (mode == 2 && K == 1) ? num[i] : num[i] / (den[i] + 1e-9f);
+  Mat<D> out;
+  if (mode == 1) {  // Cholesky of mult * acc
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) { acc.a[i][j] *= mult; out.a[i][j] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      float s = acc.a[j][j];
+#pragma unroll
+      for (int k = 0; k < D; ++k)
+        if (k < j) s -= out.a[j][k] * out.a[j][k];
+      const float dj = sqrtf(s);
+      out.a[j][j] = dj;
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+        if (i > j) {
+          float t = acc.a[i][j];
+#pragma unroll
+          for (int k = 0; k < D; ++k)
+            if (k < j) t -= out.a[i][k] * out.a[j][k];
+          out.a[i][j] = t / dj;
+        }
+    }
+  } else if (K == 1) {
+    out = acc;
+  } else {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) acc.a[i][j] += 1e-9f;
+    out = inverse<D>(acc);
+  }
+  store_mat<D>(tril_out + static_cast<size_t>(n) * D * D, out);
+}
+
 }  // namespace
+
+extern "C" int mmf_fuse_virtual_sensors(const float* z, const float* tril, const float* w, float* z_out,
+                                        float* tril_out, int N, int d, int K, int mode, void* stream) {
+  if (!z || !tril || !z_out || !tril_out) return MMF_EINVAL;
+  if (N < 0 || K < 1 || (mode != 1 && mode != 2) || (mode == 1 && !w)) return MMF_EINVAL;
+  if (N == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = (N + 255) / 256;
+  if (d == 2) fuse_sensors_kernel<2><<<grid, 256, 0, s>>>(z, tril, w, z_out, tril_out, N, K, mode);
+  else if (d == 3) fuse_sensors_kernel<3><<<grid, 256, 0, s>>>(z, tril, w, z_out, tril_out, N, K, mode);
+  else return MMF_EINVAL;
+  MMF_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int mmf_ekf_step(const float* A, const float* mu_pred, const float* q_tril,
                             const float* z, const float* r_tril, const float* fuse_w, float* mu,
