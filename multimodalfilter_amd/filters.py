@@ -6,16 +6,17 @@ num_particles=)`` with public mutable ``num_particles`` / ``dynamics_model`` /
 ``train_helpers.py:46,94``); ``VirtualSensorExtendedKalmanFilter(dynamics_model=,
 virtual_sensor_model=)`` with ``_belief_mean`` / ``_belief_covariance``
 (``door_models/kf.py:14-28``, ``base_models/crossmodal_kf.py:180``) -- with the recursion
-itself running in hand-written HIP: K1 (``mmf_pf_reweight_resample``) for reweight /
-normalise / estimate / resample / gather and K3 (``mmf_ekf_step``) for the Kalman algebra.
+itself running in hand-written HIP: ``mmf_pf_init_particles`` for the initial belief, K1
+(``mmf_pf_reweight_resample``) for reweight / normalise / estimate / resample / gather, K3
+(``mmf_ekf_step``) for the Kalman algebra, and the native step loops
+(``mmf_pf_forward_loop`` / ``mmf_ekf_forward_loop``) behind ``forward_loop``.
 Step order follows upstream torchfilter.
 """
+import ctypes
 import math
 from typing import Optional
 
 import torch
-
-import ctypes
 
 from . import _abi, base, engine
 from .engine import _timed, check_range, require_device, reserve_memory, use_autograd
