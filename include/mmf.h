@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 13
+#define MMF_ABI_VERSION 14
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -81,6 +81,15 @@ int mmf_pf_reweight_resample(const float* loglik, const float* logw_in, const fl
  */
 int mmf_pf_init_particles(const float* mean, const float* covariance, const float* eps, float* states,
                           float* logw, int32_t* not_pd, int N, int M, int d, void* stream);
+
+/* K6: backward of the no-resample step (mode 0 of mmf_pf_reweight_resample):
+ *   a = logw_in + loglik, logw_out = a - logsumexp_m(a), estimate = sum_m exp(logw_out) x_m.
+ *  logw_out (N, M) as returned by the forward, states (N, M, d), g_estimate (N, d),
+ *  g_logw_out (N, M) or null -> d_a (N, M) (= d loglik = d logw_in), d_states (N, M, d)
+ */
+int mmf_pf_reweight_backward(const float* logw_out, const float* states, const float* g_estimate,
+                             const float* g_logw_out, float* d_a, float* d_states, int N, int M, int d,
+                             void* stream);
 
 size_t mmf_pf_reweight_resample_lds_bytes(int M, int mode);
 

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmmf_hip.so")
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 13
+ABI_VERSION = 14
 PREC_F32, PREC_F16X3 = 0, 1
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}
 
@@ -90,6 +90,7 @@ SIGNATURES = {
     "mmf_pf_measure": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, c_int, _FP, c_int, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_dynamics_jacobian": (c_int, [_FP, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_ekf_step": (c_int, [_FP] * 10 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmf_pf_reweight_backward": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_init_particles": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_forward_loop": (c_int, [POINTER(MmfPfLoopArgs), c_void_p]),
     "mmf_traj_program": (c_int, [_FP, c_int, _FP, POINTER(c_void_p), c_int, c_void_p]),
@@ -290,6 +291,13 @@ def traj_program(prog: torch.Tensor, n_instr: int, weights: torch.Tensor, io_ten
     with _on(weights):
         _check(load().mmf_traj_program(ptr(prog, dtype=torch.uint8), n_instr, ptr(weights), arr, R,
                                        stream_of(weights)), "mmf_traj_program")
+
+
+def pf_reweight_backward(logw_out, states, g_estimate, g_logw_out, d_a, d_states):
+    N, M, d = states.shape
+    with _on(states):
+        _check(load().mmf_pf_reweight_backward(ptr(logw_out), ptr(states), ptr(g_estimate), ptr(g_logw_out), ptr(d_a),
+                                               ptr(d_states), N, M, d, stream_of(states)), "mmf_pf_reweight_backward")
 
 
 def pf_init_particles(mean, covariance, eps, states, logw, not_pd):

@@ -65,7 +65,57 @@ __global__ __launch_bounds__(256) void pf_init_particles_kernel(
   }
 }
 
+// K6 (K1, no-resample path): backward of
+//     a = logw_in + loglik;  lw = a - logsumexp_m(a);  estimate_i = sum_m exp(lw_m) x_mi
+// (torchfilter's train-mode particle-filter step).  With w = exp(lw) and upstream
+// gradients g_est (N, d), g_lw (N, M):
+//     G_m = g_lw_m + w_m sum_i x_mi g_est_i;   d a_k = G_k - w_k sum_m G_m;   d x_mi = w_m g_est_i
+// One workgroup per trajectory, two passes over its M particles.
+template <int D>
+__global__ __launch_bounds__(256) void pf_reweight_backward_kernel(
+    const float* __restrict__ lw, const float* __restrict__ states, const float* __restrict__ g_est,
+    const float* __restrict__ g_lw, float* __restrict__ d_a, float* __restrict__ d_states, int M) {
+  __shared__ float red[4];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const size_t base = static_cast<size_t>(n) * M;
+  float ge[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) ge[i] = g_est[static_cast<size_t>(n) * D + i];
+  float sum = 0.f;
+  for (int m = tid; m < M; m += blockDim.x) {
+    const float w = expf(lw[base + m]);
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      dot += states[(base + m) * D + i] * ge[i];
+      d_states[(base + m) * D + i] = w * ge[i];
+    }
+    const float G = (g_lw ? g_lw[base + m] : 0.f) + w * dot;
+    d_a[base + m] = G;  // completed in the second pass
+    sum += G;
+  }
+  sum = mmf::wave_sum(sum);
+  if ((tid & 63) == 0) red[tid >> 6] = sum;
+  __syncthreads();
+  const float S = red[0] + red[1] + red[2] + red[3];
+  for (int m = tid; m < M; m += blockDim.x) d_a[base + m] -= expf(lw[base + m]) * S;
+}
+
 }  // namespace
+
+extern "C" int mmf_pf_reweight_backward(const float* logw_out, const float* states, const float* g_estimate,
+                                        const float* g_logw_out, float* d_a, float* d_states, int N, int M,
+                                        int d, void* stream) {
+  if (!logw_out || !states || !g_estimate || !d_a || !d_states) return MMF_EINVAL;
+  if (N < 0 || M < 1) return MMF_EINVAL;
+  if (N == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d == 2) pf_reweight_backward_kernel<2><<<N, 256, 0, s>>>(logw_out, states, g_estimate, g_logw_out, d_a, d_states, M);
+  else if (d == 3) pf_reweight_backward_kernel<3><<<N, 256, 0, s>>>(logw_out, states, g_estimate, g_logw_out, d_a, d_states, M);
+  else return MMF_EINVAL;
+  MMF_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int mmf_pf_init_particles(const float* mean, const float* covariance, const float* eps,
                                      float* states, float* logw, int32_t* not_pd, int N, int M, int d,

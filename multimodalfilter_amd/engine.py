@@ -335,6 +335,35 @@ class ParticleNetFunction(torch.autograd.Function):
         return (None, None, None, None, d_states, d_traj_bias, *grads)
 
 
+class ReweightEstimateFunction(torch.autograd.Function):
+    """K6 (K1, no-resample path): ``(loglik, logw_in, states) -> (estimate, logw_out)`` with
+    ``logw_out = logw_in + loglik - logsumexp`` and ``estimate = sum_m exp(logw_out) x_m``;
+    forward = K1 mode 0, backward = ``mmf_pf_reweight_backward``."""
+
+    @staticmethod
+    def forward(ctx, loglik, logw_in, states):
+        require_device(states, "ReweightEstimateFunction")
+        N, M, d = states.shape
+        st = states.detach().to(torch.float32).contiguous()
+        est = torch.empty((N, d), dtype=torch.float32, device=states.device)
+        logw_out = torch.empty((N, M), dtype=torch.float32, device=states.device)
+        _abi.pf_reweight_resample(loglik.detach().to(torch.float32).contiguous(),
+                                  logw_in.detach().to(torch.float32).contiguous(), st, None, est, None,
+                                  logw_out, None, 0)
+        ctx.save_for_backward(logw_out, st)
+        return est, logw_out
+
+    @staticmethod
+    def backward(ctx, g_est, g_logw):
+        logw_out, st = ctx.saved_tensors
+        d_a = torch.empty_like(logw_out)
+        d_states = torch.empty_like(st)
+        g_est = torch.zeros_like(st[:, 0, :]) if g_est is None else g_est.to(torch.float32).contiguous()
+        g_logw = None if g_logw is None else g_logw.to(torch.float32).contiguous()
+        _abi.pf_reweight_backward(logw_out, st, g_est, g_logw, d_a, d_states)
+        return d_a, d_a, d_states
+
+
 def run_dynamics(net: PackedParticleNet, states: torch.Tensor, traj_bias: torch.Tensor,
                  noise, scale_tril, out: torch.Tensor = None) -> torch.Tensor:
     """``states`` ``(N, M, d)`` or ``(R, d)`` with ``traj_bias`` ``(N, 64)``."""

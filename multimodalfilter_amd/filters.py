@@ -196,12 +196,17 @@ class ParticleFilter(base.Filter):
             pred, tril = self.dynamics_model(initial_states=flat, controls=rep)
             eps = self.noise.gaussian((N, M, d), like=pred).reshape(N * M, d)
             states = (pred + torch.einsum("rij,rj->ri", tril, eps)).reshape(N, M, d)
-        logw = self.particle_log_weights + self.measurement_model(states=states, observations=observations)
-        logw = logw - torch.logsumexp(logw, dim=1, keepdim=True)
-        if self.estimation_method == "weighted_average":
-            estimate = torch.sum(torch.exp(logw)[:, :, None] * states, dim=1)
+        loglik = self.measurement_model(states=states, observations=observations)
+        if engine.use_hip_backward() and self.estimation_method == "weighted_average":
+            # K6: reweight + normalise + estimate forward (K1 mode 0) and backward in HIP
+            estimate, logw = engine.ReweightEstimateFunction.apply(loglik, self.particle_log_weights, states)
         else:
-            estimate = states[torch.arange(N, device=states.device), torch.argmax(logw, dim=1)]
+            logw = self.particle_log_weights + loglik
+            logw = logw - torch.logsumexp(logw, dim=1, keepdim=True)
+            if self.estimation_method == "weighted_average":
+                estimate = torch.sum(torch.exp(logw)[:, :, None] * states, dim=1)
+            else:
+                estimate = states[torch.arange(N, device=states.device), torch.argmax(logw, dim=1)]
         self.particle_states, self.particle_log_weights = states, logw
         if do_resample:
             Mo = self.num_particles

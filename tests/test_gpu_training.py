@@ -233,3 +233,33 @@ def test_train_filter_step_descends_and_matches_manual_sgd():
         assert losses[-1] < losses[0]
     finally:
         engine.set_training_backend(None)
+
+
+@pytest.mark.parametrize("N,M,d", [(1, 1, 3), (4, 30, 3), (3, 1000, 2), (2, 8192, 3)])
+def test_k6_reweight_estimate_function_matches_autograd(N, M, d):
+    """K6 (K1 no-resample path): estimate, normalised log-weights and the gradients w.r.t.
+    log-likelihoods, previous log-weights and particles against torch autograd in fp64."""
+    from multimodalfilter_amd import engine
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(N + M)
+    ll = (torch.randn((N, M), generator=g) * 2).to(dev).requires_grad_(True)
+    lw = torch.log_softmax(torch.randn((N, M), generator=g), dim=1).to(dev).requires_grad_(True)
+    x = torch.randn((N, M, d), generator=g).to(dev).requires_grad_(True)
+    g_est = torch.randn((N, d), generator=g).to(dev)
+    g_lw = torch.randn((N, M), generator=g).to(dev)
+    est, out = engine.ReweightEstimateFunction.apply(ll, lw, x)
+    got = torch.autograd.grad([est, out], [ll, lw, x], [g_est, g_lw])
+
+    l64, w64, x64 = (t.detach().double().requires_grad_(True) for t in (ll, lw, x))
+    a = w64 + l64
+    o64 = a - torch.logsumexp(a, dim=1, keepdim=True)
+    e64 = torch.sum(torch.exp(o64)[:, :, None] * x64, dim=1)
+    want = torch.autograd.grad([e64, o64], [l64, w64, x64], [g_est.double(), g_lw.double()])
+
+    def rel(p, q):
+        return float((p.detach().double() - q).abs().max()) / max(1e-6, float(q.abs().max()))
+
+    assert rel(est, e64.detach()) < 1e-4 and rel(out, o64.detach()) < 1e-4
+    for name, p, q in zip(("loglik", "logw_in", "states"), got, want):
+        assert rel(p, q) < 1e-4, f"{name}: {rel(p, q):.2e}"
