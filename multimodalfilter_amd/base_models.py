@@ -129,6 +129,34 @@ class CrossmodalParticleFilterMeasurementModel(base.ParticleFilterMeasurementMod
         assert not first, "no measurement model enabled"
         return loglik
 
+    def encode_observations_autograd(self, observations):
+        """Training counterpart of ``encode_observations`` (differentiable torch ops on ``R`` rows):
+        each enabled unimodal model's hoisted bias and the modality log-weights; ``None`` when a
+        unimodal model does not implement the protocol."""
+        if not all(hasattr(m, "encode_observations_autograd") for m in self.measurement_models):
+            return None
+        ctx = {}
+        for i, m in enumerate(self.measurement_models):
+            if self._enabled_models[i]:
+                for k, v in m.encode_observations_autograd(observations).items():
+                    ctx[f"m{i}.{k}"] = v
+        if self.crossmodal_weight_model is not None:
+            ctx["modality_log_weights"] = self.crossmodal_weight_model(observations=observations)
+        return ctx
+
+    def forward_encoded_autograd(self, states, ctx):
+        """``logsumexp_k(log beta_k + ll_k)`` (``crossmodal_pf.py:106-139``) from hoisted terms."""
+        N, M, _ = states.shape
+        on = self._enabled_models
+        ll = torch.stack(
+            [m.forward_encoded_autograd(states, {k[len(f"m{i}."):]: v for k, v in ctx.items()
+                                                 if k.startswith(f"m{i}.")})
+             for i, m in enumerate(self.measurement_models) if on[i]], dim=2)
+        beta = ctx.get("modality_log_weights")
+        if beta is not None:
+            ll = ll + beta[:, on][:, None, :]
+        return torch.logsumexp(ll, dim=2)
+
     def forward(self, *, states, observations):
         N, M, _state_dim = states.shape
         if self._fusable() and not use_autograd(self):

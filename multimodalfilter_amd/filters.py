@@ -178,7 +178,7 @@ class ParticleFilter(base.Filter):
             self.particle_log_weights = logw_out
         return estimate
 
-    def _step_autograd(self, observations, controls) -> torch.Tensor:
+    def _step_autograd(self, observations, controls, dyn_bias=None, meas_ctx=None) -> torch.Tensor:
         """Differentiable torch formulation of the step (training backend "autograd"): gradients
         flow through the reparameterised noise and the log-weights; resampling, when requested,
         runs through K1 on detached tensors (it stops gradients upstream as well)."""
@@ -187,7 +187,8 @@ class ParticleFilter(base.Filter):
         do_resample = (not self.training) if self.resample is None else bool(self.resample)
         if engine.use_hip_backward() and hasattr(self.dynamics_model, "forward_particles"):
             # K6: the N*M-row network evaluates and differentiates in HIP
-            pred = self.dynamics_model.forward_particles(states=self.particle_states, controls=controls)
+            pred = self.dynamics_model.forward_particles(states=self.particle_states, controls=controls,
+                                                         bias=dyn_bias)
             eps = self.noise.gaussian((N, M, d), like=pred)
             states = pred + eps @ self.dynamics_model.scale_tril().t()
         else:
@@ -196,7 +197,10 @@ class ParticleFilter(base.Filter):
             pred, tril = self.dynamics_model(initial_states=flat, controls=rep)
             eps = self.noise.gaussian((N, M, d), like=pred).reshape(N * M, d)
             states = (pred + torch.einsum("rij,rj->ri", tril, eps)).reshape(N, M, d)
-        loglik = self.measurement_model(states=states, observations=observations)
+        if meas_ctx is not None:
+            loglik = self.measurement_model.forward_encoded_autograd(states, meas_ctx)
+        else:
+            loglik = self.measurement_model(states=states, observations=observations)
         if engine.use_hip_backward() and self.estimation_method == "weighted_average":
             # K6: reweight + normalise + estimate forward (K1 mode 0) and backward in HIP
             estimate, logw = engine.ReweightEstimateFunction.apply(loglik, self.particle_log_weights, states)
@@ -296,9 +300,25 @@ class ParticleFilter(base.Filter):
         work costs one launch sequence per ``forward_loop`` instead of one per step."""
         T, N = tree_leading_shape(controls)[:2]
         assert tree_leading_shape(observations)[:2] == (T, N)
-        if use_autograd(self):
-            return base.Filter.forward_loop(self, observations=observations, controls=controls)
         flat = lambda x: x.reshape((T * N,) + tuple(x.shape[2:]))
+        if use_autograd(self):
+            if not engine.use_hip_backward():
+                return base.Filter.forward_loop(self, observations=observations, controls=controls)
+            # training, K6 backend: the per-trajectory networks (image CNNs, encoders, weight
+            # model) are differentiable torch ops evaluated ONCE on the T*N flattened rows
+            dyn_all = meas_all = None
+            if hasattr(self.dynamics_model, "encode_controls_autograd"):
+                dyn_all = self.dynamics_model.encode_controls_autograd(tree_map(controls, flat))
+            if hasattr(self.measurement_model, "encode_observations_autograd"):
+                meas_all = self.measurement_model.encode_observations_autograd(tree_map(observations, flat))
+            out = []
+            for t in range(T):
+                sl = slice(t * N, (t + 1) * N)
+                out.append(self._step_autograd(
+                    tree_index(observations, t), tree_index(controls, t),
+                    None if dyn_all is None else dyn_all[sl],
+                    None if meas_all is None else {k: v[sl] for k, v in meas_all.items()}))
+            return torch.stack(out, dim=0)
         obs_all = ctrl_all = None
         with torch.no_grad():
             if hasattr(self.measurement_model, "forward_encoded"):

@@ -179,13 +179,19 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             mu_pred, A = engine.run_jacobian(self._net, mean, ctx["bias"])
             return mu_pred, A, self.scale_tril().contiguous()
 
-        def forward_particles(self, *, states, controls):
-            """Differentiable one-step prediction (no noise) of ``(N, M, d)`` particles under
-            per-trajectory ``controls (N, 7)`` with the ``N*M``-row work in HIP (K6): the control
-            encoder and the control half of the join layer stay torch ops on ``N`` rows."""
-            N, M, d = states.shape
+        def encode_controls_autograd(self, controls):
+            """Differentiable hoisted control term ``(R, 64)`` (torch ops on ``R`` rows)."""
             join = self.shared_layers[0]
-            bias = self.control_layers(controls) @ join.weight[:, :self.units].t() + join.bias
+            return self.control_layers(controls) @ join.weight[:, :self.units].t() + join.bias
+
+        def forward_particles(self, *, states, controls=None, bias=None):
+            """Differentiable one-step prediction (no noise) of ``(N, M, d)`` particles under
+            per-trajectory ``controls (N, 7)`` (or their pre-computed ``bias``) with the
+            ``N*M``-row work in HIP (K6): the control encoder and the control half of the join
+            layer stay torch ops on ``N`` rows."""
+            N, M, d = states.shape
+            if bias is None:
+                bias = self.encode_controls_autograd(controls)
             flat = states.reshape(N * M, d)
             out = engine.ParticleNetFunction.apply(self._net, 0, N, M, flat, bias, *self._net._sources())
             return (flat + out[:, :d] * torch.sigmoid(out[:, d:])).reshape(N, M, d)
@@ -255,6 +261,20 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             self._obs_prog.run(t, R)
             return {"bias": t["bias"]}
 
+        def encode_observations_autograd(self, observations):
+            """Differentiable hoisted observation term: encoders and the observation half of the
+            join layer as torch ops on ``R`` rows -> ``{"bias": (R, 64)}``."""
+            obs = self.observation_features_autograd(observations)
+            join = self.shared_layers[0]
+            return {"bias": obs @ join.weight[:, :obs.shape[1]].t() + join.bias}
+
+        def forward_encoded_autograd(self, states, ctx):
+            """K6: the per-particle network runs (and differentiates) in HIP."""
+            N, M, d = states.shape
+            out = engine.ParticleNetFunction.apply(self._net, 1, N, M, states.reshape(N * M, d), ctx["bias"],
+                                                   *self._net._sources())
+            return out[:, 0].reshape(N, M)
+
         def fused_measurements(self, ctx):
             """``([(network, bias (R, 64), modality log-weight column or None)], stride)`` for the
             native step loop (``mmf_pf_forward_loop``)."""
@@ -273,15 +293,7 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             assert len(states.shape) == 3  # (N, M, state_dim)
             assert states.shape[2] == self.state_dim
             if engine.use_autograd(self) and engine.use_hip_backward():
-                # K6: observation encoders and the observation half of the join layer are torch
-                # ops on N rows; the per-particle network runs (and differentiates) in HIP
-                N, M, d = states.shape
-                obs = self.observation_features_autograd(observations)
-                join = self.shared_layers[0]
-                bias = obs @ join.weight[:, :obs.shape[1]].t() + join.bias
-                out = engine.ParticleNetFunction.apply(self._net, 1, N, M, states.reshape(N * M, d), bias,
-                                                       *self._net._sources())
-                return out[:, 0].reshape(N, M)
+                return self.forward_encoded_autograd(states, self.encode_observations_autograd(observations))
             if engine.use_autograd(self):
                 N, M, _ = states.shape
                 obs = self.observation_features_autograd(observations)
