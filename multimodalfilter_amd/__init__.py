@@ -10,10 +10,10 @@ does not need a GPU; running a filter does, and there is no CPU fallback.
 from . import _abi, base, types, utils  # noqa: F401
 from . import filters, base_models  # noqa: F401
 from . import door_models, push_models  # noqa: F401
-from . import train  # noqa: F401
+from . import data, train  # noqa: F401
 from .utils import NoiseSource, ReplayNoise, StackedNoise  # noqa: F401
 
-__all__ = ["base", "filters", "types", "utils", "base_models", "door_models", "push_models", "train",
+__all__ = ["base", "filters", "types", "utils", "base_models", "door_models", "push_models", "data", "train",
            "NoiseSource", "ReplayNoise", "StackedNoise", "model_types"]
 
 
