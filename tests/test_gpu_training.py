@@ -263,3 +263,45 @@ def test_k6_reweight_estimate_function_matches_autograd(N, M, d):
     assert rel(est, e64.detach()) < 1e-4 and rel(out, o64.detach()) < 1e-4
     for name, p, q in zip(("loglik", "logw_in", "states"), got, want):
         assert rel(p, q) < 1e-4, f"{name}: {rel(p, q):.2e}"
+
+
+def test_recordings_to_training_to_evaluation_pipeline():
+    """Synthetic door recordings -> ``data.trajectory_from_raw`` -> device-resident subsequence
+    batches -> ``train.train_filter_step`` (K6 backend) -> ``evaluation.run_filter`` on the
+    stacked trajectories: the pieces of SURVEY.md 8f rows 1 and 3 fit together on the GPU."""
+    import numpy as np
+
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import data, engine, evaluation, train
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(0)
+
+    def recording(T):
+        theta = np.cumsum(rng.normal(size=T) * 0.02) + 0.6
+        return {"object-state": np.stack([np.zeros(T), theta, np.zeros(T), np.full(T, 0.001), np.full(T, -0.001)], 1).astype(np.float32),
+                "eef_pos": (np.array([0.37, -0.1, 1.57]) + rng.normal(size=(T, 3)) * 0.05).astype(np.float32),
+                "ee-force-obs": rng.normal(size=(T, 3)).astype(np.float32) * 10,
+                "ee-torque-obs": rng.normal(size=(T, 3)).astype(np.float32),
+                "contact-obs": (rng.uniform(size=T) > 0.4).astype(np.float32),
+                "image": rng.uniform(size=(T, 64, 64)).astype(np.float32)}
+
+    trajs = [data.trajectory_from_raw(recording(T), data.DOOR, image_blackout_ratio=0.3, rng=rng) for T in (20, 17, 25, 18)]
+    loader = data.SubsequenceBatcher(trajs, subsequence_length=4, batch_size=4, device=dev, seed=1)
+    torch.manual_seed(0)
+    f = mmf.door_models.DoorCrossmodalParticleFilter().to(dev).train()
+    opt = torch.optim.Adam(f.parameters(), lr=1e-3)
+    cov = torch.eye(3, device=dev) * 0.1
+    engine.set_training_backend("hip")
+    try:
+        losses = [train.train_filter_step(f, batch, opt, initial_covariance=cov, noise=mmf.NoiseSource(seed=3))
+                  for _ in range(2) for batch in loader]
+    finally:
+        engine.set_training_backend(None)
+    assert len(losses) == 2 * len(loader) and all(np.isfinite(losses))
+    f.eval()
+    f.noise = mmf.NoiseSource(seed=4)
+    batch = data.stack_trajectories(trajs, dev)
+    pred = evaluation.run_filter(f, batch)
+    assert pred.shape == (16, 4, 3) and bool(torch.isfinite(pred).all()) and not pred.requires_grad
+    assert evaluation.raw_rmse(evaluation.per_trajectory_mse(pred, batch["states"][1:], start=5)).shape == (3,)
