@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 14
+#define MMF_ABI_VERSION 15
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -172,6 +172,13 @@ int mmf_pf_measure(const float* packed, int n_res, int precision, const float* s
 int mmf_dynamics_jacobian(const float* packed, int n_res, const float* states_in,
                           const float* traj_bias, float* states_out, float* jac, int N, int d,
                           void* stream);
+
+/* K independent Jacobian problems of one shape in ONE launch (the sub-filters of a fused EKF):
+ * states_in / states_out (K, N, d), jac (K, N, d, d); packed[k], traj_bias[k] per problem.
+ */
+int mmf_dynamics_jacobian_multi(const float* const* packed, int n_res, const float* states_in,
+                                const float* const* traj_bias, float* states_out, float* jac,
+                                int K, int N, int d, void* stream);
 
 /* ---------------------------------------------------------------- K6: training through the per-particle networks
  * Replaces autograd through DoorDynamicsModel*.forward / DoorMeasurementModel.forward over N*M

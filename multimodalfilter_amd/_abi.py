@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmmf_hip.so")
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 14
+ABI_VERSION = 15
 PREC_F32, PREC_F16X3 = 0, 1
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}
 
@@ -96,6 +96,8 @@ SIGNATURES = {
     "mmf_traj_program": (c_int, [_FP, c_int, _FP, POINTER(c_void_p), c_int, c_void_p]),
     "mmf_fuse_virtual_sensors": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_ekf_forward_loop": (c_int, [POINTER(MmfEkfLoopArgs), c_void_p]),
+    "mmf_dynamics_jacobian_multi": (c_int, [POINTER(c_void_p), c_int, _FP, POINTER(c_void_p), _FP, _FP,
+                                            c_int, c_int, c_int, c_void_p]),
     "mmf_particle_net_train_forward": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_particle_net_weight_grads": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_particle_net_train_backward": (c_int, [_FP, _FP, c_int, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),

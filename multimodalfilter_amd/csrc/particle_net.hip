@@ -463,8 +463,15 @@ struct NetArgs {
   int* range_flag;          // f16x3: set to 1 when an activation left the f16-split range
 };
 
+// blockIdx.y selects one of up to MMF_LOOP_MAX_MEAS independent problems of the same shape (the
+// sub-filters of a fused EKF evaluate their Jacobians in one launch); every other caller uses 1.
+struct NetArgsMulti {
+  NetArgs a[MMF_LOOP_MAX_MEAS];
+};
+
 template <int D, int NRES, int KIND, int CT, int PREC, int WPS, bool PIPE = false>
-__global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgs a) {
+__global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMulti multi) {
+  const NetArgs a = multi.a[blockIdx.y];
   static_assert(!PIPE || (CT == 2 && PREC == MMF_PREC_F16X3 && KIND != kJacobian), "pipelined halves: f16x3, 64-particle tiles");
   constexpr int kThreads = WPS * 256;           // WPS waves per SIMD, one workgroup per CU (LDS)
   constexpr int kWavesPerBlock = kThreads / MMF_WAVE;
@@ -751,7 +758,8 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgs a)
 }
 
 template <int D, int NRES, int KIND, int PREC, int CT, int WPS, bool PIPE = false>
-int launch_variant(const NetArgs& a, hipStream_t s) {
+int launch_variant(const NetArgsMulti& m, int count, hipStream_t s) {
+  const NetArgs& a = m.a[0];
   const size_t lds = static_cast<size_t>(blob_floats(NRES)) * sizeof(float);
   constexpr int waves = WPS * 4, tile = 32 * CT;
   const int ntiles = (a.R + tile - 1) / tile;
@@ -762,33 +770,44 @@ int launch_variant(const NetArgs& a, hipStream_t s) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   if (e != hipSuccess) return static_cast<int>(e);
-  k<<<grid, WPS * 256, lds, s>>>(a);
+  k<<<dim3(grid, count), WPS * 256, lds, s>>>(m);
   MMF_CHECK_LAUNCH();
   return 0;
 }
 
 template <int D, int NRES, int KIND, int PREC>
-int launch_ct(const NetArgs& a, hipStream_t s) {
+int launch_ct(const NetArgsMulti& m, int count, hipStream_t s) {
+  const NetArgs& a = m.a[0];
   // small problems: 32-particle tiles spread over more waves; large: 64-particle tiles
   const bool big = a.R >= 256 * 8 * 64;
   static const int variant = [] { const char* v = getenv("MMF_K2_VARIANT"); return v ? atoi(v) : 0; }();
   if constexpr (PREC == MMF_PREC_F16X3 && KIND != kJacobian) {
-    if (big && variant == 1) return launch_variant<D, NRES, KIND, PREC, 1, 3>(a, s);  // 32-particle tiles, 3 waves/SIMD
-    if (big && variant == 2) return launch_variant<D, NRES, KIND, PREC, 1, 2>(a, s);
-    if (big && variant == 3) return launch_variant<D, NRES, KIND, PREC, 2, 2, false>(a, s);  // unpipelined
-    if (big) return launch_variant<D, NRES, KIND, PREC, 2, 2, true>(a, s);
+    if (big && variant == 1) return launch_variant<D, NRES, KIND, PREC, 1, 3>(m, count, s);  // 32-particle tiles, 3 waves/SIMD
+    if (big && variant == 2) return launch_variant<D, NRES, KIND, PREC, 1, 2>(m, count, s);
+    if (big && variant == 3) return launch_variant<D, NRES, KIND, PREC, 2, 2, false>(m, count, s);  // unpipelined
+    if (big) return launch_variant<D, NRES, KIND, PREC, 2, 2, true>(m, count, s);
   }
-  if (big) return launch_variant<D, NRES, KIND, PREC, 2, 2>(a, s);
-  return launch_variant<D, NRES, KIND, PREC, 1, 2>(a, s);
+  if (big) return launch_variant<D, NRES, KIND, PREC, 2, 2>(m, count, s);
+  return launch_variant<D, NRES, KIND, PREC, 1, 2>(m, count, s);
 }
 
 template <int KIND>
+int launch_multi(const NetArgsMulti& m, int count, int d, int n_res, int precision, hipStream_t s);
+
+template <int KIND>
 int launch(const NetArgs& a, int d, int n_res, int precision, hipStream_t s) {
+  NetArgsMulti m{};
+  m.a[0] = a;
+  return launch_multi<KIND>(m, 1, d, n_res, precision, s);
+}
+
+template <int KIND>
+int launch_multi(const NetArgsMulti& m, int count, int d, int n_res, int precision, hipStream_t s) {
 #define MMF_CASE(D, NR)                                                              \
   if (d == D && n_res == NR) {                                                       \
-    if (precision == MMF_PREC_F32) return launch_ct<D, NR, KIND, MMF_PREC_F32>(a, s); \
+    if (precision == MMF_PREC_F32) return launch_ct<D, NR, KIND, MMF_PREC_F32>(m, count, s); \
     if constexpr (KIND != kJacobian)                                                 \
-      if (precision == MMF_PREC_F16X3) return launch_ct<D, NR, KIND, MMF_PREC_F16X3>(a, s); \
+      if (precision == MMF_PREC_F16X3) return launch_ct<D, NR, KIND, MMF_PREC_F16X3>(m, count, s); \
     return MMF_EINVAL;                                                               \
   }
   if (KIND == kJacobian || KIND == kDynamics) {
@@ -865,6 +884,26 @@ extern "C" int mmf_dynamics_jacobian(const float* packed, int n_res, const float
   a.packed = packed; a.states_in = states_in; a.traj_bias = traj_bias;
   a.states_out = states_out; a.jac = jac; a.R = 4 * N; a.M = 4;
   return launch<kJacobian>(a, d, n_res, MMF_PREC_F32, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mmf_dynamics_jacobian_multi(const float* const* packed, int n_res, const float* states_in,
+                                           const float* const* traj_bias, float* states_out, float* jac,
+                                           int K, int N, int d, void* stream) {
+  if (!packed || !states_in || !traj_bias || !states_out || !jac) return MMF_EINVAL;
+  if (K < 1 || K > MMF_LOOP_MAX_MEAS || N < 0) return MMF_EINVAL;
+  if (N > 0x7fffffff / 32) return MMF_ETOOLARGE;
+  if (N == 0) return 0;
+  NetArgsMulti m{};
+  for (int k = 0; k < K; ++k) {
+    if (!packed[k] || !traj_bias[k]) return MMF_EINVAL;
+    NetArgs& a = m.a[k];
+    a.packed = packed[k]; a.traj_bias = traj_bias[k];
+    a.states_in = states_in + static_cast<size_t>(k) * N * d;
+    a.states_out = states_out + static_cast<size_t>(k) * N * d;
+    a.jac = jac + static_cast<size_t>(k) * N * d * d;
+    a.R = 4 * N; a.M = 4;
+  }
+  return launch_multi<kJacobian>(m, K, d, n_res, MMF_PREC_F32, static_cast<hipStream_t>(stream));
 }
 
 #include "particle_net_train.inc"
