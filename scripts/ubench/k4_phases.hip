@@ -40,14 +40,14 @@ int main(int argc, char** argv) {
     hipMemcpyToSymbol(HIP_SYMBOL(g_phase), zero, sizeof(zero));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    if (mmf_image_encoder(blobs, nets, images, feat, ws, nullptr, MMF_PREC_F16X3, N, nullptr)) return 2;
+    if (mmf_image_encoder(blobs, nets, images, feat, ws, nullptr, MMF_PREC_F16X3, MMF_ENCODER_DEFAULT, N, nullptr)) return 2;
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long ph[4][8];
     hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase), sizeof(ph));
     printf("rep %d: %d images x %d nets in %.3f ms\n", rep, N, nets, ms);
     const char* names[4] = {"32->32", "32->32+skip", "32->16", "16->8"};
-    const int bands = 2 * N / (256 / nets);  // bands per persistent workgroup
+    const int bands = 2 * N / (256 / nets);  // 16-row units per CU (two 8-row bands each, one per resident workgroup)
     for (int l = 0; l < 4; ++l)
       printf("  %-12s us/band: wait-prev %.2f commit %.2f barrier %.2f prefetch-issue %.2f mfma %.2f epilogue %.2f  (x%d bands)\n",
              names[l], ph[l][0] * 0.01 / bands, ph[l][1] * 0.01 / bands, ph[l][2] * 0.01 / bands,
