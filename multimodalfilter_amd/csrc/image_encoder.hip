@@ -384,34 +384,36 @@ __global__ __launch_bounds__(BAND * 32) void conv_f16x3_kernel(ConvHArgs a) {
   const int it_rr[2] = {tid / (XG * CG), (tid + THREADS) / (XG * CG)};
   static_assert(IPT <= 2, "staging indices are precomputed for two rounds");
 
-  // prefetch registers: IPT items x 8 channels x 4 pixels
+  // prefetch registers: IPT items x 8 channels x 4 pixels.  The loads are UNCONDITIONAL (row and
+  // item clamped to valid addresses) and the out-of-image / out-of-range masking happens at
+  // commit time: a select on the loaded value here would make the wave wait for every load
+  // before the MFMA phase it is supposed to overlap with.
   f32x4 pf[IPT][8];
   auto prefetch = [&](int band) {
     const int img = band / BPI, y0 = (band % BPI) * BAND;
     const float* in = in_net + static_cast<size_t>(img) * CIN * kImg * kImg;
 #pragma unroll
     for (int it = 0; it < IPT; ++it) {
-      const int y = y0 - 1 + it_rr[it];
-      const bool ok = tid + it * THREADS < ITEMS && y >= 0 && y < kImg;
-      const float* p = in + ((it_cg[it] * 8) * kImg + (ok ? y : 0)) * kImg + 4 * it_xg[it];
+      const int y = min(max(y0 - 1 + min(it_rr[it], RB - 1), 0), kImg - 1);
+      const float* p = in + ((it_cg[it] * 8) * kImg + y) * kImg + 4 * it_xg[it];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        pf[it][i] = ok ? *reinterpret_cast<const f32x4*>(p + i * kImg * kImg) : zero;
-      }
+      for (int i = 0; i < 8; ++i) pf[it][i] = *reinterpret_cast<const f32x4*>(p + i * kImg * kImg);
     }
   };
   float amax = 0.f;
-  auto commit = [&]() {  // registers -> split -> swizzled LDS planes
+  auto commit = [&](int band) {  // registers -> split -> swizzled LDS planes
+    const int y0 = (band % BPI) * BAND;
 #pragma unroll
     for (int it = 0; it < IPT; ++it) {
       if (tid + it * THREADS < ITEMS) {
+        const int y = y0 - 1 + it_rr[it];
+        const bool inside = y >= 0 && y < kImg;  // rows above / below the image are zero padding
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
           u32x4 hv, lv;
 #pragma unroll
           for (int p = 0; p < 4; ++p) {
-            const float x0 = pf[it][2 * p][px], x1 = pf[it][2 * p + 1][px];
+            const float x0 = inside ? pf[it][2 * p][px] : 0.f, x1 = inside ? pf[it][2 * p + 1][px] : 0.f;
             amax = fmaxf(amax, fmaxf(fabsf(x0), fabsf(x1)));
             const auto hh = __builtin_amdgcn_cvt_pkrtz(x0, x1);
             const f32x2 xs = {x0, x1};
@@ -430,6 +432,15 @@ __global__ __launch_bounds__(BAND * 32) void conv_f16x3_kernel(ConvHArgs a) {
     }
   };
 
+  // bias per accumulator register, loaded once: a global load between the prefetch and the MFMA
+  // loop would make the wave drain the (in-order) load counter, i.e. wait for the prefetch
+  float bias_r[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int ch = (r & 3) + 8 * (r >> 2) + 4 * h;
+    bias_r[r] = ch < COUT ? blob[a.boff + ch] : 0.f;
+  }
+
   int band = blockIdx.x;
   if (band < nbands) prefetch(band);
 #ifdef MMF_K4_PHASE_CLOCKS
@@ -439,7 +450,7 @@ __global__ __launch_bounds__(BAND * 32) void conv_f16x3_kernel(ConvHArgs a) {
   for (; band < nbands; band += gridDim.x) {
     __syncthreads();  // everyone finished reading the previous band's planes (and the weights landed)
     K4_CLOCK(0);
-    commit();
+    commit(band);
     K4_CLOCK(1);
     __syncthreads();
     K4_CLOCK(2);
@@ -454,9 +465,8 @@ __global__ __launch_bounds__(BAND * 32) void conv_f16x3_kernel(ConvHArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ch = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const float b = ch < COUT ? blob[a.boff + ch] : 0.f;
-      acc[0][r] = b;
-      acc[1][r] = b;
+      acc[0][r] = bias_r[r];
+      acc[1][r] = bias_r[r];
       if (SKIP) {  // issued now, consumed after the MFMAs: the load latency hides under them
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
