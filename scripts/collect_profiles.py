@@ -29,7 +29,7 @@ def one(pattern):
     hits = glob.glob(pattern, recursive=True)
     if not hits:
         raise SystemExit(f"missing {pattern}")
-    return hits[0]
+    return max(hits, key=os.path.getmtime)  # gpurun_out/ accumulates runs: take the latest
 
 
 def main(src, dst):
