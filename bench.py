@@ -232,6 +232,9 @@ def main():
     d = spec.state_dim
 
     f = build_filter(wl, device)
+    # untrained dynamics are expanding maps; keep any --steps the driver asks for finite
+    # (same arithmetic per step; see synthetic.stabilise_dynamics)
+    synthetic.stabilise_dynamics(f)
     # rank-private trajectories (weak scaling): seed 20201025 + config id + rank
     traj_w_cpu, traj_w = make_inputs(wl, W, B, 20201025 + 1000 * rank + 1, device, d)
     traj_cpu, traj = make_inputs(wl, K, B, 20201025 + 1000 * rank + 2, device, d)

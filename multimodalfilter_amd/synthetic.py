@@ -81,3 +81,22 @@ def calibrate_measurement_heads(pf, observations, states, target_std: float = 1.
             head.bias.mul_(s)
             scale_used = s
     return scale_used
+
+
+def stabilise_dynamics(filter_model, gain: float = 2e-3) -> None:
+    """Randomly initialised dynamics networks are expanding maps: ``x' = x + dir(x) * gate`` with
+    ``|dir(x)| ~ c |x|`` multiplies the state by ``(1 + c)`` per step, so an untrained filter
+    leaves any finite range after a few hundred steps (|x| ~ 9e6 at step 400, fp32 and f16x3
+    alike).  Scaling the direction rows of the dynamics head by ``gain`` keeps the same
+    arithmetic per step (no work is removed) and bounds the growth to ``exp(gain * c * steps)``,
+    so a benchmark run of any practical length stays finite.  Works on any filter exposing the
+    reference's module layout (``dynamics_model.shared_layers[-1]``; fused EKFs: every
+    ``filter_models[k].dynamics_model``)."""
+    subs = list(getattr(filter_model, "filter_models", [filter_model]))
+    with torch.no_grad():
+        for f in subs:
+            head = f.dynamics_model.shared_layers[-1]
+            d = head.out_features - 1  # rows 0..d-1: direction, row d: gate logit
+            head.weight[:d].mul_(gain)
+            head.bias[:d].mul_(gain)
+
