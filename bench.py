@@ -236,7 +236,7 @@ def main():
     # (same arithmetic per step; see synthetic.stabilise_dynamics)
     synthetic.stabilise_dynamics(f)
     # rank-private trajectories (weak scaling): seed 20201025 + config id + rank
-    traj_w_cpu, traj_w = make_inputs(wl, W, B, 20201025 + 1000 * rank + 1, device, d)
+    traj_w_cpu, traj_w = make_inputs(wl, max(W, 1), B, 20201025 + 1000 * rank + 1, device, d)  # unused when W == 0
     traj_cpu, traj = make_inputs(wl, K, B, 20201025 + 1000 * rank + 2, device, d)
 
     if wl["kind"] == "pf":
@@ -245,7 +245,7 @@ def main():
         cal_states = traj["states"][0][:, None, :] + 0.3 * torch.randn((B, 256, d), device=device)
         synthetic.calibrate_measurement_heads(
             f, {k: traj[k][0] for k in ("image", "gripper_pos", "gripper_sensors")}, cal_states)
-        noise_w = synthetic.draw_filter_noise(T=W, N=B, M=M, state_dim=d, seed=77 + rank)
+        noise_w = synthetic.draw_filter_noise(T=max(W, 1), N=B, M=M, state_dim=d, seed=77 + rank)
         noise = synthetic.draw_filter_noise(T=K, N=B, M=M, state_dim=d, seed=78 + rank)
         mv = lambda nz: (nz[0].to(device), torch.stack(nz[1]).to(device), torch.stack(nz[2]).to(device))
         noise_w, noise = mv(noise_w), mv(noise)
