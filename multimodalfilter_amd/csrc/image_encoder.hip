@@ -396,8 +396,18 @@ __global__ __launch_bounds__(BAND * 32) void conv_f16x3_kernel(ConvHArgs a) {
     for (int it = 0; it < IPT; ++it) {
       const int y = min(max(y0 - 1 + min(it_rr[it], RB - 1), 0), kImg - 1);
       const float* p = in + ((it_cg[it] * 8) * kImg + y) * kImg + 4 * it_xg[it];
+      // The skip variant also holds 32 skip values across the MFMA loop; with 64 prefetch
+      // registers genuinely in flight as well it needs 344 registers and loses the second
+      // workgroup per CU (456 us instead of ~360).  There the select below makes the wave wait
+      // for the loads here (the old blocking scheme), which lets the allocator overlap them.
+      const int yr = y0 - 1 + it_rr[it];
+      const bool ok = tid + it * THREADS < ITEMS && yr >= 0 && yr < kImg;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) pf[it][i] = *reinterpret_cast<const f32x4*>(p + i * kImg * kImg);
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + i * kImg * kImg);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        pf[it][i] = SKIP ? (ok ? v : zero) : v;
+      }
     }
   };
   float amax = 0.f;
@@ -465,8 +475,9 @@ __global__ __launch_bounds__(BAND * 32) void conv_f16x3_kernel(ConvHArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ch = (r & 3) + 8 * (r >> 2) + 4 * h;
-      acc[0][r] = bias_r[r];
-      acc[1][r] = bias_r[r];
+      const float b = SKIP ? (ch < COUT ? blob[a.boff + ch] : 0.f) : bias_r[r];  // skip variant: fewer live registers
+      acc[0][r] = b;
+      acc[1][r] = b;
       if (SKIP) {  // issued now, consumed after the MFMAs: the load latency hides under them
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
