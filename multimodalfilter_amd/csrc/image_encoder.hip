@@ -56,6 +56,7 @@ __host__ __device__ constexpr int conv_w_floats(int cin, int cout, int ks) {
 struct Layout {
   int w1, b1, w2a, b2a, w2b, b2b, w3, b3, w4, b4, fcw, fcb, r1t, r1b, r2t, r2b;
   int h2a, h2b, h3, h4;  // f16x3 fragment-ordered copies of the 3x3 convolutions' weights
+  int hfc;               // f16x3 fragment-ordered copy of the 8192 -> 64 linear layer's weights
   int total;
 };
 // floats (= halves / 2) of a 3x3 conv in f16x3 fragment order [tap][kc][hi|lo][lane][8 halves]
@@ -83,6 +84,7 @@ __host__ __device__ constexpr Layout layout() {
   L.h2b = o; o += conv_h_floats(32);
   L.h3 = o; o += conv_h_floats(32);
   L.h4 = o; o += conv_h_floats(16);
+  L.hfc = o; o += kFcSplit * (kFcK / kFcSplit / 16) * 2 * 2 * 64 * 8 / 2;  // [split][k-step][tile][hi|lo][lane][8 halves]
   L.total = o;
   return L;
 }
@@ -155,9 +157,22 @@ __global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ o
       v = d.res_w[1][o * kFeat + k];
     } else if (q0 < L.h2a) {
       v = d.res_b[1][q0 - L.r2b];
+    } else if (q0 >= L.hfc) {
+      // f16x3 linear layer: element i of lane (row, h) in k-step ks of split sp is W[32 tile + row][512 sp + 16 ks + 8 h + i]
+      unsigned short hb[2];
+      for (int z = 0; z < 2; ++z) {
+        const int he = 2 * (q0 - L.hfc) + z;
+        const int i = he & 7, lane = (he >> 3) & 63, part = (he >> 9) & 1, tile = (he >> 10) & 1, rest = he >> 11;
+        const int ks = rest % (kFcK / kFcSplit / 16), sp = rest / (kFcK / kFcSplit / 16);
+        const int o = 32 * tile + (lane & 31), k = sp * (kFcK / kFcSplit) + 16 * ks + 8 * (lane >> 5) + i;
+        const float w = fc_in == kFcK ? d.fc_w[static_cast<size_t>(o) * kFcK + k] : 0.f;
+        const __half hi = __float2half_rz(w);
+        hb[z] = part ? __half_as_ushort(__float2half_rz(w - __half2float(hi))) : __half_as_ushort(hi);
+      }
+      v = __uint_as_float(static_cast<unsigned>(hb[0]) | (static_cast<unsigned>(hb[1]) << 16));
     } else {
       // f16x3 sections: two halves per float slot
-      const int offs[5] = {L.h2a, L.h2b, L.h3, L.h4, L.total};
+      const int offs[5] = {L.h2a, L.h2b, L.h3, L.h4, L.hfc};
       const int cins[4] = {32, 32, 32, 16}, couts[4] = {32, 32, 16, cout4};
       int c = 0;
       while (q0 >= offs[c + 1]) ++c;
@@ -550,6 +565,7 @@ struct FcArgs {
   const float* act;   // (nets, N, 8192)
   float* partial;     // (nets, kFcSplit, N, 64)
   float* feat;        // (nets, N, 64)
+  int* range_flag;    // f16x3 path: OR-ed with 1 when an activation leaves the split range
   int N;
 };
 
@@ -576,6 +592,70 @@ __global__ __launch_bounds__(256) void fc_partial_kernel(FcArgs a) {
   if (tile * 16 + j < a.N) {
     float* p = a.partial + ((static_cast<size_t>(net) * kFcSplit + split) * a.N + tile * 16 + j) * kFeat + 16 * wave + 4 * q;
     *reinterpret_cast<f32x4*>(p) = acc0 + acc1;  // lane (j, q) reg r -> output 16*wave + 4q + r of image j
+  }
+}
+
+// The same split-K partial sums with f16x3 products (v_mfma_f32_32x32x16_f16): a wave owns 32
+// images x 64 outputs of one K slice; the activations are split on load (8 consecutive k per
+// lane = one B fragment), the weights come pre-split in fragment order (hfc section).  The f32
+// version above runs at a quarter of the f32-MFMA peak; this one is bound by reading the
+// activations once (134 MB per 2048 images x 2 encoders).
+__global__ __launch_bounds__(256) void fc_partial_f16x3_kernel(FcArgs a) {
+  constexpr Layout L = layout();
+  constexpr int KSTEPS = kFcK / kFcSplit / 16;  // 32
+  const int split = blockIdx.y, net = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int img0 = (blockIdx.x * 4 + wave) * 32;
+  if (img0 >= a.N) return;
+  const int img = min(img0 + j, a.N - 1);
+  const float* X = a.act + (static_cast<size_t>(net) * a.N + img) * kFcK + split * (kFcK / kFcSplit) + 8 * h;
+  const unsigned char* W = reinterpret_cast<const unsigned char*>(a.packed[net] + L.hfc) +
+                           static_cast<size_t>(split) * KSTEPS * 4096 + lane * 16;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+  float amax = 0.f;
+#pragma unroll 4
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    const f32x4 x0 = *reinterpret_cast<const f32x4*>(X + 16 * ks);
+    const f32x4 x1 = *reinterpret_cast<const f32x4*>(X + 16 * ks + 4);
+    const float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+    u32x4 hv, lv;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float v0 = xv[2 * p], v1 = xv[2 * p + 1];
+      amax = fmaxf(amax, fmaxf(fabsf(v0), fabsf(v1)));
+      const auto hh = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+      const f32x2 xs = {v0, v1};
+      const f32x2 hf = {static_cast<float>(hh[0]), static_cast<float>(hh[1])};
+      const f32x2 r = xs - hf;
+      const auto ll = __builtin_amdgcn_cvt_pkrtz(r[0], r[1]);
+      hv[p] = __builtin_bit_cast(unsigned, hh);
+      lv[p] = __builtin_bit_cast(unsigned, ll);
+    }
+    const half8 bhi = __builtin_bit_cast(half8, hv), blo = __builtin_bit_cast(half8, lv);
+    const unsigned char* wp = W + static_cast<size_t>(ks) * 4096;
+    const half8 a0hi = *reinterpret_cast<const half8*>(wp), a0lo = *reinterpret_cast<const half8*>(wp + 1024);
+    const half8 a1hi = *reinterpret_cast<const half8*>(wp + 2048), a1lo = *reinterpret_cast<const half8*>(wp + 3072);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0hi, bhi, acc0, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0hi, blo, acc0, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0lo, bhi, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1hi, bhi, acc1, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1hi, blo, acc1, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1lo, bhi, acc1, 0, 0, 0);
+  }
+  if (a.range_flag != nullptr && !(amax < 65504.0f)) atomicOr(a.range_flag, 1);
+  if (img0 + j < a.N) {
+    // lane (image j, h), register r of tile t -> output 32 t + (r & 3) + 8 (r >> 2) + 4 h
+    float* p = a.partial + ((static_cast<size_t>(net) * kFcSplit + split) * a.N + img0 + j) * kFeat + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v0 = {acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]};
+      const f32x4 v1 = {acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]};
+      *reinterpret_cast<f32x4*>(p + 8 * g) = v0;
+      *reinterpret_cast<f32x4*>(p + 32 + 8 * g) = v1;
+    }
   }
 }
 
@@ -721,7 +801,12 @@ extern "C" int mmf_image_encoder(const float* const* packed, int n_nets, const f
     MMF_CHECK_LAUNCH();
     return 0;
   }
-  fc_partial_kernel<<<dim3((N + 15) / 16, kFcSplit, n_nets), 256, 0, s>>>(f);
+  if (precision == MMF_PREC_F16X3) {
+    f.range_flag = range_flag;
+    fc_partial_f16x3_kernel<<<dim3((N + 127) / 128, kFcSplit, n_nets), 256, 0, s>>>(f);
+  } else {
+    fc_partial_kernel<<<dim3((N + 15) / 16, kFcSplit, n_nets), 256, 0, s>>>(f);
+  }
   MMF_CHECK_LAUNCH();
   fc_tail_kernel<false><<<dim3((N + 3) / 4, n_nets), 256, 0, s>>>(f);
   MMF_CHECK_LAUNCH();
