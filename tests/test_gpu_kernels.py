@@ -568,3 +568,46 @@ def test_pf_init_particles_matches_cholesky_sampling(N, M, d):
     f.noise = mmf.ReplayNoise([eps], [])
     with pytest.raises(ValueError):
         f.initialize_beliefs(mean=mean.to(dev), covariance=bad.to(dev))
+
+
+@pytest.mark.parametrize("task", ["door", "push"])
+def test_k2_full_size_cross_checks(task):
+    """BASELINE.json's full size (256 trajectories x 4096 particles = 1M rows), where the oracle
+    would take minutes: the f16x3 kernels (64-particle tiles, pipelined halves) against the exact
+    f32-MFMA kernels on the same inputs (two independent code paths, 1e-4 relative), bit-for-bit
+    repeatability, and no range flag."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine
+
+    dev = _cuda()
+    N, M = 256, 4096
+    d = om.TASKS[task].state_dim
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn((N, M, d), generator=g).to(dev)
+    u = torch.randn((N, 7), generator=g).to(dev)
+    eps = torch.randn((N, M, d), generator=g).to(dev)
+    obs = {"image": torch.randn((N, 32, 32), generator=g).clamp(-1, 1).to(dev),
+           "gripper_pos": torch.randn((N, 3), generator=g).to(dev),
+           "gripper_sensors": torch.randn((N, 7), generator=g).to(dev)}
+    torch.manual_seed(5)
+    pf = mmf.model_types(task)[f"{task.capitalize()}CrossmodalParticleFilter"]().to(dev).eval()
+    dyn, meas = pf.dynamics_model, pf.measurement_model
+    old = engine.DEFAULT_PRECISION
+    out = {}
+    try:
+        for prec in ("f16x3", "f32"):
+            engine.set_default_precision(prec)
+            ctx = dyn.encode_controls(u)
+            nxt = dyn.propagate_encoded(x, ctx, eps)
+            ll = meas(states=x, observations=obs)
+            out[prec] = (nxt.clone(), ll.clone())
+            if prec == "f16x3":
+                again = dyn.propagate_encoded(x, ctx, eps)
+                assert torch.equal(again, nxt)
+                assert torch.equal(meas(states=x, observations=obs), ll)
+                engine.check_range(dev)
+    finally:
+        engine.set_default_precision(old)
+    for a, b in zip(out["f16x3"], out["f32"]):
+        assert bool(torch.isfinite(a).all())
+        assert _rel_err(a.cpu(), b.cpu()) < 1e-4
