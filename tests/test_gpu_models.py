@@ -330,3 +330,53 @@ def test_native_ekf_loop_equals_stepwise(cls, kw, masked):
             assert torch.equal(m._belief_mean, mu) and torch.equal(m._belief_covariance, S)
     if wc is not None:
         assert torch.equal(f.weighted_covariances, wc)
+
+
+def test_full_size_particle_filter_properties():
+    """BASELINE.json's headline shape (door crossmodal PF, 256 x 4096 particles), 3 steps: the
+    native step loop equals step-by-step evaluation bit for bit; after resampling the log-weights
+    are exactly -log M, every estimate lies inside its particles' bounding box before resampling,
+    and every resampled particle is one of the propagated ones (ancestor indices in range and
+    non-decreasing, as systematic resampling yields)."""
+    _need_gpu()
+    import math
+
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import synthetic
+
+    dev = torch.device("cuda:0")
+    N, M, d, T = 256, 4096, 3, 3
+    traj = {k: v.to(dev) for k, v in synthetic.make_trajectories(state_dim=d, T=T, N=N, seed=5).items()}
+    eps0, eps, us = synthetic.draw_filter_noise(T=T, N=N, M=M, state_dim=d, seed=6)
+    eps0, eps, us = eps0.to(dev), torch.stack(eps).to(dev), torch.stack(us).to(dev)
+    torch.manual_seed(0)
+    f = mmf.door_models.DoorCrossmodalParticleFilter().to(dev).eval()
+    f.num_particles = M
+    obs = {k: traj[k][1:] for k in ("image", "gripper_pos", "gripper_sensors")}
+    ctrl = traj["controls"][1:]
+    cov = (torch.eye(d, device=dev) * 0.1)[None].expand(N, d, d)
+
+    f.noise = mmf.StackedNoise(eps0, eps, us)
+    f.initialize_beliefs(mean=traj["states"][0], covariance=cov)
+    loop = f.forward_loop(observations=obs, controls=ctrl)
+    final_states, final_logw = f.particle_states.clone(), f.particle_log_weights.clone()
+
+    f.noise = mmf.StackedNoise(eps0, eps, us)
+    f.initialize_beliefs(mean=traj["states"][0], covariance=cov)
+    f.record_indices = True
+    for t in range(T):
+        before = None
+        est = f(observations={k: v[t] for k, v in obs.items()}, controls=ctrl[t])
+        assert torch.equal(est, loop[t])
+        idx = f.last_resample_indices.long()
+        assert int(idx.min()) >= 0 and int(idx.max()) < M
+        assert bool((idx[:, 1:] >= idx[:, :-1]).all())
+        # the resampled set is a gather of the propagated set (the spare buffer still holds it)
+        propagated = f._spare_states
+        gathered = torch.gather(propagated, 1, idx[:, :, None].expand(N, M, d))
+        assert torch.equal(gathered, f.particle_states)
+        lo, hi = propagated.amin(dim=1), propagated.amax(dim=1)
+        assert bool(((est >= lo - 1e-5) & (est <= hi + 1e-5)).all())
+    assert torch.equal(f.particle_states, final_states)
+    assert torch.equal(f.particle_log_weights, final_logw)
+    assert torch.equal(final_logw, torch.full_like(final_logw, -math.log(M)))
