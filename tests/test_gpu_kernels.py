@@ -259,7 +259,7 @@ def precision(request):
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"], indirect=True)
 @pytest.mark.parametrize("task", ["door", "push"])
-@pytest.mark.parametrize("N,M", [(1, 1), (3, 5), (2, 64), (4, 300), (2, 4096), (40, 4096)])
+@pytest.mark.parametrize("N,M", [(1, 1), (3, 5), (2, 64), (4, 300), (2, 4096), (40, 4096), (33, 4001)])
 def test_k2_dynamics_and_measurement_match_oracle(task, N, M, precision):
     import multimodalfilter_amd as mmf
 
