@@ -136,7 +136,7 @@ def test_eval_mode_stays_on_the_hip_path(autograd_backend):
 
 
 @pytest.mark.parametrize("task,kind", [("door", "dynamics"), ("door", "measure"), ("push", "dynamics"), ("push", "measure")])
-@pytest.mark.parametrize("N,M", [(3, 40), (2, 64), (5, 7)])
+@pytest.mark.parametrize("N,M", [(3, 40), (2, 64), (5, 7), (9, 1000), (16, 4096)])
 def test_k6_particle_net_function_matches_autograd(task, kind, N, M):
     """K6: head outputs and every gradient (states, per-trajectory bias, all weights and biases)
     of ``engine.ParticleNetFunction`` against torch autograd through the same layers (fp64
@@ -169,15 +169,42 @@ def test_k6_particle_net_function_matches_autograd(task, kind, N, M):
     p64 = [p.detach().double().requires_grad_(True) for p in params]
     s64 = states.detach().double().requires_grad_(True)
     t64 = tbias.detach().double().requires_grad_(True)
-    relu = torch.relu
-    a = relu(s64 @ p64[0].t() + p64[1])
-    a = relu(a + relu(a @ p64[2].t() + p64[3]) @ p64[4].t() + p64[5])
+    # Among millions of pre-activations a few sit within fp32 rounding of zero, where an fp32
+    # forward and an fp64 one take different ReLU branches (one such particle moves a
+    # per-trajectory gradient by 1e-3).  For the large cases the reference therefore applies the
+    # masks the kernel's own forward produced (its stash: layer inputs > 0), so that only the
+    # arithmetic is compared; the small cases use plain ReLUs.
+    NL = 3 + 2 * net.n_res
+    masks = None
+    if R > 1000:
+        from multimodalfilter_amd import _abi
+        stash = torch.empty((NL + 1, R, 64), dtype=torch.float32, device=dev)
+        scratch = torch.empty((R, net.n_out), dtype=torch.float32, device=dev)
+        _abi.particle_net_train_forward(net.blob(_abi.PREC_F32), net.n_res, 0 if kind == "dynamics" else 1,
+                                        states.detach().contiguous(), tbias.detach().contiguous(), stash, scratch, N, M, d)
+        masks = (stash > 0).double()
+    layer = [0]
+
+    def relu(z):  # the output of every ReLU is the input of the next 64x64 layer (or of the head)
+        k = layer[0]
+        layer[0] += 1
+        return torch.relu(z) if masks is None else z * masks[k]
+
+    a = relu(s64 @ p64[0].t() + p64[1])                                   # stash[0]
+    h = relu(a @ p64[2].t() + p64[3])                                     # stash[1]
+    a = relu(a + h @ p64[4].t() + p64[5])                                 # stash[2]
     off = net.join_state_off
     jn = a @ p64[6][:, off:off + 64].t() + t64.repeat_interleave(M, dim=0)
-    a = relu(jn) if net.relu_after_join else jn
+    if net.relu_after_join:
+        a = relu(jn)                                                      # stash[3]
+    else:
+        a = jn
+        layer[0] += 1
     for i in range(net.n_res):
         w1, b1, w2, b2 = p64[7 + 4 * i: 11 + 4 * i]
-        a = relu(a + relu(a @ w1.t() + b1) @ w2.t() + b2)
+        h = relu(a @ w1.t() + b1)
+        a = relu(a + h @ w2.t() + b2)
+    assert layer[0] == NL + 1
     want_out = a @ p64[-2].t() + p64[-1]
     want = torch.autograd.grad(want_out, [s64, t64] + p64, gout.double())
 
