@@ -1,4 +1,4 @@
-for v in 0 3; do
+for v in 0 1 2 3; do
 MMF_K2_VARIANT=$v python bench.py --no-cpu-baseline --no-f32-mode --steps 64 2>&1 | tail -1 > gpurun_out/b.json
 python - <<PY
 import json
