@@ -41,12 +41,20 @@ def k2_kernel_name(d: int, prec: str) -> str:
 
 WORKLOADS = {
     "door_pf": dict(task="door", cls="DoorCrossmodalParticleFilter", kind="pf", batch=256, particles=4096,
-                    desc="door crossmodal particle filter, 4096 particles, batch 256 per GPU"),
+                    desc="door crossmodal particle filter"),
     "push_pf": dict(task="push", cls="PushCrossmodalParticleFilter", kind="pf", batch=256, particles=4096,
-                    desc="push crossmodal particle filter, 4096 particles, batch 256 per GPU"),
+                    desc="push crossmodal particle filter"),
     "door_ekf": dict(task="door", cls="DoorCrossmodalKalmanFilter", kind="ekf", batch=1024, particles=1,
-                     desc="door crossmodal EKF, batch 1024 trajectories per GPU"),
+                     desc="door crossmodal EKF"),
 }
+
+
+def workload_desc(wl, batch, particles, total_batch, world, scaling) -> str:
+    """Built from the numbers the run actually used (never a static string)."""
+    what = wl["desc"] + (f", {particles} particles" if wl["kind"] == "pf" else "")
+    if scaling == "strong":
+        return f"{what}, {total_batch} trajectories in total sharded over {world} GPU(s) (this rank: {batch})"
+    return f"{what}, batch {batch} trajectories per GPU x {world} GPU(s)"
 
 
 def pmc_traffic(kernel_key: str):
@@ -101,38 +109,96 @@ CPU_THREADS = 16  # measured on the GPU box's host (2 x EPYC 9575F, 256 hw threa
                   # step is fastest at 16 torch threads (8: 0.88x, 32: 0.84x, 64: 0.45x, 128: 0.24x)
 
 
-def cpu_baseline_pf(wl, engine_filter, state_dim, cores, sample_batch=32, sample_steps=12, warm=1):
-    """The oracle (pure torch, fp32, CPU) on a bounded sample of the same workload, with the
-    engine run on the identical sample (same weights, observations, noise) for parity."""
+def oracle_pf_run(cls, state_dict, traj, eps0, eps, us, M, *, mode="systematic", warm=0, keep_beliefs=True):
+    """The oracle particle filter (CPU) over ``traj`` on pre-drawn randomness.  Returns the
+    estimates ``(T, N, d)``, the seconds spent on the steps after ``warm``, and per step the
+    belief the oracle held BEFORE the step plus the ancestor indices it drew (references, not
+    copies: the oracle rebinds its belief tensors every step)."""
     from multimodalfilter_amd import synthetic
-    import multimodalfilter_amd as mmf
     from oracle import models as om
     from oracle.tf.base import ReplayNoise as OReplay
+
+    T = len(eps)
+    N, d = traj["states"].shape[1:]
+    oracle = om.build(cls, **({"resample_mode": mode} if mode != "systematic" else {}))
+    oracle.load_state_dict(state_dict)
+    oracle.eval()
+    oracle.num_particles = M
+    oracle.noise = OReplay([eps0] + list(eps), list(us))
+    obs = synthetic.observations_of(traj)
+    cov = (torch.eye(d) * 0.1)[None].expand(N, d, d)
+    ests, beliefs, ess, dt = [], [], [], 0.0
+    resample = oracle._resample
+
+    def resample_and_record_ess():  # effective sample size of the weights about to be resampled
+        w = torch.softmax(oracle.particle_log_weights, dim=1)
+        ess.append(float((1.0 / (w * w).sum(1)).mean()) / w.shape[1])
+        resample()
+
+    if keep_beliefs:
+        oracle._resample = resample_and_record_ess
+    with torch.no_grad():
+        oracle.initialize_beliefs(mean=traj["states"][0], covariance=cov)
+        for t in range(1, T + 1):
+            before = (oracle.particle_states, oracle.particle_log_weights)
+            t0 = time.perf_counter()
+            ests.append(oracle(observations={k: v[t] for k, v in obs.items()}, controls=traj["controls"][t]))
+            if t > warm:
+                dt += time.perf_counter() - t0
+            if keep_beliefs:
+                beliefs.append(before + (oracle.last_resample_indices, ess[-1]))
+    return torch.stack(ests), dt, beliefs
+
+
+def teacher_forced_parity(engine_filter, traj, eps, us, beliefs, want, M, *, mode="systematic"):
+    """Engine against oracle with the recursion's chaos taken out: before EVERY step the engine's
+    belief is overwritten with the belief the oracle held at that point, then one engine step
+    runs on the same noise.  What remains is kernel arithmetic: the posterior mean of that step
+    and the ancestor indices the resampler draws from log-weights that differ in the last ulp."""
+    import multimodalfilter_amd as mmf
+
+    dev = next(engine_filter.parameters()).device
+    f = engine_filter
+    N, d = traj["states"].shape[1:]
+    obs = {k: traj[k] for k in ("image", "gripper_pos", "gripper_sensors")}
+    f.num_particles, f.resample_mode = M, mode
+    rec, f.record_indices = f.record_indices, True
+    f.noise = mmf.ReplayNoise([torch.zeros((N, M, d))], [])
+    cov = (torch.eye(d, device=dev) * 0.1)[None].expand(N, d, d)
+    f.initialize_beliefs(mean=traj["states"][0].to(dev), covariance=cov)
+    scale = max(1.0, float(want.abs().max()))
+    errs, flips = [], []
+    for t, (S, W, idx, _) in enumerate(beliefs):
+        f.particle_states = S.to(dev).contiguous()
+        f.particle_log_weights = W.to(dev).contiguous()
+        f._spare_states = None
+        f.noise = mmf.ReplayNoise([eps[t]], [us[t]])
+        est = f(observations={k: v[t + 1].to(dev) for k, v in obs.items()}, controls=traj["controls"][t + 1].to(dev))
+        errs.append(float((est.cpu() - want[t]).abs().max()) / scale)
+        flips.append(int((f.last_resample_indices.cpu().long() != idx).sum()))
+    f.record_indices = rec
+    return {"max_rel_err_posterior_mean_per_step": errs,
+            "max_rel_err_posterior_mean": max(errs),
+            "resample_index_mismatches_per_step": flips,
+            "resample_index_mismatch_fraction": sum(flips) / float(len(beliefs) * N * M),
+            "oracle_ess_over_m_per_step": [round(b[3], 4) for b in beliefs]}
+
+
+def cpu_baseline_pf(wl, engine_filter, state_dim, cores, sample_batch=32, sample_steps=12, warm=1):
+    """The oracle (pure torch, fp32, CPU) on a bounded sample of the same workload, with the
+    engine run on the identical sample (same weights, observations, noise) for parity:
+    teacher-forced (kernel arithmetic, the 1e-4 bar) and free-running (both filters left alone
+    for the whole horizon; resampling flips at CDF boundaries decorrelate a few particles)."""
+    from multimodalfilter_amd import synthetic
 
     M = wl["particles"]
     T = sample_steps + warm
     torch.set_num_threads(cores)
     traj = synthetic.make_trajectories(state_dim=state_dim, T=T, N=sample_batch, seed=4242)
     eps0, eps, us = synthetic.draw_filter_noise(T=T, N=sample_batch, M=M, state_dim=state_dim, seed=4243)
-    oracle = om.build(wl["cls"])
-    oracle.load_state_dict({k: v.detach().cpu() for k, v in engine_filter.state_dict().items()})
-    oracle.eval()
-    oracle.num_particles = M
-    oracle.noise = OReplay([eps0] + eps, us)
-    obs = synthetic.observations_of(traj)
-    d = state_dim
-    cov = (torch.eye(d) * 0.1)[None].expand(sample_batch, d, d)
-    ests = []
-    with torch.no_grad():
-        oracle.initialize_beliefs(mean=traj["states"][0], covariance=cov)
-        for t in range(1, warm + 1):
-            ests.append(oracle(observations={k: v[t] for k, v in obs.items()}, controls=traj["controls"][t]))
-        t0 = time.perf_counter()
-        for t in range(warm + 1, T + 1):
-            ests.append(oracle(observations={k: v[t] for k, v in obs.items()}, controls=traj["controls"][t]))
-        dt = time.perf_counter() - t0
+    sd = {k: v.detach().cpu() for k, v in engine_filter.state_dict().items()}
+    want, dt, beliefs = oracle_pf_run(wl["cls"], sd, traj, eps0, eps, us, M, warm=warm)
     cpu_rate = sample_batch * M * sample_steps / dt
-    want = torch.stack(ests)
 
     dev = next(engine_filter.parameters()).device
     got = run_pf(engine_filter, to_device(traj, dev),
@@ -141,12 +207,16 @@ def cpu_baseline_pf(wl, engine_filter, state_dim, cores, sample_batch=32, sample
     rm_e = ((got - traj["states"][1:]) ** 2).mean((0, 1)).sqrt()
     rm_o = ((want - traj["states"][1:]) ** 2).mean((0, 1)).sqrt()
     parity = {
-        # step 1 isolates kernel arithmetic; later steps also carry the (rare) resampling
-        # flips that a 1e-7 log-likelihood difference can cause ("Parity")
-        "max_rel_err_posterior_mean_step1": float((got[0] - want[0]).abs().max()) / scale,
-        "max_rel_err_posterior_mean_all_steps": float((got - want).abs().max()) / scale,
-        "rmse_engine": [float(x) for x in rm_e], "rmse_oracle": [float(x) for x in rm_o],
-        "rmse_rel_diff": float(((rm_e - rm_o).abs() / rm_o).max()),
+        "teacher_forced": teacher_forced_parity(engine_filter, traj, eps, us, beliefs, want, M),
+        "free_running": {
+            # both filters run the whole horizon on their own beliefs: a 1e-7 difference in a
+            # log-likelihood occasionally moves a resampling position across a CDF boundary,
+            # after which a few particles differ ("Parity")
+            "max_rel_err_posterior_mean_step1": float((got[0] - want[0]).abs().max()) / scale,
+            "max_rel_err_posterior_mean_all_steps": float((got - want).abs().max()) / scale,
+            "rmse_engine": [float(x) for x in rm_e], "rmse_oracle": [float(x) for x in rm_o],
+            "rmse_rel_diff": float(((rm_e - rm_o).abs() / rm_o).max()),
+        },
     }
     return {"value": cpu_rate, "unit": "particle-steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle PF (oracle/), {wl['cls']}, batch {sample_batch} x {M} particles x "
@@ -186,6 +256,64 @@ def cpu_baseline_ekf(wl, engine_filter, state_dim, cores, sample_batch=256, samp
                       f"after {warm} warm-up, {dt:.1f} s"}, parity
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def launch_ranks(n_ranks: int, argv) -> int:
+    """``python bench.py --gpus N`` without a launcher around it: this process starts N fresh
+    children (one per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, the
+    same contract ``torch.distributed.run`` provides) and waits for them.  It never touches the
+    GPU itself -- no HIP call, no ``.so`` load -- and nothing is ever re-exec'ed.  Rank 0's JSON
+    line passes through on stdout.  Any non-zero child ends the others and becomes the exit code."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    procs = []
+    for r in range(n_ranks):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:  # exact PIDs of our own children only
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def dry_run(args):
+    """``MMF_BENCH_DRY=1``: the N-rank plumbing without the GPU work (CPU test of the launcher):
+    rendezvous, the same all-gather / max-over-ranks the real run uses, one JSON line from rank 0."""
+    from multimodalfilter_amd import distributed
+
+    rank, world, local = distributed.init_from_env()
+    if os.environ.get("MMF_BENCH_DRY") == f"fail{rank}":
+        raise SystemExit(3)
+    rows = distributed.all_gather_rows(torch.full((rank + 1, 2), float(rank)))
+    slowest = distributed.max_over_ranks(float(rank), torch.device("cpu"))
+    distributed.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "world_size_seen": world,
+                          "gathered_rows": int(rows.shape[0]), "max_over_ranks": slowest,
+                          "steps": args.steps, "warmup": args.warmup}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,7 +328,16 @@ def main():
                     help="arithmetic of the per-particle 64x64 layers (default: engine default)")
     ap.add_argument("--no-f32-mode", action="store_true",
                     help="skip the extra timed pass in exact-f32 mode")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="STRONG scaling: this many trajectories in total, sharded over the ranks "
+                         "(BASELINE config 4: --workload door_ekf --global-batch 8192)")
     args = ap.parse_args()
+
+    # N > 1 without a launcher: become the launcher (before the HIP library or the GPU is touched)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("MMF_BENCH_DRY"):
+        return dry_run(args)
 
     import multimodalfilter_amd as mmf
     from multimodalfilter_amd import _abi, distributed, engine, evaluation, synthetic
@@ -213,11 +350,11 @@ def main():
     if args.precision:
         engine.set_default_precision(args.precision)
     precision = engine.DEFAULT_PRECISION
-    rank, world, local = distributed.init_from_env()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+    rank, world, local = distributed.init_from_env()
     local_dev = local % torch.cuda.device_count()
     torch.cuda.set_device(local_dev)
     device = torch.device("cuda", local_dev)
@@ -227,6 +364,10 @@ def main():
         wl["batch"] = args.batch
     if args.particles:
         wl["particles"] = args.particles
+    scaling = "weak"
+    if args.global_batch:
+        lo, hi = distributed.shard_bounds(args.global_batch, rank, world)
+        wl["batch"], scaling = hi - lo, "strong"
     K, W, B, M = args.steps, args.warmup, wl["batch"], wl["particles"]
     spec = mmf.door_models._ns.task if wl["task"] == "door" else mmf.push_models._ns.task
     d = spec.state_dim
@@ -285,7 +426,8 @@ def main():
         f32_pass = timed_pass()
         engine.set_default_precision(precision)
 
-    units_per_step = B * M * world if wl["kind"] == "pf" else B * world
+    total_batch = args.global_batch if args.global_batch else B * world
+    units_per_step = total_batch * M if wl["kind"] == "pf" else total_batch
     value = units_per_step * K / elapsed
     rmse = evaluation.raw_rmse(mse_all)
 
@@ -296,13 +438,15 @@ def main():
         "value": value,
         "unit": "particle-steps/s" if wl["kind"] == "pf" else "trajectory-steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32" if precision == "f32" or wl["kind"] != "pf" else
                  "f32 via f16x3 (operands split into 2 f16 halves exact to 2^-22, 3 f16 MFMA products "
                  "per product, f32 accumulate)",
         "data": "synthetic",
-        "config": {"workload": wl["desc"], "filter": wl["cls"], "batch_per_gpu": B, "particles": M,
-                   "global_batch": B * world, "state_dim": d, "resample": "systematic",
+        "config": {"workload": workload_desc(wl, B, M, total_batch, world, scaling), "filter": wl["cls"],
+                   "batch_per_gpu": B, "particles": M,
+                   "global_batch": total_batch, "state_dim": d, "resample": "systematic",
+                   "world_size_seen": world,
                    "parallelism": f"trajectory-sharded x{world}"},
         "posterior_rmse_vs_truth": [float(x) for x in rmse],
         "traffic_source": "profiles/r01/pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "

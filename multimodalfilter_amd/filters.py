@@ -106,6 +106,30 @@ class ParticleFilter(base.Filter):
         reserve_memory(dev, nbytes)
         return nbytes
 
+    def _adapt_particle_count(self) -> None:
+        """Upstream torchfilter's particle-count adaptation for steps that do not resample
+        (the reference flips 30 <-> 300 in ``train()``,
+        ``/root/reference/crossmodal/door_models/pf.py:24-27``, so a train-mode step right after
+        an eval-mode belief lands here): the first ``(M_new // M) * M`` slots are whole copies of
+        the particle set, the rest a sample without replacement (one permutation shared by the
+        batch -- drawn from ``self.noise``: the arg-sort of ``M`` uniforms -- where upstream calls
+        ``torch.randperm``); log-weights are gathered alongside and re-normalised."""
+        N, M, d = self.particle_states.shape
+        Mo = int(self.num_particles)
+        dev = self.particle_states.device
+        copies = (Mo // M) * M
+        parts = []
+        if copies > 0:
+            parts.append(torch.arange(M, device=dev).repeat(copies // M))
+        if Mo - copies > 0:
+            perm = torch.argsort(self.noise.uniform((M,), like=self.particle_states), stable=True)
+            parts.append(perm[:Mo - copies])
+        idx = torch.cat(parts)[None, :].expand(N, Mo)
+        self.particle_states = torch.gather(self.particle_states, 1, idx[:, :, None].expand(N, Mo, d)).contiguous()
+        lw = torch.gather(self.particle_log_weights, 1, idx)
+        self.particle_log_weights = (lw - torch.logsumexp(lw, dim=1, keepdim=True)).contiguous()
+        self._spare_states = None
+
     # ------------------------------------------------------------------ one step
     def _propagate(self, controls, ctrl_ctx, N, M, d):
         eps = self.noise.gaussian((N, M, d), like=self.particle_states)
@@ -136,9 +160,8 @@ class ParticleFilter(base.Filter):
         N, M, d = self.particle_states.shape
         do_resample = (not self.training) if self.resample is None else bool(self.resample)
         if not do_resample and self.num_particles != M:
-            raise NotImplementedError(
-                "changing num_particles without resampling (upstream's copy / randperm "
-                "adaptation) is not implemented: call initialize_beliefs() after changing it")
+            self._adapt_particle_count()
+            N, M, d = self.particle_states.shape
 
         with torch.no_grad():
             states = self._propagate(controls, ctrl_ctx, N, M, d)
@@ -185,6 +208,9 @@ class ParticleFilter(base.Filter):
         assert self._initialized, "Particle filter not initialized!"
         N, M, d = self.particle_states.shape
         do_resample = (not self.training) if self.resample is None else bool(self.resample)
+        if not do_resample and self.num_particles != M:
+            self._adapt_particle_count()
+            N, M, d = self.particle_states.shape
         if engine.use_hip_backward() and hasattr(self.dynamics_model, "forward_particles"):
             # K6: the N*M-row network evaluates and differentiates in HIP
             pred = self.dynamics_model.forward_particles(states=self.particle_states, controls=controls,

@@ -434,8 +434,6 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
                 if self.add_R_noise[0] > 0:
                     cov = cov + torch.diag(self.add_R_noise).to(cov.device)
                 return z, torch.sqrt(cov)
-            if self.noise_R_tril is not None:
-                raise NotImplementedError("a fixed noise_R_tril is not supported by the HIP virtual sensor")
             d, U = self.state_dim, self.units
             if self._prog is None:
                 p = TrajProgram()
@@ -466,6 +464,15 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             t["tril"] = torch.empty((N, d, d), dtype=torch.float32, device=dev)
             self._prog.run(t, N)
             assert t["z"].shape == (N, self.state_dim)
+            if self.noise_R_tril is not None:
+                # a fixed measurement noise replaces the r head's output (kf.py:36-37,111-126): the
+                # reference feeds it through the same diag_embed / square / + add_R_noise / sqrt
+                lt = torch.diag_embed(self.noise_R_tril.to(device=dev, dtype=torch.float32))
+                assert lt.shape == (N, d, d)
+                cov = lt ** 2
+                if self.add_R_noise[0] > 0:
+                    cov = cov + torch.diag(self.add_R_noise).to(dev)
+                return t["z"], torch.sqrt(cov)
             return t["z"], t["tril"]
 
     VirtualSensorModel.__name__ = VirtualSensorModel.__qualname__ = f"{P}VirtualSensorModel"

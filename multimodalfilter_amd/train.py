@@ -19,6 +19,18 @@ import torch
 from . import distributed, engine
 from .utils import NoiseSource
 
+# initial-belief perturbations when neither the caller nor the filter brings a noise source: ONE
+# module-level generator that advances from step to step (upstream ``train_filter`` samples a
+# fresh ``MultivariateNormal`` per batch), seeded per data-parallel rank on first use
+_DEFAULT_NOISE = NoiseSource(20201025)
+
+
+def default_noise(filter_model) -> NoiseSource:
+    """The persistent source a training step draws from by default: the filter's own ``noise``
+    (particle filters carry one) or the module-level one -- never a fresh seed-0 generator."""
+    own = getattr(filter_model, "noise", None)
+    return own if type(own) is NoiseSource else _DEFAULT_NOISE  # replayed / stacked blocks are the steps' own
+
 
 def filter_loss(filter_model, batch: Dict[str, torch.Tensor], *, initial_covariance: torch.Tensor,
                 noise: Optional[NoiseSource] = None, measurement_initialize: bool = False) -> torch.Tensor:
@@ -32,7 +44,7 @@ def filter_loss(filter_model, batch: Dict[str, torch.Tensor], *, initial_covaria
     if measurement_initialize and hasattr(filter_model, "measurement_initialize_beliefs"):
         filter_model.measurement_initialize_beliefs({k: v[0] for k, v in obs.items()})
     else:
-        noise = noise if noise is not None else NoiseSource()
+        noise = noise if noise is not None else default_noise(filter_model)
         tril = torch.linalg.cholesky(initial_covariance.to(torch.float32))
         mean = states[0] + noise.gaussian((N, d), like=states) @ tril.t()
         filter_model.initialize_beliefs(mean=mean, covariance=initial_covariance[None].expand(N, d, d))

@@ -27,18 +27,34 @@ def tree_leading_shape(x: Any):
     return tuple(x.shape)
 
 
+def rank_seed(base_seed: int = 0) -> int:
+    """``base_seed`` offset by this process's data-parallel rank (``torch.distributed`` when
+    initialised, else torchrun's ``RANK``): ranks own different trajectories and must not
+    propagate them with identical noise streams."""
+    import os
+
+    import torch.distributed as dist
+
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else int(os.environ.get("RANK", "0"))
+    return int(base_seed) + 1_000_003 * rank
+
+
 class NoiseSource:
     """Every random draw of a filter goes through one of these, so that a CPU oracle and
-    the HIP engine can consume identical, pre-drawn tensors."""
+    the HIP engine can consume identical, pre-drawn tensors.  The generator is created on
+    first use (per device) from ``seed`` -- offset by the data-parallel rank unless
+    ``per_rank=False`` -- and then ADVANCES: consecutive draws are independent."""
 
-    def __init__(self, seed: int = 0, device=None):
+    def __init__(self, seed: int = 0, device=None, per_rank: bool = True):
         self.seed = seed
+        self.per_rank = per_rank
         self._gens = {}
 
     def _gen(self, device):
         key = str(device)
         if key not in self._gens:
-            self._gens[key] = torch.Generator(device=device).manual_seed(self.seed)
+            seed = rank_seed(self.seed) if self.per_rank else self.seed
+            self._gens[key] = torch.Generator(device=device).manual_seed(seed)
         return self._gens[key]
 
     def gaussian(self, shape, *, like: torch.Tensor) -> torch.Tensor:

@@ -102,6 +102,13 @@ def run_obs_only(model, inp, n, m, dark=False):
     return out
 
 
+def run_obs_fixed_noise(model, inp, n, m):
+    """Virtual sensor with ``noise_R_tril`` set: a fixed ``(N, d)`` diagonal replaces the learned
+    ``r`` head (``door_models/kf.py:36-37,111-115``)."""
+    model.noise_R_tril = _t(np.abs(inp["states0"][:n]) + np.float32(0.1))
+    return run_obs_only(model, inp, n, m)
+
+
 def run_encoder(model, inp, n, m):
     return {"feat": _np(model(_t(inp["image"][0, :n])[:, None]))}
 
@@ -207,6 +214,9 @@ def _cases() -> List[Case]:
         A(Case(f"virtual_sensor_{tag}",
                (lambda mods: lambda cm, t: _cls(cm, t, "VirtualSensorModel")(modalities=set(mods)))(mods),
                (lambda mods: lambda t: om.VirtualSensorModel(t, mods))(mods), run_obs_only))
+    A(Case("virtual_sensor_fixed_noise",
+           lambda cm, t: _cls(cm, t, "VirtualSensorModel")(),
+           lambda t: om.VirtualSensorModel(t), run_obs_fixed_noise))
     # R4 weight model, blackout off/on
     A(Case("pf_weight_model",
            lambda cm, t: getattr(_pkg(cm, t).crossmodal_pf, f"{t.name.capitalize()}CrossmodalWeightModel")(know_image_blackout=False),

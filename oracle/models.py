@@ -244,9 +244,10 @@ class VirtualSensorModel(tf.base.VirtualSensorModel, _ObservationEncoders):
     ``push_models/kf.py:31-128``)."""
 
     def __init__(self, task: TaskSpec, modalities=MODALITIES, units: int = 64,
-                 add_R_noise: float = 1e-6):
+                 add_R_noise: float = 1e-6, noise_R_tril: torch.Tensor = None):
         super().__init__(state_dim=task.state_dim)
         d = task.state_dim
+        self.noise_R_tril = noise_R_tril  # fixed (N, d) diagonal replacing the r head (kf.py:36-37,111-115)
         self._build_encoders(task, modalities, units, spanning_pool=task.vs_image_spanning_pool)
         self.shared_layers = nn.Sequential(
             nn.Linear(units * len(self.modalities), 2 * units),
@@ -266,8 +267,9 @@ class VirtualSensorModel(tf.base.VirtualSensorModel, _ObservationEncoders):
     def forward(self, *, observations):
         shared = self.shared_layers(self.encode_observations(observations))
         z = self.z_layer(shared[:, : self.units])
-        r_hat = self.r_layer(shared[:, self.units:])
+        r_hat = self.r_layer(shared[:, self.units:]) if self.noise_R_tril is None else self.noise_R_tril
         R = torch.diag_embed(r_hat) ** 2
+        assert R.shape == (z.shape[0], self.state_dim, self.state_dim)
         if self.add_R_noise > 0:
             R = R + self.add_R_noise * torch.eye(self.state_dim, dtype=R.dtype, device=R.device)
         return z, torch.sqrt(R)

@@ -58,9 +58,9 @@ class ParticleFilter(base.Filter):
         assert self._initialized, "initialize_beliefs() first"
         N, M, d = self.particle_states.shape
         do_resample = (not self.training) if self.resample is None else self.resample
-        assert do_resample or self.num_particles == M, (
-            "particle-count adaptation without resampling is not restated"
-        )
+        if not do_resample and self.num_particles != M:
+            self._adapt_particle_count()
+            N, M, d = self.particle_states.shape
 
         # propagate: same control for each of a trajectory's M particles
         flat = self.particle_states.reshape(N * M, d)
@@ -87,6 +87,25 @@ class ParticleFilter(base.Filter):
         if do_resample:
             self._resample()
         return estimate
+
+    def _adapt_particle_count(self):
+        """Upstream's adaptation when a non-resampling step finds ``num_particles != M``
+        (SURVEY.md A.2): whole copies of the set first, then a sample without replacement shared
+        by the batch; weights gathered and re-normalised.  Upstream draws the permutation with
+        ``torch.randperm`` (global RNG); here it is the arg-sort of ``M`` explicit uniforms."""
+        N, M, d = self.particle_states.shape
+        Mo = int(self.num_particles)
+        copies = (Mo // M) * M
+        parts = []
+        if copies > 0:
+            parts.append(torch.arange(M).repeat(copies // M))
+        if Mo - copies > 0:
+            u = self.noise.uniform((M,), like=self.particle_log_weights)
+            parts.append(torch.argsort(u, stable=True)[: Mo - copies])
+        idx = torch.cat(parts)[None, :].expand(N, Mo)
+        self.particle_states = torch.gather(self.particle_states, 1, idx[:, :, None].expand(N, Mo, d))
+        lw = torch.gather(self.particle_log_weights, 1, idx)
+        self.particle_log_weights = lw - torch.logsumexp(lw, dim=1, keepdim=True)
 
     def _resample(self):
         N, M, d = self.particle_states.shape

@@ -139,3 +139,39 @@ def test_gradient_all_reduce_averages_over_ranks(tmp_path):
     for a, b, r0, r1 in zip(g0["local"], g1["local"], g0["reduced"], g1["reduced"]):
         torch.testing.assert_close(r0, (a + b) / 2)
         torch.testing.assert_close(r1, r0)
+
+
+def _run_bench(extra_env, *argv):
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env,
+                          capture_output=True, text=True, timeout=240)
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launches_n_ranks():
+    """``python bench.py --gpus 2`` as the driver invokes it for N > 1 when no launcher wraps it:
+    the parent spawns 2 ranks (gloo here), rank 0 prints ONE JSON line carrying ``n_gpus: 2``
+    and the world size the process group reported."""
+    import json
+
+    r = _run_bench({"MMF_BENCH_DRY": "1", "MMF_DIST_BACKEND": "gloo"}, "--gpus", "2", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size_seen"] == 2
+    assert out["gathered_rows"] == 3 and out["max_over_ranks"] == 1.0  # ragged all-gather: 1 + 2 rows
+    assert out["steps"] == 3 and out["warmup"] == 1
+
+
+@pytest.mark.timeout(300)
+def test_bench_launcher_propagates_a_failing_rank():
+    r = _run_bench({"MMF_BENCH_DRY": "fail1", "MMF_DIST_BACKEND": "gloo"}, "--gpus", "2")
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -73,6 +73,7 @@ def _product(case_name: str, task: om.TaskSpec):
         "filter_kf_meas_crossmodal": lambda: g("MeasurementCrossmodalKalmanFilter")(),
         "filter_kf_meas_unimodal": lambda: g("MeasurementUnimodalKalmanFilter")(),
     }
+    table["virtual_sensor_fixed_noise"] = lambda: g("VirtualSensorModel")()
     for tag, m in mods.items():
         table[f"pf_measurement_{tag}"] = (lambda m: lambda: g("MeasurementModel")(modalities=set(m)))(m)
         table[f"virtual_sensor_{tag}"] = (lambda m: lambda: g("VirtualSensorModel")(modalities=set(m)))(m)

@@ -191,3 +191,41 @@ def test_reweight_resample_none_mode_matches_logsumexp():
     np.testing.assert_allclose(lwo, want.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(est, (want.exp()[:, :, None] * torch.from_numpy(x)).sum(1).numpy(), rtol=1e-5, atol=1e-6)
     assert idx is None
+
+
+def test_particle_count_adaptation_without_resampling():
+    """eval (300 particles) -> train (30) -> eval-sized again with ``resample=False``: upstream's
+    copy / sample-without-replacement adaptation keeps the weights normalised, draws every new
+    particle from the old set, and expanding by whole copies leaves the estimate unchanged."""
+    A, B, L, Rt = _system()
+    d, N = 3, 4
+    pf = tf.filters.ParticleFilter(dynamics_model=LinearDynamics(A, B, L), measurement_model=GaussianLik(d, Rt @ Rt.T),
+                                   num_particles=300, resample=False)
+    pf.noise = NoiseSource(7)
+    g = torch.Generator().manual_seed(8)
+    pf.initialize_beliefs(mean=torch.zeros(N, d), covariance=(0.1 * torch.eye(d))[None].expand(N, d, d))
+    step = lambda: pf(observations={"z": 0.3 * torch.randn(N, d, generator=g)}, controls=torch.randn(N, 7, generator=g))
+    step()
+    old = pf.particle_states.clone()
+    pf.num_particles = 30  # shrink: a sample without replacement, shared by the batch
+    step()
+    assert pf.particle_states.shape == (N, 30, d) and pf.particle_log_weights.shape == (N, 30)
+    torch.testing.assert_close(torch.logsumexp(pf.particle_log_weights, 1), torch.zeros(N), atol=1e-5, rtol=0)
+    before = pf.particle_states.clone(), pf.particle_log_weights.clone()
+    pf.num_particles = 75  # expand: two whole copies + 15 without replacement
+    pf._adapt_particle_count()
+    S, W = pf.particle_states, pf.particle_log_weights
+    assert S.shape == (N, 75, d)
+    assert torch.equal(S[:, :30], before[0]) and torch.equal(S[:, 30:60], before[0])
+    for n in range(N):
+        rows = {tuple(r.tolist()) for r in before[0][n]}
+        tail = [tuple(r.tolist()) for r in S[n, 60:]]
+        assert set(tail) <= rows and len(set(tail)) == 15
+    torch.testing.assert_close(torch.logsumexp(W, 1), torch.zeros(N), atol=1e-5, rtol=0)
+    pf.num_particles = 60  # whole copies only: the weighted mean is unchanged
+    pf.particle_states, pf.particle_log_weights = before
+    mean = (before[1].exp()[:, :, None] * before[0]).sum(1)
+    pf._adapt_particle_count()
+    torch.testing.assert_close((pf.particle_log_weights.exp()[:, :, None] * pf.particle_states).sum(1), mean,
+                               atol=1e-6, rtol=1e-5)
+    del old
