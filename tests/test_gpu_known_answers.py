@@ -138,7 +138,7 @@ def test_engine_pf_with_user_models_tracks_oracle_and_kalman(mode):
     posterior means within 1e-4 of the oracle's at every step (4 steps of resampling), resample
     indices equal except where a last-ulp difference between the GPU's and the CPU's torch
     arithmetic of the USER model moves a position across a CDF boundary (bound: 1e-3 of them),
-    and both within Monte-Carlo distance (0.02, M = 16,384) of the Kalman closed form."""
+    and both within Monte-Carlo distance (0.04 ~ 4 sigma at M = 16,384) of the Kalman closed form."""
     import multimodalfilter_amd as mmf
 
     dev = _dev()
@@ -181,7 +181,7 @@ def test_engine_pf_with_user_models_tracks_oracle_and_kalman(mode):
         differ += int((f.last_resample_indices.cpu().long() != want_idx[t]).sum())
         for n in range(N):
             kf = _kalman_closed_form(A, B, L, Rt, mu0[n], 0.1 * torch.eye(d), us[:, n], zs[:, n])
-            assert float((est[n].double() - kf[t][0]).abs().max()) < 0.02, (n, t)
+            assert float((est[n].double() - kf[t][0]).abs().max()) < 0.04, (n, t)
     assert differ <= 1e-3 * T * N * M, f"{differ} of {T * N * M} resample indices differ"
 
     # forward_loop on user models = the Python step loop: same numbers
