@@ -57,6 +57,8 @@ struct Layout {
   int w1, b1, w2a, b2a, w2b, b2b, w3, b3, w4, b4, fcw, fcb, r1t, r1b, r2t, r2b;
   int h2a, h2b, h3, h4;  // f16x3 fragment-ordered copies of the 3x3 convolutions' weights
   int hfc;               // f16x3 fragment-ordered copy of the 8192 -> 64 linear layer's weights
+  int hs;                // f16x3 5x5 stem as 2 k-steps of 16 taps: [k-step][hi|lo][lane][8 halves]
+  int g3;                // f16x3 conv 32->16 for v_mfma_f32_16x16x32_f16: [tap][hi|lo][lane][8 halves]
   int total;
 };
 // floats (= halves / 2) of a 3x3 conv in f16x3 fragment order [tap][kc][hi|lo][lane][8 halves]
@@ -85,6 +87,8 @@ __host__ __device__ constexpr Layout layout() {
   L.h3 = o; o += conv_h_floats(32);
   L.h4 = o; o += conv_h_floats(16);
   L.hfc = o; o += kFcSplit * (kFcK / kFcSplit / 16) * 2 * 2 * 64 * 8 / 2;  // [split][k-step][tile][hi|lo][lane][8 halves]
+  L.hs = o; o += 2 * 2 * 64 * 8 / 2;
+  L.g3 = o; o += 9 * 2 * 64 * 8 / 2;
   L.total = o;
   return L;
 }
@@ -157,6 +161,25 @@ __global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ o
       v = d.res_w[1][o * kFeat + k];
     } else if (q0 < L.h2a) {
       v = d.res_b[1][q0 - L.r2b];
+    } else if (q0 >= L.hs) {
+      // fused path: stem (element i of lane (co, h) in k-step s = tap 16 s + 8 h + i, zero past 24) and
+      // conv 32->16 in 16x16x32 fragments (element i of lane (co, q) for a tap = input channel 8 q + i)
+      const bool stem = q0 < L.g3;
+      unsigned short hb[2];
+      for (int z = 0; z < 2; ++z) {
+        const int he = 2 * (q0 - (stem ? L.hs : L.g3)) + z;
+        const int i = he & 7, lane = (he >> 3) & 63, part = (he >> 9) & 1, blk = he >> 10;
+        float w;
+        if (stem) {
+          const int t = 16 * blk + 8 * (lane >> 5) + i;
+          w = t < 25 ? d.conv_w[0][(lane & 31) * 25 + t] : 0.f;
+        } else {
+          w = d.conv_w[3][((lane & 15) * 32 + 8 * (lane >> 4) + i) * 9 + blk];
+        }
+        const __half hi = __float2half_rz(w);
+        hb[z] = part ? __half_as_ushort(__float2half_rz(w - __half2float(hi))) : __half_as_ushort(hi);
+      }
+      v = __uint_as_float(static_cast<unsigned>(hb[0]) | (static_cast<unsigned>(hb[1]) << 16));
     } else if (q0 >= L.hfc) {
       // f16x3 linear layer: element i of lane (row, h) in k-step ks of split sp is W[32 tile + row][512 sp + 16 ks + 8 h + i]
       unsigned short hb[2];
@@ -715,6 +738,8 @@ int launch_conv(const ConvArgs& a, int nets, hipStream_t s) {
   return 0;
 }
 
+#include "image_encoder_fused.inc"
+
 }  // namespace
 
 extern "C" size_t mmf_image_encoder_floats(void) { return static_cast<size_t>(layout().total); }
@@ -761,10 +786,24 @@ extern "C" int mmf_image_encoder(const float* const* packed, int n_nets, const f
   }
   c.N = N;
   int rc;
-  // conv 1 -> 32, k5, ReLU                      images -> A
-  c.in = images; c.in_net_stride = 0; c.skip = nullptr; c.out = bufA; c.woff = L.w1; c.boff = L.b1;
-  if ((rc = launch_conv<1, 32, 5, true, false>(c, n_nets, s))) return rc;
-  if (precision == MMF_PREC_F16X3) {
+  if (precision == MMF_PREC_F16X3 && !getenv("MMF_K4_UNFUSED")) {
+    // fused path (image_encoder_fused.inc): image -> B (bufA), B -> D (bufB), D -> E (bufC)
+    FusedArgs fa{};
+    for (int i = 0; i < n_nets; ++i) fa.packed[i] = packed[i];
+    fa.images = images; fa.N = N; fa.range_flag = range_flag;
+    fa.out = bufA;
+    if ((rc = launch_fused(fa, n_nets, 0, s))) return rc;
+    fa.bin = bufA; fa.out = bufB;
+    if ((rc = launch_fused(fa, n_nets, 1, s))) return rc;
+    ConvHArgs hcv{};
+    for (int i = 0; i < n_nets; ++i) hcv.packed[i] = packed[i];
+    hcv.N = N; hcv.range_flag = range_flag;
+    hcv.in = bufB; hcv.skip = nullptr; hcv.out = bufC; hcv.hoff = L.h4; hcv.boff = L.b4;
+    if ((rc = launch_conv_h<16, 8, false, false>(hcv, n_nets, s))) return rc;
+    bufB = bufC;  // the linear tail reads E
+  } else if (precision == MMF_PREC_F16X3) {
+    c.in = images; c.in_net_stride = 0; c.skip = nullptr; c.out = bufA; c.woff = L.w1; c.boff = L.b1;
+    if ((rc = launch_conv<1, 32, 5, true, false>(c, n_nets, s))) return rc;
     ConvHArgs hcv{};
     for (int i = 0; i < n_nets; ++i) hcv.packed[i] = packed[i];
     hcv.N = N; hcv.range_flag = range_flag;
@@ -777,6 +816,9 @@ extern "C" int mmf_image_encoder(const float* const* packed, int n_nets, const f
     hcv.in = bufA; hcv.out = bufB; hcv.hoff = L.h4; hcv.boff = L.b4;
     if ((rc = launch_conv_h<16, 8, false, false>(hcv, n_nets, s))) return rc;
   } else {
+  // conv 1 -> 32, k5, ReLU                      images -> A
+  c.in = images; c.in_net_stride = 0; c.skip = nullptr; c.out = bufA; c.woff = L.w1; c.boff = L.b1;
+  if ((rc = launch_conv<1, 32, 5, true, false>(c, n_nets, s))) return rc;
   // ResConv block1: conv 32 -> 32, ReLU          A -> B
   c.in = bufA; c.in_net_stride = static_cast<long long>(N) * 32 * kImg * kImg; c.out = bufB;
   c.woff = L.w2a; c.boff = L.b2a;
