@@ -17,7 +17,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # particle_net.hip: with the SLP vectoriser on, the f16x3 operand split (x - float(hi) -> f16)
 # becomes cvt + cvt + v_pk_add_f32 + cvt; without it the same source selects
 # v_fma_mixlo_f16 / v_fma_mixhi_f16 (2 instructions per pair fewer; K2 is VALU-issue bound)
-EXTRA_FLAGS = {"particle_net.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"particle_net.hip": ["-fno-slp-vectorize"], "image_encoder.hip": ["-fno-slp-vectorize"]}
 OBJ = os.path.join(CSRC, "_obj")
 
 
