@@ -33,6 +33,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half2v = __attribute__((ext_vector_type(2))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 constexpr int kImg = 32;         // images are 32 x 32
@@ -176,8 +177,8 @@ __global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ o
         } else {
           w = d.conv_w[3][((lane & 15) * 32 + 8 * (lane >> 4) + i) * 9 + blk];
         }
-        const __half hi = __float2half_rz(w);
-        hb[z] = part ? __half_as_ushort(__float2half_rz(w - __half2float(hi))) : __half_as_ushort(hi);
+        const __half hi = __float2half_rn(w);
+        hb[z] = part ? __half_as_ushort(__float2half_rn(w - __half2float(hi))) : __half_as_ushort(hi);
       }
       v = __uint_as_float(static_cast<unsigned>(hb[0]) | (static_cast<unsigned>(hb[1]) << 16));
     } else if (q0 >= L.hfc) {
@@ -189,8 +190,8 @@ __global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ o
         const int ks = rest % (kFcK / kFcSplit / 16), sp = rest / (kFcK / kFcSplit / 16);
         const int o = 32 * tile + (lane & 31), k = sp * (kFcK / kFcSplit) + 16 * ks + 8 * (lane >> 5) + i;
         const float w = fc_in == kFcK ? d.fc_w[static_cast<size_t>(o) * kFcK + k] : 0.f;
-        const __half hi = __float2half_rz(w);
-        hb[z] = part ? __half_as_ushort(__float2half_rz(w - __half2float(hi))) : __half_as_ushort(hi);
+        const __half hi = __float2half_rn(w);
+        hb[z] = part ? __half_as_ushort(__float2half_rn(w - __half2float(hi))) : __half_as_ushort(hi);
       }
       v = __uint_as_float(static_cast<unsigned>(hb[0]) | (static_cast<unsigned>(hb[1]) << 16));
     } else {
@@ -208,8 +209,8 @@ __global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ o
         const int kc = rest % KC, tap = rest / KC;
         const int co = lane & 31, ci = 16 * kc + 8 * (lane >> 5) + i;
         const float w = co < cout ? W[(co * cin + ci) * 9 + tap] : 0.f;
-        const __half hi = __float2half_rz(w);
-        hb[z] = part ? __half_as_ushort(__float2half_rz(w - __half2float(hi))) : __half_as_ushort(hi);
+        const __half hi = __float2half_rn(w);
+        hb[z] = part ? __half_as_ushort(__float2half_rn(w - __half2float(hi))) : __half_as_ushort(hi);
       }
       v = __uint_as_float(static_cast<unsigned>(hb[0]) | (static_cast<unsigned>(hb[1]) << 16));
     }
@@ -463,11 +464,11 @@ __global__ __launch_bounds__(BAND * 32) void conv_f16x3_kernel(ConvHArgs a) {
           for (int p = 0; p < 4; ++p) {
             const float x0 = inside ? pf[it][2 * p][px] : 0.f, x1 = inside ? pf[it][2 * p + 1][px] : 0.f;
             amax = fmaxf(amax, fmaxf(fabsf(x0), fabsf(x1)));
-            const auto hh = __builtin_amdgcn_cvt_pkrtz(x0, x1);
             const f32x2 xs = {x0, x1};
+            const half2v hh = __builtin_convertvector(xs, half2v);  // round to nearest even
             const f32x2 hf = {static_cast<float>(hh[0]), static_cast<float>(hh[1])};
             const f32x2 r = xs - hf;
-            const auto ll = __builtin_amdgcn_cvt_pkrtz(r[0], r[1]);
+            const half2v ll = __builtin_convertvector(r, half2v);
             hv[p] = __builtin_bit_cast(unsigned, hh);
             lv[p] = __builtin_bit_cast(unsigned, ll);
           }
@@ -649,11 +650,11 @@ __global__ __launch_bounds__(256) void fc_partial_f16x3_kernel(FcArgs a) {
     for (int p = 0; p < 4; ++p) {
       const float v0 = xv[2 * p], v1 = xv[2 * p + 1];
       amax = fmaxf(amax, fmaxf(fabsf(v0), fabsf(v1)));
-      const auto hh = __builtin_amdgcn_cvt_pkrtz(v0, v1);
       const f32x2 xs = {v0, v1};
+      const half2v hh = __builtin_convertvector(xs, half2v);  // round to nearest even
       const f32x2 hf = {static_cast<float>(hh[0]), static_cast<float>(hh[1])};
       const f32x2 r = xs - hf;
-      const auto ll = __builtin_amdgcn_cvt_pkrtz(r[0], r[1]);
+      const half2v ll = __builtin_convertvector(r, half2v);
       hv[p] = __builtin_bit_cast(unsigned, hh);
       lv[p] = __builtin_bit_cast(unsigned, ll);
     }

@@ -61,7 +61,7 @@ __host__ __device__ constexpr int kmap16(int s, int h, int i) {
 }
 
 __device__ __forceinline__ unsigned short f16_bits_rz(float x) {
-  return __half_as_ushort(__float2half_rz(x));
+  return __half_as_ushort(__float2half_rn(x));
 }
 
 __global__ void pack_particle_net_kernel(MmfParticleNetDesc d, float* __restrict__ out, int precision) {
@@ -92,7 +92,7 @@ __global__ void pack_particle_net_kernel(MmfParticleNetDesc d, float* __restrict
           const int he = 2 * e + z;
           const int i = he & 7, lane = (he >> 3) & 63, part = (he >> 9) & 1, s = (he >> 10) & 3, t = he >> 12;
           const float w = W[(32 * t + (lane & 31)) * stride + coff + kmap16(s, lane >> 5, i)];
-          const __half hi = __float2half_rz(w);
+          const __half hi = __float2half_rn(w);
           hb[z] = part ? f16_bits_rz(w - __half2float(hi)) : __half_as_ushort(hi);
         }
         v = __uint_as_float(static_cast<unsigned>(hb[0]) | (static_cast<unsigned>(hb[1]) << 16));
@@ -244,11 +244,13 @@ struct SplitAct {
 // cvt_pkrtz + 2 cvt_f32_f16 + pk_add + cvt_pkrtz.  (v_fma_mixlo/hi_f16 would fold the final
 // conversion as well but issue at half rate on gfx950: scripts/ubench/valu_rate.hip.)
 // x - hi is exact in fp32 (the residual has <= 13 significant bits).
+using half2v = __attribute__((ext_vector_type(2))) _Float16;
+using f32x2v = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ void split_pair(float x0, float x1, float neg_one, unsigned& hi, unsigned& lo) {
-  const auto h = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+  const half2v h = __builtin_convertvector(f32x2v{x0, x1}, half2v);  // v_cvt_pk_f16_f32: round to nearest even
   const float r0 = __builtin_fmaf(static_cast<float>(h[0]), neg_one, x0);
   const float r1 = __builtin_fmaf(static_cast<float>(h[1]), neg_one, x1);
-  const auto l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+  const half2v l = __builtin_convertvector(f32x2v{r0, r1}, half2v);
   hi = __builtin_bit_cast(unsigned, h);
   lo = __builtin_bit_cast(unsigned, l);
 }
@@ -692,8 +694,15 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
     float mine[NOUT];
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
-      if (CT == 2) mine[o] = h ? out[o][CT - 1] : out[o][0];
-      else mine[o] = out[o][0];
+      if (CT == 2) {
+        // a plain `h ? out[o][1] : out[o][0]` is canonicalised into a dynamically indexed array,
+        // i.e. a round trip through scratch (12-48 B/lane); pin both values in VGPRs first
+        float lo_col = out[o][0], hi_col = out[o][CT - 1];
+        asm volatile("" : "+v"(lo_col), "+v"(hi_col));
+        mine[o] = h ? hi_col : lo_col;
+      } else {
+        mine[o] = out[o][0];
+      }
     }
     const int my_row = base + (CT == 2 ? lane : j);
     const bool active = my_row < a.R && (CT == 2 || h == 0);

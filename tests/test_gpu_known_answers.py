@@ -361,3 +361,30 @@ def test_particle_count_adaptation_matches_oracle():
     assert float((got - want).abs().max()) / scale < REL_TOL
     assert float((S_e - S_o).abs().max()) / max(1.0, float(S_o.abs().max())) < REL_TOL
     assert float((W_e - W_o).abs().max()) < 1e-4
+
+
+def test_f16x3_error_against_fp64_within_2x_of_exact_f32_products_at_full_size():
+    """The split-f16 arithmetic (default) against the exact-fp32-product mode, both measured
+    against an fp64 evaluation of the same networks on the same fp32 inputs at BASELINE's size
+    (256 x 4096 rows): dynamics (un-stabilised random init) and both measurement networks of the
+    door crossmodal PF.  Both modes sit two orders below the 1e-4 bar, and f16x3's worst error is
+    within 2x of the f32 mode's on every network -- the condition under which ``bench.py`` reports
+    the f16x3 throughput as the unqualified number."""
+    import bench
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import synthetic
+
+    dev = _dev()
+    N, M, d = 256, 4096, 3
+    wl = dict(bench.WORKLOADS["door_pf"])
+    torch.manual_seed(0)
+    f = mmf.door_models.DoorCrossmodalParticleFilter().to(dev).eval()
+    traj = {k: v.to(dev) for k, v in synthetic.make_trajectories(state_dim=d, T=2, N=N, seed=11).items()}
+    cal_states = traj["states"][0][:, None, :] + 0.3 * torch.randn((N, 256, d), device=dev)
+    synthetic.calibrate_measurement_heads(f, {k: traj[k][0] for k in ("image", "gripper_pos", "gripper_sensors")}, cal_states)
+    r = bench.precision_errors(wl, f, traj, N, M)
+    print(r)
+    for mode in ("f32", "f16x3"):
+        for net, e in r[mode].items():
+            assert e["max_rel"] < 1e-5, (mode, net, e)
+    assert max(r["f16x3_over_f32_max_err"].values()) <= 2.0, r["f16x3_over_f32_max_err"]
