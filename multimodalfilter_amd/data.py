@@ -19,7 +19,8 @@ What it restates (host-side numpy; nothing here is on the timed path):
 
 Reading the recordings themselves needs ``h5py`` (``load_hdf5``); the container this was built in
 has neither ``h5py`` nor the datasets (Drive URLs, ``tasks/_door.py:11-20``), so that one function
-is untested.
+is exercised only through a stand-in ``h5py`` module (``tests/test_data_cpu.py``).  Everything after
+the file read is pinned against the reference's own loaders (``tests/golden/loaders.npz``).
 """
 from dataclasses import dataclass
 from typing import Dict, Iterator, List, Optional, Sequence, Tuple
@@ -128,9 +129,19 @@ def controls_from_end_effector(eef_positions: np.ndarray, contact: np.ndarray) -
 def trajectory_from_raw(raw: Dict[str, np.ndarray], spec: DatasetSpec, *, use_vision: bool = True,
                         use_proprioception: bool = True, use_haptics: bool = True,
                         image_blackout_ratio: float = 0.0, sequential_image_rate: int = 1,
-                        start_timestep: int = 0, rng: Optional[np.random.Generator] = None) -> TrajectoryNumpy:
+                        start_timestep: int = 0, rng: Optional[np.random.Generator] = None,
+                        reference_aliasing: bool = True) -> TrajectoryNumpy:
     """One recorded trajectory (dict of ``(T, ...)`` arrays as stored in the HDF5 files) -> the
-    normalised ``TrajectoryNumpy`` the reference's ``_load_trajectories`` appends."""
+    normalised ``TrajectoryNumpy`` the reference's ``_load_trajectories`` appends
+    (pinned by ``tests/golden/loaders.npz``: the reference's own loaders run on synthetic
+    recordings, ``oracle/capture_golden.py``).
+
+    ``reference_aliasing`` (quirk, default preserved): in the reference ``observations
+    ["gripper_pos"]`` IS the raw end-effector array (``tasks/_door.py:150``,
+    ``tasks/_push.py:178-181``), so ``use_proprioception=False`` zeroes the positions the controls
+    are built from as well: controls become ``[0, 0, 0, 0, 0, 0, contact]`` before z-scoring.
+    ``False`` keeps the real positions in the controls.  ``rng``: anything with
+    ``uniform(size=)`` (``np.random.RandomState`` reproduces the reference's global-RNG draws)."""
     T = len(raw[spec.state_columns[0][0]])
     states = np.stack([raw[k][:, c] for k, c in spec.state_columns], axis=1).astype(F32)
 
@@ -155,13 +166,15 @@ def trajectory_from_raw(raw: Dict[str, np.ndarray], spec: DatasetSpec, *, use_vi
     image *= image_mask(T, use_vision=use_vision, image_blackout_ratio=image_blackout_ratio,
                         sequential_image_rate=sequential_image_rate, rng=rng)
 
-    controls = controls_from_end_effector(np.asarray(raw[spec.eef_key], dtype=F32),
-                                          np.asarray(raw[spec.contact_key], dtype=F32))
     # modalities that are switched off are zeroed BEFORE normalisation, as in the reference
+    eef = np.array(raw[spec.eef_key], dtype=F32)
     if not use_proprioception:
         pos[:] = 0
+        if reference_aliasing:
+            eef[:] = 0
     if not use_haptics:
         sensors[:] = 0
+    controls = controls_from_end_effector(eef, np.asarray(raw[spec.contact_key], dtype=F32))
     observations = {"gripper_pos": pos, "gripper_sensors": sensors, "image": image}
     for key, target in (("gripper_pos", pos), ("gripper_sensors", sensors), ("states", states), ("controls", controls)):
         mean, std = spec.norm[key]

@@ -117,6 +117,94 @@ def capture_eval(cm):
     print(f"wrote {path}: {len(blob)} arrays")
 
 
+def synthetic_recordings(seed: int = 7, T: int = 7):
+    """Raw trajectories shaped like the three HDF5 recordings (keys and shapes read off
+    ``tasks/_door.py:137-177`` and ``tasks/_push.py:160-213``), two per dataset."""
+    rng = np.random.RandomState(seed)
+    f = np.float32
+    contact = lambda: (rng.uniform(size=(T,)) > 0.4).astype(f)
+    coarse = lambda lo, hi, shape: (np.round(rng.uniform(lo, hi, shape) * 4) / 4).astype(f)  # few levels: small fixture
+    out = {"door": [], "push": [], "push-kloss": []}
+    for _ in range(2):
+        out["door"].append({
+            "object-state": rng.standard_normal((T, 5)).astype(f), "eef_pos": rng.standard_normal((T, 3)).astype(f),
+            "ee-force-obs": (10 * rng.standard_normal((T, 3))).astype(f), "ee-torque-obs": rng.standard_normal((T, 3)).astype(f),
+            "contact-obs": contact(), "image": coarse(-1, 1, (T, 64, 64))})
+        out["push"].append({
+            "object-state": rng.standard_normal((T, 4)).astype(f), "Cylinder0_pos": rng.standard_normal((T, 3)).astype(f),
+            "eef_pos": rng.standard_normal((T, 3)).astype(f), "force": rng.standard_normal((T, 6)).astype(f),
+            "contact": contact(), "image": coarse(-1, 1, (T, 32, 32))})
+        out["push-kloss"].append({
+            "pos": rng.standard_normal((T, 3)).astype(f), "tip": rng.standard_normal((T, 3)).astype(f),
+            "force": rng.standard_normal((T, 3)).astype(f), "contact": contact(),
+            "image": coarse(0, 1, (T, 32, 32, 3))})
+    return out
+
+
+LOADER_CASES = [
+    ("default", {}),
+    ("no_vision", {"use_vision": False}),
+    ("no_proprioception", {"use_proprioception": False}),
+    ("no_haptics", {"use_haptics": False}),
+    ("sequential3", {"sequential_image_rate": 3}),
+    ("start2", {"start_timestep": 2}),
+    ("blackout", {"image_blackout_ratio": 0.4}),
+]
+
+
+def capture_loaders(cm):
+    """Dataset layer: the reference's ``_load_trajectories`` of both tasks
+    run on synthetic recordings.  ``fannypack.data.TrajectoriesFile`` / ``cached_drive_file``
+    (Drive download + HDF5 read) are replaced by an in-memory list for the duration of the call;
+    everything after the file read is the reference's code."""
+    import copy
+
+    import oracle.fp.data as fpdata
+
+    raws = synthetic_recordings()
+    blob = {}
+    for ds, recs in raws.items():
+        for i, r in enumerate(recs):
+            for k, v in r.items():
+                blob[f"raw/{ds}/{i}/{k}"] = v
+
+    class Files:
+        def __init__(self, recs):
+            self.recs = recs
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def __iter__(self):
+            return iter(copy.deepcopy(self.recs))  # the reference mutates what it reads
+
+    saved = fpdata.TrajectoriesFile, fpdata.cached_drive_file
+    try:
+        fpdata.cached_drive_file = lambda name, url: name
+        for ds, module, fname, extra in (("door", cm.tasks._door, "panda_door_pull_10.hdf5", {}),
+                                         ("push", cm.tasks._push, "gentle_push_10.hdf5", {}),
+                                         ("push-kloss", cm.tasks._push, "kloss_val.hdf5", {"kloss_dataset": True})):
+            fpdata.TrajectoriesFile = lambda name, ds=ds: Files(raws[ds])
+            for tag, args in LOADER_CASES:
+                np.random.seed(0)  # blackout masks come from numpy's global RNG
+                trajs = module._load_trajectories(fname, **args, **extra)
+                assert len(trajs) == 2
+                for i, t in enumerate(trajs):
+                    states, obs, controls = t
+                    blob[f"{ds}/{tag}/{i}/states"] = np.asarray(states)
+                    blob[f"{ds}/{tag}/{i}/controls"] = np.asarray(controls)
+                    for k in ("image", "gripper_pos", "gripper_sensors"):
+                        blob[f"{ds}/{tag}/{i}/{k}"] = np.asarray(obs[k])
+    finally:
+        fpdata.TrajectoriesFile, fpdata.cached_drive_file = saved
+    path = os.path.join(OUT, "loaders.npz")
+    np.savez_compressed(path, **blob)
+    print(f"wrote {path}: {len(blob)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def main():
     warnings.filterwarnings("ignore")
     torch.set_num_threads(4)
@@ -124,6 +212,7 @@ def main():
     cm = import_reference_crossmodal()
     capture_models(cm)
     capture_eval(cm)
+    capture_loaders(cm)
 
 
 if __name__ == "__main__":
