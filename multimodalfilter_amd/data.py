@@ -17,6 +17,11 @@ What it restates (host-side numpy; nothing here is on the timed path):
   (``SubsequenceBatcher``; keeps everything on the device, yields time-major batches for
   ``train.train_filter_step``).
 
+* ``torchfilter.data.SingleStepDataset`` and ``ParticleFilterMeasurementDataset`` as
+  ``train_helpers.py:39,83-87,110`` use them (``SingleStepBatcher``,
+  ``ParticleFilterMeasurementBatcher``; published behaviour of the absent package, restated in
+  ``oracle/tf/data.py`` too).
+
 Reading the recordings themselves needs ``h5py`` (``load_hdf5``); the container this was built in
 has neither ``h5py`` nor the datasets (Drive URLs, ``tasks/_door.py:11-20``), so that one function
 is exercised only through a stand-in ``h5py`` module (``tests/test_data_cpu.py``).  Everything after
@@ -246,3 +251,75 @@ class SubsequenceBatcher:
         for b in range(len(self)):
             idx = order[b * self.batch_size:(b + 1) * self.batch_size].to(dev)
             yield {k: v.index_select(1, idx) for k, v in self.data.items()}
+
+
+class _DeviceBatcher:
+    """Seeded, shuffled batches of a dict of device tensors that share dim 0."""
+
+    def __init__(self, tensors: Dict[str, torch.Tensor], batch_size: int, seed: int, drop_last: bool):
+        self.data = tensors
+        self.count = next(iter(tensors.values())).shape[0]
+        self.batch_size = batch_size
+        self.drop_last = drop_last
+        self._gen = torch.Generator(device="cpu").manual_seed(seed)
+
+    def __len__(self) -> int:
+        return self.count // self.batch_size if self.drop_last else -(-self.count // self.batch_size)
+
+    def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
+        order = torch.randperm(self.count, generator=self._gen)
+        dev = next(iter(self.data.values())).device
+        for b in range(len(self)):
+            idx = order[b * self.batch_size:(b + 1) * self.batch_size].to(dev)
+            yield {k: v.index_select(0, idx) for k, v in self.data.items()}
+
+
+class SingleStepBatcher(_DeviceBatcher):
+    """``torchfilter.data.SingleStepDataset`` behind a shuffling loader, device-resident: every
+    consecutive pair of every trajectory as ``initial_states x_t``, ``next_states x_{t+1}``,
+    ``controls u_{t+1}`` and the observations ``o_{t+1}`` (``train_helpers.py:39-43,110-114``)."""
+
+    def __init__(self, trajectories: Sequence[TrajectoryNumpy], *, batch_size: int, device, seed: int = 0):
+        cat = lambda arrays: torch.from_numpy(np.concatenate(arrays, axis=0)).to(device=device, dtype=torch.float32)
+        t = {"initial_states": cat([tr.states[:-1] for tr in trajectories]),
+             "next_states": cat([tr.states[1:] for tr in trajectories]),
+             "controls": cat([tr.controls[1:] for tr in trajectories])}
+        for key in ("image", "gripper_pos", "gripper_sensors"):
+            t[key] = cat([tr.observations[key][1:] for tr in trajectories])
+        super().__init__(t, batch_size, seed, drop_last=False)
+
+
+def gaussian_log_pdf(x: torch.Tensor, mean: torch.Tensor, covariance: torch.Tensor) -> torch.Tensor:
+    """``log N(x; mean, covariance)`` row-wise, in fp64."""
+    d = covariance.shape[0]
+    e = (x - mean).double()
+    sol = torch.linalg.solve(covariance.double(), e.t()).t()
+    return -0.5 * ((e * sol).sum(-1) + d * np.log(2.0 * np.pi) + torch.logdet(covariance.double()))
+
+
+class ParticleFilterMeasurementBatcher(_DeviceBatcher):
+    """``torchfilter.data.ParticleFilterMeasurementDataset`` (``train_helpers.py:83-91``): for every
+    ``(state, observation)`` pair ``samples_per_pair`` perturbed states -- the first half from
+    ``N(state, covariance)``, the second half from ``N(state, 5 covariance)`` -- each with the
+    regression target ``log N(noisy_state; state, covariance)``.  All draws are made once, on the
+    CPU, from ``seed`` (upstream redraws from numpy's global RNG on every access)."""
+
+    FAR_SCALE = 5.0
+
+    def __init__(self, trajectories: Sequence[TrajectoryNumpy], *, covariance: np.ndarray, samples_per_pair: int,
+                 batch_size: int, device, seed: int = 0):
+        cat = lambda arrays: torch.from_numpy(np.concatenate(arrays, axis=0)).to(torch.float32)
+        states = cat([tr.states for tr in trajectories])
+        P, d = states.shape
+        S = samples_per_pair
+        cov = torch.as_tensor(np.asarray(covariance), dtype=torch.float64)
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        eps = torch.randn((P, S, d), generator=g, dtype=torch.float64)
+        scale = torch.where(torch.arange(S) < S * 0.5, 1.0, float(np.sqrt(self.FAR_SCALE))).double()
+        noisy = states.double()[:, None, :] + (eps * scale[None, :, None]) @ torch.linalg.cholesky(cov).t()
+        target = gaussian_log_pdf(noisy.reshape(P * S, d), states.double().repeat_interleave(S, dim=0), cov)
+        rep = lambda x: x.repeat_interleave(S, dim=0).to(device)
+        t = {"noisy_states": noisy.reshape(P * S, d).float().to(device), "log_likelihoods": target.float().to(device)}
+        for key in ("image", "gripper_pos", "gripper_sensors"):
+            t[key] = rep(cat([tr.observations[key] for tr in trajectories]))
+        super().__init__(t, batch_size, seed + 1, drop_last=False)

@@ -1,4 +1,5 @@
-"""End-to-end filter training step.
+"""Training steps: the end-to-end filter step and the pre-training losses of
+the reference's curricula (8f rank 4).
 
 Mirrors ``torchfilter.train.train_filter`` as the reference calls it
 (``/root/reference/crossmodal/train_helpers.py:124-162``; upstream behaviour SURVEY.md A.2):
@@ -6,6 +7,14 @@ a batch of subsequences ``(L, N, ...)``, belief initialised at a sample
 ``~ N(states[0], initial_covariance)`` (or from the first observation), ``forward_loop`` over
 ``[1:]``, mean-squared error against ``states[1:]``, one optimiser step.  Randomness is explicit
 (``noise``), as everywhere in this package.
+
+Pre-training (``train_helpers.py:31-121`` -> ``torchfilter.train.train_dynamics_single_step`` /
+``train_dynamics_recurrent`` / ``train_particle_filter_measurement`` / ``train_virtual_sensor``; the
+package is absent and un-pinned, its published losses are restated -- same formulas as
+``oracle/tf/train.py``): ``dynamics_single_step_loss``, ``dynamics_recurrent_loss``,
+``particle_filter_measurement_loss``, ``virtual_sensor_loss`` and ``pretrain_step``; batches come
+from ``data.SingleStepBatcher`` / ``data.SubsequenceBatcher`` /
+``data.ParticleFilterMeasurementBatcher``.
 
 The filter must be in ``train()`` mode with a training backend selected
 (``engine.set_training_backend("hip")``: per-particle networks forward + backward in HIP,
@@ -62,5 +71,61 @@ def train_filter_step(filter_model, batch, optimizer: torch.optim.Optimizer, *, 
     loss.backward()
     if all_reduce:
         distributed.all_reduce_gradients(filter_model)
+    optimizer.step()
+    return float(loss.detach())
+
+
+# ------------------------------------------------------------------------------ pre-training losses
+def _check_training(module):
+    assert module.training, "call .train() first"
+    assert engine.TRAINING_BACKEND is not None, "select engine.set_training_backend('hip' | 'autograd')"
+
+
+def dynamics_single_step_loss(dynamics_model, batch: Dict[str, torch.Tensor], *, loss_function: str = "mse") -> torch.Tensor:
+    """``mse(f(x_t, u_{t+1}), x_{t+1})`` on a ``data.SingleStepBatcher`` batch (``"nll"``: negative
+    log-likelihood under the model's noise); ``train_helpers.py:31-48`` uses ``"mse"``."""
+    _check_training(dynamics_model)
+    pred, tril = dynamics_model(initial_states=batch["initial_states"], controls=batch["controls"])
+    if loss_function == "mse":
+        return torch.nn.functional.mse_loss(pred, batch["next_states"])
+    assert loss_function == "nll", loss_function
+    dist = torch.distributions.MultivariateNormal(loc=pred, scale_tril=tril)
+    return -torch.mean(dist.log_prob(batch["next_states"]))
+
+
+def dynamics_recurrent_loss(dynamics_model, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """Open-loop rollout from ``states[0]`` over ``controls[1:]``, mse against ``states[1:]``
+    (time-major ``data.SubsequenceBatcher`` batch; ``train_helpers.py:51-74``)."""
+    _check_training(dynamics_model)
+    pred, _ = dynamics_model.forward_loop(initial_states=batch["states"][0], controls=batch["controls"][1:])
+    return torch.nn.functional.mse_loss(pred, batch["states"][1:])
+
+
+def particle_filter_measurement_loss(measurement_model, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """``mse(loglik(noisy_state, observation), log N(noisy_state; state, covariance))`` with one
+    particle per sample (``data.ParticleFilterMeasurementBatcher`` batch; ``train_helpers.py:76-96``).
+    With the ``"hip"`` backend the per-particle network runs forward and backward in K6."""
+    _check_training(measurement_model)
+    obs = {k: batch[k] for k in ("image", "gripper_pos", "gripper_sensors")}
+    pred = measurement_model(states=batch["noisy_states"][:, None, :].contiguous(), observations=obs)
+    assert pred.shape == (batch["noisy_states"].shape[0], 1)
+    return torch.nn.functional.mse_loss(pred, batch["log_likelihoods"][:, None])
+
+
+def virtual_sensor_loss(virtual_sensor_model, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """``mse(z(o_{t+1}), x_{t+1})`` on a ``data.SingleStepBatcher`` batch (``train_helpers.py:98-121``)."""
+    _check_training(virtual_sensor_model)
+    obs = {k: batch[k] for k in ("image", "gripper_pos", "gripper_sensors")}
+    z, _tril = virtual_sensor_model(observations=obs)
+    return torch.nn.functional.mse_loss(z, batch["next_states"])
+
+
+def pretrain_step(loss_fn, module, batch, optimizer: torch.optim.Optimizer, *, all_reduce: bool = False, **kw) -> float:
+    """One optimisation step of a pre-training loss (``loss_fn(module, batch, **kw)``)."""
+    optimizer.zero_grad(set_to_none=True)
+    loss = loss_fn(module, batch, **kw)
+    loss.backward()
+    if all_reduce:
+        distributed.all_reduce_gradients(module)
     optimizer.step()
     return float(loss.detach())
