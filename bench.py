@@ -132,7 +132,7 @@ def oracle_pf_run(cls, state_dict, traj, eps0, eps, us, M, *, mode="systematic",
 
     def resample_and_record_ess():  # effective sample size of the weights about to be resampled
         w = torch.softmax(oracle.particle_log_weights, dim=1)
-        ess.append(float((1.0 / (w * w).sum(1)).mean()) / w.shape[1])
+        ess.append((1.0 / (w * w).sum(1)) / w.shape[1])  # per trajectory, as a fraction of M
         resample()
 
     if keep_beliefs:
@@ -146,7 +146,7 @@ def oracle_pf_run(cls, state_dict, traj, eps0, eps, us, M, *, mode="systematic",
             if t > warm:
                 dt += time.perf_counter() - t0
             if keep_beliefs:
-                beliefs.append(before + (oracle.last_resample_indices, ess[-1]))
+                beliefs.append(before + (oracle.last_resample_indices, float(ess[-1].mean()), ess[-1]))
     return torch.stack(ests), dt, beliefs
 
 
@@ -168,7 +168,7 @@ def teacher_forced_parity(engine_filter, traj, eps, us, beliefs, want, M, *, mod
     f.initialize_beliefs(mean=traj["states"][0].to(dev), covariance=cov)
     scale = max(1.0, float(want.abs().max()))
     errs, flips = [], []
-    for t, (S, W, idx, _) in enumerate(beliefs):
+    for t, (S, W, idx, _, _) in enumerate(beliefs):
         f.particle_states = S.to(dev).contiguous()
         f.particle_log_weights = W.to(dev).contiguous()
         f._spare_states = None

@@ -429,12 +429,12 @@ def test_pretrain_step_reduces_the_measurement_loss():
         pf = mmf.push_models.PushParticleFilter().to(dev).train()
         batcher = data.ParticleFilterMeasurementBatcher(trajs, covariance=np.eye(2) * 0.1, samples_per_pair=10,
                                                         batch_size=64, device=dev, seed=5)
-        opt = torch.optim.Adam(pf.measurement_model.parameters(), lr=1e-3)
-        losses = []
-        for epoch in range(3):
-            for batch in batcher:
-                losses.append(train.pretrain_step(train.particle_filter_measurement_loss, pf.measurement_model, batch, opt))
-        assert np.mean(losses[-4:]) < 0.5 * np.mean(losses[:4]), (losses[:4], losses[-4:])
+        opt = torch.optim.Adam(pf.measurement_model.parameters(), lr=3e-3)
+        epochs = []
+        for epoch in range(15):
+            epochs.append(np.mean([train.pretrain_step(train.particle_filter_measurement_loss, pf.measurement_model, batch, opt)
+                                   for batch in batcher]))
+        assert epochs[-1] < 0.6 * epochs[0], epochs
         # default noise sources are persistent (consecutive draws differ)
         src = train.default_noise(pf)
         a = src.gaussian((3, 2), like=torch.zeros(1, device=dev))
