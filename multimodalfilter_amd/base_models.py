@@ -286,9 +286,21 @@ class _FusedKalmanFilters(base.Filter, _EnabledModels):
         if wm is not None and np.sum(on) < len(on):
             wm = None
         batched_w = wm is not None and hasattr(wm, "raw_weights")
-        feats = encode_observation_images(sensors + [wm if batched_w else None], flat)
-        outs = [None if m is None else call_with_image_feat(m, feats[i], observations=flat)
-                for i, m in enumerate(sensors)]
+        # only ROW-WISE sensors may see the T*N flattened rows: a sensor that couples the rows of
+        # a batch (batch statistics, the reshape-quirk weight model inside a fused sensor) must be
+        # evaluated one step at a time, exactly as step-by-step ``forward`` would
+        row_wise = [m is not None and getattr(m, "row_wise", False) for m in sensors]
+        feats = encode_observation_images([m if rw else None for m, rw in zip(sensors, row_wise)]
+                                          + [wm if batched_w else None], flat)
+        outs = []
+        for i, m in enumerate(sensors):
+            if m is None:
+                outs.append(None)
+            elif row_wise[i]:
+                outs.append(call_with_image_feat(m, feats[i], observations=flat))
+            else:
+                steps = [m(observations=tree_index(observations, t)) for t in range(T)]
+                outs.append((torch.cat([z for z, _ in steps]), torch.cat([r for _, r in steps])))
         raw = call_with_image_feat(wm.raw_weights, feats[-1], observations=flat) if batched_w else None
         w_all = wm.finish_weights_steps(raw, T) if batched_w and hasattr(wm, "finish_weights_steps") else None
         encs = []

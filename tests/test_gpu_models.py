@@ -381,3 +381,38 @@ def test_full_size_particle_filter_properties():
     assert torch.equal(f.particle_states, final_states)
     assert torch.equal(f.particle_log_weights, final_logw)
     assert torch.equal(final_logw, torch.full_like(final_logw, -math.log(M)))
+
+
+def test_batch_coupled_sub_filter_sensor_is_evaluated_per_step():
+    """A sub-filter sensor that couples the rows of a batch (here: batch-mean subtraction) is not
+    ``row_wise``: ``forward_loop`` must evaluate it one step at a time, so its results equal
+    step-by-step ``forward`` (``_encode_loop`` used to flatten T*N rows unconditionally)."""
+    _need_gpu()
+    import multimodalfilter_amd as mmf
+
+    class Coupled(mmf.base.VirtualSensorModel):
+        def __init__(self, inner):
+            super().__init__(state_dim=inner.state_dim)
+            self.inner = inner
+
+        def forward(self, *, observations):
+            z, r = self.inner(observations=observations)
+            return z - z.mean(dim=0, keepdim=True), r
+
+    dev = torch.device("cuda:0")
+    d, N, T = 3, 6, 4
+    g = torch.Generator().manual_seed(77)
+    obs = {"image": (torch.randn((T, N, 32, 32), generator=g) * 0.5).clamp(-1, 1).to(dev),
+           "gripper_pos": torch.randn((T, N, 3), generator=g).to(dev),
+           "gripper_sensors": torch.randn((T, N, 7), generator=g).to(dev)}
+    ctrl = torch.randn((T, N, 7), generator=g).to(dev)
+    x0 = torch.randn((N, d), generator=g).to(dev)
+    cov = (torch.eye(d) * 0.1)[None].expand(N, d, d).to(dev)
+    torch.manual_seed(1)
+    f = mmf.door_models.DoorCrossmodalKalmanFilter().to(dev).eval()
+    f.filter_models[0].virtual_sensor_model = Coupled(f.filter_models[0].virtual_sensor_model)
+    f.initialize_beliefs(mean=x0, covariance=cov)
+    step = torch.stack([f(observations={k: v[t] for k, v in obs.items()}, controls=ctrl[t]) for t in range(T)])
+    f.initialize_beliefs(mean=x0, covariance=cov)
+    loop = f.forward_loop(observations=obs, controls=ctrl)
+    assert torch.equal(loop, step)
