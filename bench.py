@@ -556,10 +556,10 @@ def main():
             k1 = ks.get("pf_reweight_resample")
             if k1:
                 gbs = k1["bytes_per_launch"] / (k1["avg_ms"] * 1e-3) / 1e9
-                out["roofline_k1"] = {"kernel": "pf_reweight_resample_kernel<3>", "bound": "hbm",
+                out["roofline_k1"] = {"kernel": f"pf_reweight_resample_kernel<{d}, true>", "bound": "hbm",
                                       "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": gbs / HBM_PEAK_GBS,
-                                      "traffic": pmc_traffic("pf_reweight_resample_kernel<3>") if default_shape else None}
+                                      "traffic": pmc_traffic("pf_reweight_resample_kernel") if default_shape else None}
         if wl["kind"] != "pf" and "image_encoder" in ks:
             # EKF steps are > 99 % image-encoder MACs: the K4 launch sequence
             # (stem + four 3x3 convolutions + linear tail) is the dominant "kernel"

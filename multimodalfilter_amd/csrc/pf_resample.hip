@@ -25,7 +25,10 @@ struct Scratch {  // lives behind the slots in dynamic LDS
   float bcast[MMF_MAX_STATE_DIM + 2];
 };
 
-template <int D>
+// STAGE: the particle states are kept in LDS next to the CDF (M * 4D more bytes), so the gather
+// of the resampling step reads LDS instead of going back to L2 / HBM for rows this workgroup
+// has just streamed through.
+template <int D, bool STAGE>
 __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
     const float* __restrict__ loglik, const float* __restrict__ logw_in,
     const float* __restrict__ states_in, const float* __restrict__ u,
@@ -38,6 +41,7 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
   float* xf = reinterpret_cast<float*>(smem);                            // mode 0: x_i at [i]
   unsigned long long* cdf = reinterpret_cast<unsigned long long*>(smem);  // modes 1/2
   Scratch& sc = *reinterpret_cast<Scratch*>(smem + slots_sz);
+  float* xs_lds = reinterpret_cast<float*>(smem + slots_sz + ((sizeof(Scratch) + 15) & ~static_cast<size_t>(15)));  // STAGE
 
   const int n = blockIdx.x;
   const int tid = threadIdx.x;
@@ -57,6 +61,25 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
   auto x_load = [&](int i) -> float {
     return need_cdf ? reinterpret_cast<const float*>(cdf + i)[0] : xf[i];
   };
+
+  // the first chunk's particle states are requested before anything waits on memory: their
+  // latency overlaps pass 1 (log-weights, row maximum, two barriers)
+  float st0[4 * D];
+  {
+    const int i0 = tid * 4;
+    if (vec && i0 + 3 < M) {
+      const float4* p = reinterpret_cast<const float4*>(xs + static_cast<size_t>(i0) * D);
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const float4 t = p[k];
+        st0[4 * k] = t.x; st0[4 * k + 1] = t.y; st0[4 * k + 2] = t.z; st0[4 * k + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4 * D; ++k)
+        st0[k] = (i0 * D + k < M * D) ? xs[static_cast<size_t>(i0) * D + k] : 0.f;
+    }
+  }
 
   // ---- pass 1: x_i = logw_i + loglik_i -> LDS, row max
   float mx = -INFINITY;
@@ -92,7 +115,10 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
     float e[4];
     unsigned long long q[4], tsum = 0;
     float st[4 * D];
-    if (vec && i0 + 3 < M) {
+    if (base == 0) {
+#pragma unroll
+      for (int k = 0; k < 4 * D; ++k) st[k] = st0[k];
+    } else if (vec && i0 + 3 < M) {
       const float4* p = reinterpret_cast<const float4*>(xs + static_cast<size_t>(i0) * D);
 #pragma unroll
       for (int k = 0; k < D; ++k) {
@@ -103,6 +129,11 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
 #pragma unroll
       for (int k = 0; k < 4 * D; ++k)
         st[k] = (i0 * D + k < M * D) ? xs[static_cast<size_t>(i0) * D + k] : 0.f;
+    }
+    if (STAGE && need_cdf) {
+#pragma unroll
+      for (int k = 0; k < 4 * D; ++k)
+        if (i0 * D + k < M * D) xs_lds[i0 * D + k] = st[k];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -201,14 +232,23 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
           const unsigned long long U = static_cast<unsigned long long>(floorf(un[k] * 16777216.0f));
           p = (U * Q) >> kFixBits;
         }
-        int lo_i = (mode == 1 && j > 0) ? idx[j - 1] : 0, hi_i = M;  // sorted positions
+        int lo_i = 0, hi_i = M;
+        if (mode == 1 && j > 0) {
+          // systematic positions are sorted and evenly spaced: the ancestor of output k sits at or
+          // just above that of output k - 1 -- gallop from there (2-3 LDS reads on average
+          // instead of log2 M) before the bisection
+          lo_i = idx[j - 1];
+          int step = 1;
+          while (lo_i + step <= M && cdf[lo_i + step - 1] <= p) { lo_i += step; step <<= 1; }
+          hi_i = min(M, lo_i + step - 1);
+        }
         while (lo_i < hi_i) {
           const int mid = (lo_i + hi_i) >> 1;
           if (cdf[mid] <= p) lo_i = mid + 1; else hi_i = mid;
         }
         idx[j] = lo_i;
 #pragma unroll
-        for (int c = 0; c < D; ++c) g[j * D + c] = xs[static_cast<size_t>(lo_i) * D + c];
+        for (int c = 0; c < D; ++c) g[j * D + c] = STAGE ? xs_lds[lo_i * D + c] : xs[static_cast<size_t>(lo_i) * D + c];
       }
     }
     if (vec_out && k0 + 3 < M_out) {
@@ -239,6 +279,14 @@ extern "C" size_t mmf_pf_reweight_resample_lds_bytes(int M, int mode) {
   return slots + sizeof(Scratch);
 }
 
+namespace {
+// LDS with the particle states staged behind the CDF; used when one workgroup per CU still fits
+size_t staged_lds_bytes(int M, int d, int mode) {
+  const size_t slots = (static_cast<size_t>(M) * (mode ? 8 : 4) + 15) & ~static_cast<size_t>(15);
+  return slots + ((sizeof(Scratch) + 15) & ~static_cast<size_t>(15)) + static_cast<size_t>(M) * d * sizeof(float);
+}
+}  // namespace
+
 extern "C" int mmf_pf_reweight_resample(const float* loglik, const float* logw_in,
                                         const float* states_in, const float* u, float* estimate,
                                         float* states_out, float* logw_out, int32_t* indices_out,
@@ -248,28 +296,38 @@ extern "C" int mmf_pf_reweight_resample(const float* loglik, const float* logw_i
   if (mode != 0 && (!u || !states_out || states_out == states_in)) return MMF_EINVAL;
   if (mode == 0 && M_out != M) return MMF_EINVAL;
   if (M > 65536 || M_out > 65536) return MMF_ETOOLARGE;
-  const size_t lds = mmf_pf_reweight_resample_lds_bytes(M, mode);
+  size_t lds = mmf_pf_reweight_resample_lds_bytes(M, mode);
   if (lds > 160 * 1024) return MMF_ETOOLARGE;
   if (N == 0) return 0;
+  // stage the states in LDS when occupancy does not pay for it: always if every trajectory gets
+  // a CU of its own (N <= 256), otherwise only while two workgroups still fit a CU (<= 80 KB each)
+  const size_t staged = staged_lds_bytes(M, d, mode);
+  const bool stage = mode != 0 && (N <= 256 ? staged <= 160 * 1024 : staged <= 80 * 1024);
+  if (stage) lds = staged;
   // enough threads to give each one a float4 of work, at least one wave
   int block = ((M + 3) / 4 + MMF_WAVE - 1) / MMF_WAVE * MMF_WAVE;
   if (block > kBlock) block = kBlock;
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define MMF_K1(D)                                                                              \
-  case D: {                                                                                    \
+#define MMF_K1_LAUNCH(D, ST)                                                                   \
+  {                                                                                            \
     if (lds > 64 * 1024) {                                                                     \
       hipError_t e = hipFuncSetAttribute(                                                      \
-          reinterpret_cast<const void*>(&pf_reweight_resample_kernel<D>),                      \
+          reinterpret_cast<const void*>(&pf_reweight_resample_kernel<D, ST>),                  \
           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                  \
       if (e != hipSuccess) return static_cast<int>(e);                                         \
     }                                                                                          \
-    pf_reweight_resample_kernel<D><<<N, block, lds, s>>>(loglik, logw_in, states_in, u,        \
+    pf_reweight_resample_kernel<D, ST><<<N, block, lds, s>>>(loglik, logw_in, states_in, u,    \
         estimate, states_out, logw_out, indices_out, M, M_out, mode);                          \
+  }
+#define MMF_K1(D)                                                                              \
+  case D: {                                                                                    \
+    if (stage) MMF_K1_LAUNCH(D, true) else MMF_K1_LAUNCH(D, false)                             \
   } break;
   switch (d) {
     MMF_K1(1) MMF_K1(2) MMF_K1(3) MMF_K1(4)
   }
 #undef MMF_K1
+#undef MMF_K1_LAUNCH
   MMF_CHECK_LAUNCH();
   return 0;
 }

@@ -333,8 +333,11 @@ def test_native_ekf_loop_equals_stepwise(cls, kw, masked):
         assert torch.equal(f.weighted_covariances, wc)
 
 
-def test_full_size_particle_filter_properties():
-    """BASELINE.json's headline shape (door crossmodal PF, 256 x 4096 particles), 3 steps: the
+@pytest.mark.parametrize("tname,cls,N", [("door", "DoorCrossmodalParticleFilter", 256),
+                                         ("push", "PushCrossmodalParticleFilter", 1024)])
+def test_full_size_particle_filter_properties(tname, cls, N):
+    """BASELINE.json's headline shape (door crossmodal PF, 256 x 4096 particles) and config 3 (push
+    crossmodal PF, 1024 x 4096, resample-bound), 3 steps: the
     native step loop equals step-by-step evaluation bit for bit; after resampling the log-weights
     are exactly -log M, every estimate lies inside its particles' bounding box before resampling,
     and every resampled particle is one of the propagated ones (ancestor indices in range and
@@ -346,12 +349,12 @@ def test_full_size_particle_filter_properties():
     from multimodalfilter_amd import synthetic
 
     dev = torch.device("cuda:0")
-    N, M, d, T = 256, 4096, 3, 3
+    M, d, T = 4096, om.TASKS[tname].state_dim, 3
     traj = {k: v.to(dev) for k, v in synthetic.make_trajectories(state_dim=d, T=T, N=N, seed=5).items()}
     eps0, eps, us = synthetic.draw_filter_noise(T=T, N=N, M=M, state_dim=d, seed=6)
     eps0, eps, us = eps0.to(dev), torch.stack(eps).to(dev), torch.stack(us).to(dev)
     torch.manual_seed(0)
-    f = mmf.door_models.DoorCrossmodalParticleFilter().to(dev).eval()
+    f = mmf.model_types(tname)[cls]().to(dev).eval()
     f.num_particles = M
     obs = {k: traj[k][1:] for k in ("image", "gripper_pos", "gripper_sensors")}
     ctrl = traj["controls"][1:]
@@ -416,3 +419,42 @@ def test_batch_coupled_sub_filter_sensor_is_evaluated_per_step():
     f.initialize_beliefs(mean=x0, covariance=cov)
     loop = f.forward_loop(observations=obs, controls=ctrl)
     assert torch.equal(loop, step)
+
+
+def test_full_size_crossmodal_ekf_matches_oracle_on_a_shard():
+    """BASELINE config 4's per-GPU shape: door crossmodal EKF, 1024 trajectories, 5 steps.  The
+    native loop equals step-by-step evaluation bit for bit; with ``fix_weight_layout`` (the
+    shard-invariant weight layout) trajectories are independent, so the first 24 of the 1024 must
+    reproduce the CPU oracle run on those 24 alone: means and fused covariances within 1e-4."""
+    _need_gpu()
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import synthetic
+
+    dev = torch.device("cuda:0")
+    N, T, d, S = 1024, 5, 3, 24
+    kw = {"feedback": "belief", "fix_weight_layout": True}
+    traj = synthetic.make_trajectories(state_dim=d, T=T, N=N, seed=21)
+    oracle = om.build("DoorCrossmodalKalmanFilter", **kw)
+    oracle.load_state_dict(om.seeded_state_dict(oracle, seed=6, gain=1.0))
+    oracle.eval()
+    obs = {k: traj[k][1:] for k in ("image", "gripper_pos", "gripper_sensors")}
+    cov = (torch.eye(d) * 0.1)[None]
+    with torch.no_grad():
+        oracle.initialize_beliefs(mean=traj["states"][0, :S], covariance=cov.expand(S, d, d))
+        want = oracle.forward_loop(observations={k: v[:, :S] for k, v in obs.items()}, controls=traj["controls"][1:, :S])
+    f = mmf.door_models.DoorCrossmodalKalmanFilter(**kw)
+    f.load_state_dict(oracle.state_dict())
+    f.to(dev).eval()
+    tdev = {k: v.to(dev) for k, v in traj.items()}
+    odev = {k: tdev[k][1:] for k in obs}
+    f.initialize_beliefs(mean=tdev["states"][0], covariance=cov.to(dev).expand(N, d, d))
+    loop = f.forward_loop(observations=odev, controls=tdev["controls"][1:])
+    cov_loop = f.weighted_covariances.clone()
+    f.initialize_beliefs(mean=tdev["states"][0], covariance=cov.to(dev).expand(N, d, d))
+    step = torch.stack([f(observations={k: v[t] for k, v in odev.items()}, controls=tdev["controls"][1 + t]) for t in range(T)])
+    assert torch.equal(loop, step) and torch.equal(cov_loop, f.weighted_covariances)
+    assert bool(torch.isfinite(loop).all())
+    scale = max(1.0, float(want.abs().max()))
+    assert float((loop[:, :S].cpu() - want).abs().max()) / scale < REL_TOL
+    wc = oracle.weighted_covariances
+    assert float((cov_loop[:S].cpu() - wc).abs().max()) / max(1.0, float(wc.abs().max())) < REL_TOL
