@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 15
+#define MMF_ABI_VERSION 16
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -363,6 +363,23 @@ int mmf_ekf_step(const float* A, const float* mu_pred, const float* q_tril, cons
                  const float* r_tril, const float* fuse_w, float* mu, float* Sigma,
                  float* mu_f, float* Sigma_f, int N, int d, int K, int fusion, int feedback,
                  void* stream);
+
+/* ---------------------------------------------------------------- unscented transform (UKF)
+ * torchfilter's UnscentedKalmanFilter / VirtualSensorUnscentedKalmanFilter (absent, un-pinned
+ * dependency of the reference, cf. crossmodal/door_models/kf.py:14-28 for the EKF sibling):
+ * sigma points of N Gaussian beliefs, and the weighted moments of the propagated points.
+ *  mu (N, d), Sigma (N, d, d); scale = sqrt(d + lambda);
+ *  points (N, 2d+1, d): [mu, mu + scale L[:, i], mu - scale L[:, i]] with L = chol(Sigma)
+ *  not_pd: int32 on the device or null, OR-ed with 1 when a covariance is not positive definite
+ */
+int mmf_ukf_sigma_points(const float* mu, const float* Sigma, float scale, float* points,
+                         int32_t* not_pd, int N, int d, void* stream);
+/*  points (N, 2d+1, d) propagated sigma points; wm0 / wc0: mean / covariance weight of point 0,
+ *  wi: weight of every other point; q_tril (d, d): dynamics noise (Q = L L^T)
+ *  -> mu_pred (N, d), Sigma_pred (N, d, d) = sum_i wc_i (X_i - mu)(X_i - mu)^T + Q
+ */
+int mmf_ukf_moments(const float* points, float wm0, float wc0, float wi, const float* q_tril,
+                    float* mu_pred, float* Sigma_pred, int N, int d, void* stream);
 
 /* R11: fusion of K virtual sensors before a single EKF (crossmodal_kf.py:291-359 mode 1;
  * unimodal_kf.py:56-115 mode 2, quirk Q5 preserved: see csrc/ekf.hip).

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmmf_hip.so")
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 15
+ABI_VERSION = 16
 PREC_F32, PREC_F16X3 = 0, 1
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}
 
@@ -90,6 +90,8 @@ SIGNATURES = {
     "mmf_pf_measure": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, c_int, _FP, c_int, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_dynamics_jacobian": (c_int, [_FP, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_ekf_step": (c_int, [_FP] * 10 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmf_ukf_sigma_points": (c_int, [_FP, _FP, ctypes.c_float, _FP, _FP, c_int, c_int, c_void_p]),
+    "mmf_ukf_moments": (c_int, [_FP, ctypes.c_float, ctypes.c_float, ctypes.c_float, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_pf_reweight_backward": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_init_particles": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_forward_loop": (c_int, [POINTER(MmfPfLoopArgs), c_void_p]),
@@ -219,6 +221,20 @@ def ekf_step(A, mu_pred, q_tril, z, r_tril, fuse_w, mu, Sigma, mu_f, Sigma_f, fu
         _check(load().mmf_ekf_step(ptr(A), ptr(mu_pred), ptr(q_tril), ptr(z), ptr(r_tril),
                                    ptr(fuse_w), ptr(mu), ptr(Sigma), ptr(mu_f), ptr(Sigma_f),
                                    N, d, K, fusion, feedback, stream_of(mu_pred)), "mmf_ekf_step")
+
+
+def ukf_sigma_points(mu, Sigma, scale: float, points, not_pd):
+    N, d = mu.shape
+    with _on(mu):
+        _check(load().mmf_ukf_sigma_points(ptr(mu), ptr(Sigma), float(scale), ptr(points), ptr(not_pd, dtype=torch.int32),
+                                           N, d, stream_of(mu)), "mmf_ukf_sigma_points")
+
+
+def ukf_moments(points, wm0: float, wc0: float, wi: float, q_tril, mu_pred, Sigma_pred):
+    N, d = mu_pred.shape
+    with _on(points):
+        _check(load().mmf_ukf_moments(ptr(points), float(wm0), float(wc0), float(wi), ptr(q_tril), ptr(mu_pred),
+                                      ptr(Sigma_pred), N, d, stream_of(points)), "mmf_ukf_moments")
 
 
 def particle_net_train_forward(packed, n_res: int, kind: int, states, traj_bias, stash, out, N: int, M: int, d: int):

@@ -502,3 +502,125 @@ class VirtualSensorExtendedKalmanFilter(base.Filter):
             out.append(self._step(tree_index(observations, t), tree_index(controls, t), sensors[t],
                                   None if ctrl_all is None else {k: v[sl] for k, v in ctrl_all.items()}))
         return torch.stack(out, dim=0)
+
+
+# ------------------------------------------------------------------------------ unscented filter
+class JulierSigmaPointStrategy:
+    """``lambda = 3 - d`` unless given; mean and covariance weights coincide (upstream
+    ``torchfilter.utils.JulierSigmaPointStrategy``, its UKFs' default)."""
+
+    def __init__(self, lambd: Optional[float] = None):
+        self.lambd = lambd
+
+    def compute_lambda(self, dim: int) -> float:
+        return 3.0 - dim if self.lambd is None else float(self.lambd)
+
+    def compute_sigma_weights(self, dim: int):
+        """``(wc0, wm0, wi)``: covariance / mean weight of the central point, weight of the rest."""
+        lambd = self.compute_lambda(dim)
+        w0 = lambd / (dim + lambd)
+        return w0, w0, 1.0 / (2.0 * (dim + lambd))
+
+
+class MerweSigmaPointStrategy:
+    """Van der Merwe's scaled points: ``lambda = alpha^2 (d + kappa) - d``, ``kappa = 3 - d`` unless
+    given; ``wc0 = wm0 + 1 - alpha^2 + beta`` (upstream ``torchfilter.utils.MerweSigmaPointStrategy``)."""
+
+    def __init__(self, alpha: float = 1e-2, beta: float = 2.0, kappa: Optional[float] = None):
+        self.alpha, self.beta, self.kappa = alpha, beta, kappa
+
+    def compute_lambda(self, dim: int) -> float:
+        kappa = 3.0 - dim if self.kappa is None else float(self.kappa)
+        return self.alpha ** 2 * (dim + kappa) - dim
+
+    def compute_sigma_weights(self, dim: int):
+        lambd = self.compute_lambda(dim)
+        wm0 = lambd / (dim + lambd)
+        return wm0 + 1.0 - self.alpha ** 2 + self.beta, wm0, 1.0 / (2.0 * (dim + lambd))
+
+
+class VirtualSensorUnscentedKalmanFilter(VirtualSensorExtendedKalmanFilter):
+    """UKF whose measurement is a learned virtual sensor observed through ``C = I`` (SURVEY.md 8f
+    rank 2; upstream ``torchfilter.filters.VirtualSensorUnscentedKalmanFilter``, absent and
+    un-pinned: published algorithm, restated in ``oracle/tf/filters.py``).
+
+    predict: ``2d + 1`` sigma points of the belief (``mmf_ukf_sigma_points``) go through the
+    dynamics model -- for the built-in networks they are rows of K2, ``N x (2d+1)`` "particles"
+    without noise -- and ``mmf_ukf_moments`` forms ``mu-`` and ``Sigma- = sum wc (X - mu-)(X - mu-)^T +
+    Q``; no Jacobian is evaluated.  correct: with an identity measurement the unscented update is
+    the Kalman update on ``(mu-, Sigma-)``, i.e. K3 with ``A = I`` and no added noise.
+    Same belief attributes and ``forward`` / ``forward_loop`` contract as the EKF."""
+
+    def __init__(self, *, dynamics_model, virtual_sensor_model, sigma_point_strategy=None):
+        super().__init__(dynamics_model=dynamics_model, virtual_sensor_model=virtual_sensor_model)
+        self.sigma_point_strategy = sigma_point_strategy if sigma_point_strategy is not None else JulierSigmaPointStrategy()
+
+    def _unscented_predict(self, controls, ctrl_ctx=None):
+        dyn = self.dynamics_model
+        mu, Sigma = self._belief_mean.contiguous(), self._belief_covariance.contiguous()
+        N, d = mu.shape
+        P = 2 * d + 1
+        lambd = self.sigma_point_strategy.compute_lambda(d)
+        wc0, wm0, wi = self.sigma_point_strategy.compute_sigma_weights(d)
+        points = torch.empty((N, P, d), dtype=torch.float32, device=mu.device)
+        not_pd = torch.zeros(1, dtype=torch.int32, device=mu.device)
+        _abi.ukf_sigma_points(mu, Sigma, math.sqrt(d + lambd), points, not_pd)
+        if hasattr(dyn, "propagate_encoded"):
+            if ctrl_ctx is None:
+                ctrl_ctx = dyn.encode_controls(controls)
+            moved = dyn.propagate_encoded(points, ctrl_ctx, None)
+            L = dyn.scale_tril().to(torch.float32).contiguous()
+        else:  # forward-only user model: one call on the N * (2d+1) flattened rows
+            rep = tree_map(controls, lambda t: torch.repeat_interleave(t, repeats=P, dim=0))
+            pred, _ = dyn(initial_states=points.reshape(N * P, d), controls=rep)
+            moved = pred.reshape(N, P, d).to(torch.float32).contiguous()
+            # noise evaluated at the belief mean (upstream); must be constant over the batch for the C ABI
+            L = dyn(initial_states=mu, controls=controls)[1][0].detach().to(torch.float32).contiguous()
+        mu_pred = torch.empty((N, d), dtype=torch.float32, device=mu.device)
+        Sigma_pred = torch.empty((N, d, d), dtype=torch.float32, device=mu.device)
+        _abi.ukf_moments(moved, wm0, wc0, wi, L, mu_pred, Sigma_pred)
+        if int(not_pd.item()):
+            raise ValueError("unscented predict: belief covariance is not positive definite")
+        return mu_pred, Sigma_pred
+
+    def _step(self, observations, controls, sensor_out=None, ctrl_ctx=None):
+        assert self._initialized, "Kalman filter not initialized!"
+        with torch.no_grad():
+            z, r_tril = sensor_out if sensor_out is not None else self.virtual_sensor_model(observations=observations)
+            mu_pred, Sigma_pred = self._unscented_predict(controls, ctrl_ctx)
+            N, d = mu_pred.shape
+            eye = torch.eye(d, dtype=torch.float32, device=mu_pred.device)[None].expand(N, d, d).contiguous()
+            mu = torch.empty((1, N, d), dtype=torch.float32, device=mu_pred.device)
+            Sigma = Sigma_pred.reshape(1, N, d, d)
+            _abi.ekf_step(eye.reshape(1, N, d, d), mu_pred.reshape(1, N, d),
+                          torch.zeros((1, d, d), dtype=torch.float32, device=mu_pred.device),
+                          z.to(torch.float32).reshape(1, N, d).contiguous(),
+                          r_tril.to(torch.float32).reshape(1, N, d, d).contiguous(), None,
+                          mu, Sigma, None, None, fusion=0, feedback=0)
+            self._belief_mean, self._belief_covariance = mu[0], Sigma[0]
+        return self._belief_mean
+
+    def _step_autograd(self, observations, controls):
+        raise NotImplementedError("the unscented filter is evaluation-only here; train the models with the EKF / PF")
+
+    def _native_loop(self, observations, ctrl_all, T, N, flat):
+        return None  # the step is sigma points -> K2 -> moments -> K3: driven from Python, sensors batched over T*N
+
+    def forward_loop(self, *, observations, controls):
+        T, N = tree_leading_shape(controls)[:2]
+        flat = lambda t: t.reshape((T * N,) + tuple(t.shape[2:]))
+        with torch.no_grad():
+            ctrl_all = None
+            if hasattr(self.dynamics_model, "propagate_encoded"):
+                ctrl_all = self.dynamics_model.encode_controls(tree_map(controls, flat))
+            if getattr(self.virtual_sensor_model, "row_wise", False):
+                z, r = self.virtual_sensor_model(observations=tree_map(observations, flat))
+                sensors = [(z[t * N:(t + 1) * N], r[t * N:(t + 1) * N]) for t in range(T)]
+            else:
+                sensors = [self.virtual_sensor_model(observations=tree_index(observations, t)) for t in range(T)]
+        out = []
+        for t in range(T):
+            sl = slice(t * N, (t + 1) * N)
+            out.append(self._step(tree_index(observations, t), tree_index(controls, t), sensors[t],
+                                  None if ctrl_all is None else {k: v[sl] for k, v in ctrl_all.items()}))
+        return torch.stack(out, dim=0)

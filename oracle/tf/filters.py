@@ -211,3 +211,84 @@ class VirtualSensorExtendedKalmanFilter(ExtendedKalmanFilter):
         z, Rtril = self.virtual_sensor_model(observations=observations)
         self.measurement_model.scale_tril = Rtril
         return super().forward(observations=z, controls=controls)
+
+
+# ------------------------------------------------------------------------------ unscented filter
+class JulierSigmaPointStrategy:
+    def __init__(self, lambd=None):
+        self.lambd = lambd
+
+    def compute_lambda(self, dim):
+        return 3.0 - dim if self.lambd is None else float(self.lambd)
+
+    def compute_sigma_weights(self, dim):
+        lambd = self.compute_lambda(dim)
+        wm = torch.full((2 * dim + 1,), 1.0 / (2.0 * (dim + lambd)))
+        wm[0] = lambd / (dim + lambd)
+        return wm.clone(), wm  # (weights_c, weights_m)
+
+
+class MerweSigmaPointStrategy:
+    def __init__(self, alpha=1e-2, beta=2.0, kappa=None):
+        self.alpha, self.beta, self.kappa = alpha, beta, kappa
+
+    def compute_lambda(self, dim):
+        kappa = 3.0 - dim if self.kappa is None else float(self.kappa)
+        return self.alpha ** 2 * (dim + kappa) - dim
+
+    def compute_sigma_weights(self, dim):
+        lambd = self.compute_lambda(dim)
+        wm = torch.full((2 * dim + 1,), 1.0 / (2.0 * (dim + lambd)))
+        wm[0] = lambd / (dim + lambd)
+        wc = wm.clone()
+        wc[0] = wm[0] + 1.0 - self.alpha ** 2 + self.beta
+        return wc, wm
+
+
+def sigma_points(mean, covariance, lambd):
+    """``(N, 2d+1, d)``: the mean, then ``mean +/- sqrt(d + lambda) chol(covariance)[:, i]``."""
+    N, d = mean.shape
+    L = torch.linalg.cholesky(covariance) * math.sqrt(d + lambd)
+    cols = L.transpose(-1, -2)  # row i = column i of L
+    return torch.cat([mean[:, None, :], mean[:, None, :] + cols, mean[:, None, :] - cols], dim=1)
+
+
+class VirtualSensorUnscentedKalmanFilter(ExtendedKalmanFilter):
+    """Upstream's UKF with a virtual sensor, written in its GENERAL form (unscented transform
+    through the dynamics, then through the measurement model -- here the identity, ``C = I``):
+    predict ``mu- = sum wm X'``, ``Sigma- = sum wc (X' - mu-)(..)^T + L L^T`` (noise at the belief
+    mean); update with fresh sigma points of ``(mu-, Sigma-)``: ``P_yy = sum wc (Y - y)(..)^T + R``,
+    ``P_xy = sum wc (X - mu-)(Y - y)^T``, ``K = P_xy P_yy^-1``."""
+
+    def __init__(self, *, dynamics_model, virtual_sensor_model, sigma_point_strategy=None):
+        ident = _IdentityMeasurementModel(state_dim=dynamics_model.state_dim)
+        super().__init__(dynamics_model=dynamics_model, measurement_model=ident)
+        self.virtual_sensor_model = virtual_sensor_model
+        self.sigma_point_strategy = sigma_point_strategy or JulierSigmaPointStrategy()
+
+    def forward(self, *, observations, controls):
+        assert self._initialized, "initialize_beliefs() first"
+        z, Rtril = self.virtual_sensor_model(observations=observations)
+        mu, Sigma = self._belief_mean, self._belief_covariance
+        N, d = mu.shape
+        P = 2 * d + 1
+        lambd = self.sigma_point_strategy.compute_lambda(d)
+        wc, wm = self.sigma_point_strategy.compute_sigma_weights(d)
+        X = sigma_points(mu, Sigma, lambd)
+        rep = SliceWrapper(controls).map(lambda t: torch.repeat_interleave(t, repeats=P, dim=0))
+        Xp = self.dynamics_model(initial_states=X.reshape(N * P, d), controls=rep)[0].reshape(N, P, d)
+        _, L = self.dynamics_model(initial_states=mu, controls=controls)
+        mu_p = torch.einsum("p,npi->ni", wm, Xp)
+        e = Xp - mu_p[:, None, :]
+        S_p = torch.einsum("p,npi,npj->nij", wc, e, e) + L @ L.transpose(-1, -2)
+        # measurement update through the (identity) measurement model
+        Xs = sigma_points(mu_p, S_p, lambd)
+        Y = Xs
+        y = torch.einsum("p,npi->ni", wm, Y)
+        ey, ex = Y - y[:, None, :], Xs - mu_p[:, None, :]
+        Pyy = torch.einsum("p,npi,npj->nij", wc, ey, ey) + Rtril @ Rtril.transpose(-1, -2)
+        Pxy = torch.einsum("p,npi,npj->nij", wc, ex, ey)
+        K = Pxy @ torch.inverse(Pyy)
+        self._belief_mean = mu_p + (K @ (z - y)[:, :, None]).squeeze(-1)
+        self._belief_covariance = S_p - K @ Pyy @ K.transpose(-1, -2)
+        return self._belief_mean

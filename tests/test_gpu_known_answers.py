@@ -390,3 +390,74 @@ def test_f16x3_error_against_fp64_within_2x_of_exact_f32_products_at_full_size()
         for net, e in r[mode].items():
             assert e["max_rel"] < 1e-5, (mode, net, e)
     assert max(r["f16x3_over_f32_max_err"].values()) <= 2.0, r["f16x3_over_f32_max_err"]
+
+
+@pytest.mark.parametrize("strategy", ["julier", "merwe"])
+def test_engine_unscented_filter_known_answers(strategy):
+    """``VirtualSensorUnscentedKalmanFilter`` (sigma points and moments in HIP, K2 for the points,
+    K3 for the update).  (a) forward-only LINEAR user models: equals the Kalman closed form (the
+    unscented transform is exact there).  (b) the door task's networks: means and covariances
+    within 1e-4 of the oracle's general-form UKF over 5 steps, loop == step-by-step."""
+    import multimodalfilter_amd as mmf
+
+    dev = _dev()
+    make = (lambda ns: ns.JulierSigmaPointStrategy()) if strategy == "julier" else \
+        (lambda ns: ns.MerweSigmaPointStrategy(alpha=0.5, beta=2.0))
+    # (a)
+    d = 3
+    A, B, L, Rt = _system(d)
+    N, T = 19, 5
+    g = torch.Generator().manual_seed(4)
+    us = torch.randn(T, N, 7, generator=g)
+    zs = torch.randn(T, N, d, generator=g)
+    mu0 = torch.randn(N, d, generator=g)
+    cov0 = (0.1 * torch.eye(d))[None].expand(N, d, d)
+    Dyn, Sensor, _ = _user_models(mmf.base, A, B, L, Rt, dev)
+    f = mmf.filters.VirtualSensorUnscentedKalmanFilter(dynamics_model=Dyn(), virtual_sensor_model=Sensor(),
+                                                       sigma_point_strategy=make(mmf.filters))
+    f.eval()
+    f.initialize_beliefs(mean=mu0.to(dev), covariance=cov0.to(dev))
+    est = f.forward_loop(observations={"z": zs.to(dev)}, controls=us.to(dev)).cpu()
+    cov = f._belief_covariance.cpu()
+    for n in range(N):
+        want = _kalman_closed_form(A, B, L, Rt, mu0[n], 0.1 * torch.eye(d), us[:, n], zs[:, n])
+        for t in range(T):
+            assert float((est[t, n].double() - want[t][0]).abs().max()) < REL_TOL * max(1.0, float(want[t][0].abs().max())), (n, t)
+        assert float((cov[n].double() - want[-1][1]).abs().max()) < REL_TOL
+
+    # (b)
+    task = om.TASKS["door"]
+    N, T = 33, 5
+    obs = {"image": (torch.randn((T, N, 32, 32), generator=g) * 0.5).clamp(-1, 1),
+           "gripper_pos": torch.randn((T, N, 3), generator=g), "gripper_sensors": torch.randn((T, N, 7), generator=g)}
+    ctrl = torch.randn((T, N, 7), generator=g)
+    x0 = torch.randn((N, d), generator=g)
+    cov0 = (0.1 * torch.eye(d))[None].expand(N, d, d)
+    base_o = om.build("DoorKalmanFilter")
+    base_o.load_state_dict(om.seeded_state_dict(base_o, seed=14, gain=1.0))
+    o = otf.filters.VirtualSensorUnscentedKalmanFilter(dynamics_model=base_o.dynamics_model,
+                                                       virtual_sensor_model=base_o.virtual_sensor_model,
+                                                       sigma_point_strategy=make(otf.filters))
+    o.eval()
+    with torch.no_grad():
+        o.initialize_beliefs(mean=x0, covariance=cov0)
+        want = o.forward_loop(observations=obs, controls=ctrl)
+    base_e = mmf.door_models.DoorKalmanFilter()
+    base_e.load_state_dict(base_o.state_dict())
+    e = mmf.filters.VirtualSensorUnscentedKalmanFilter(dynamics_model=base_e.dynamics_model,
+                                                       virtual_sensor_model=base_e.virtual_sensor_model,
+                                                       sigma_point_strategy=make(mmf.filters)).to(dev).eval()
+    e.initialize_beliefs(mean=x0.to(dev), covariance=cov0.to(dev))
+    odev = {k: v.to(dev) for k, v in obs.items()}
+    loop = e.forward_loop(observations=odev, controls=ctrl.to(dev))
+    cov_loop = e._belief_covariance.clone()
+    scale = max(1.0, float(want.abs().max()))
+    assert float((loop.cpu() - want).abs().max()) / scale < REL_TOL
+    assert float((cov_loop.cpu() - o._belief_covariance).abs().max()) / max(1.0, float(o._belief_covariance.abs().max())) < REL_TOL
+    e.initialize_beliefs(mean=x0.to(dev), covariance=cov0.to(dev))
+    step = torch.stack([e(observations={k: v[t] for k, v in odev.items()}, controls=ctrl[t].to(dev)) for t in range(T)])
+    assert torch.equal(step, loop) and torch.equal(e._belief_covariance, cov_loop)
+    # a covariance that is not positive definite is refused, as the Cholesky upstream would
+    e.initialize_beliefs(mean=x0.to(dev), covariance=-cov0.to(dev))
+    with pytest.raises(ValueError):
+        e(observations={k: v[0] for k, v in odev.items()}, controls=ctrl[0].to(dev))

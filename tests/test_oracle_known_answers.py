@@ -229,3 +229,27 @@ def test_particle_count_adaptation_without_resampling():
     torch.testing.assert_close((pf.particle_log_weights.exp()[:, :, None] * pf.particle_states).sum(1), mean,
                                atol=1e-6, rtol=1e-5)
     del old
+
+
+def test_unscented_filter_equals_kalman_filter_on_linear_system():
+    """The unscented transform is exact for linear maps: the (general-form) oracle UKF reproduces
+    the Kalman closed form with either sigma-point strategy."""
+    A, B, L, Rt = _system()
+    N, T, d = 4, 5, 3
+    g = torch.Generator().manual_seed(11)
+    us = torch.randn(T, N, 7, generator=g)
+    zs = torch.randn(T, N, d, generator=g)
+    mu0 = torch.randn(N, d, generator=g)
+    for strategy in (tf.filters.JulierSigmaPointStrategy(), tf.filters.MerweSigmaPointStrategy(alpha=0.5)):
+        f = tf.filters.VirtualSensorUnscentedKalmanFilter(dynamics_model=LinearDynamics(A, B, L),
+                                                          virtual_sensor_model=DirectSensor(d, Rt),
+                                                          sigma_point_strategy=strategy)
+        f.initialize_beliefs(mean=mu0, covariance=(0.1 * torch.eye(d))[None].expand(N, d, d))
+        est = f.forward_loop(observations={"z": zs}, controls=us)
+        for n in range(N):
+            want = _kalman_closed_form(A, B, L, Rt, mu0[n], 0.1 * torch.eye(d), us[:, n], zs[:, n])
+            for t in range(T):
+                torch.testing.assert_close(est[t, n], want[t][0], rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(f._belief_covariance[n], want[-1][1], rtol=1e-4, atol=1e-5)
+        wc, wm = strategy.compute_sigma_weights(d)
+        assert abs(float(wm.sum()) - 1.0) < 1e-5
