@@ -38,6 +38,8 @@ extern "C" {
 
 /* arithmetic of the 64x64 layers of the per-particle networks (K2) */
 #define MMF_PREC_F32 0    /* v_mfma_f32_32x32x2_f32: exact fp32 products                        */
+#define MMF_PREC_BF16 2   /* mmf_image_encoder only: operands rounded to ONE bf16, one v_mfma_*_bf16 per
+                           * product, f32 accumulate (BASELINE config 5's "bf16 measurement CNN on MFMA")   */
 #define MMF_PREC_F16X3 1  /* operands split x = hi + lo (2 x f16, exact to 2^-22), products
                              hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulate   */
 
@@ -246,9 +248,11 @@ int mmf_pack_image_encoder(const MmfImageEncoderDesc* desc /* host */, float* pa
  *  range_flag int32 on the device or null: MMF_PREC_F16X3 ORs 1 into it when an activation
  *             left the f16-split range (see mmf_pf_dynamics)
  *  variant    MMF_ENCODER_*: the architecture every blob of this call was packed for
- *  precision  MMF_PREC_F32: every layer on the f32 MFMA.  MMF_PREC_F16X3: the four 3x3
- *             convolutions (97 % of the MACs) as split-f16 products in persistent, register-
- *             prefetching workgroups; the 5x5 stem and the linear tail stay f32.
+ *  precision  MMF_PREC_F32: every layer on the f32 MFMA, one launch per layer.  MMF_PREC_F16X3: split-f16
+ *             products; stem + conv 32->32 and conv 32->32 + skip + conv 32->16 run as two fused,
+ *             persistent kernels with the activations in LDS (csrc/image_encoder_fused.inc).
+ *             MMF_PREC_BF16: the same two fused kernels with single bf16 products (94 % of the
+ *             MACs); conv 16->8 and the linear tail stay f16x3.
  */
 int mmf_image_encoder(const float* const* packed, int n_nets, const float* images, float* feat,
                       void* workspace, int32_t* range_flag, int precision, int variant, int N,

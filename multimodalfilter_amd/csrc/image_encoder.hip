@@ -60,6 +60,7 @@ struct Layout {
   int hfc;               // f16x3 fragment-ordered copy of the 8192 -> 64 linear layer's weights
   int hs;                // f16x3 5x5 stem as 2 k-steps of 16 taps: [k-step][hi|lo][lane][8 halves]
   int g3;                // f16x3 conv 32->16 for v_mfma_f32_16x16x32_f16: [tap][hi|lo][lane][8 halves]
+  int q2a, q2b, q3, qs;  // MMF_PREC_BF16 twins of h2a / h2b / g3 / hs: same fragment order, slot "hi" = bf16(w), slot "lo" unused
   int total;
 };
 // floats (= halves / 2) of a 3x3 conv in f16x3 fragment order [tap][kc][hi|lo][lane][8 halves]
@@ -90,6 +91,10 @@ __host__ __device__ constexpr Layout layout() {
   L.hfc = o; o += kFcSplit * (kFcK / kFcSplit / 16) * 2 * 2 * 64 * 8 / 2;  // [split][k-step][tile][hi|lo][lane][8 halves]
   L.hs = o; o += 2 * 2 * 64 * 8 / 2;
   L.g3 = o; o += 9 * 2 * 64 * 8 / 2;
+  L.q2a = o; o += conv_h_floats(32);
+  L.q2b = o; o += conv_h_floats(32);
+  L.q3 = o; o += 9 * 2 * 64 * 8 / 2;
+  L.qs = o; o += 2 * 2 * 64 * 8 / 2;
   L.total = o;
   return L;
 }
@@ -162,6 +167,30 @@ __global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ o
       v = d.res_w[1][o * kFeat + k];
     } else if (q0 < L.h2a) {
       v = d.res_b[1][q0 - L.r2b];
+    } else if (q0 >= L.q2a) {
+      // bf16 twins (round to nearest even): same index -> weight maps as h2a / h2b / g3 / hs, "lo" slots zero
+      const int offs[5] = {L.q2a, L.q2b, L.q3, L.qs, L.total};
+      int c = 0;
+      while (q0 >= offs[c + 1]) ++c;
+      unsigned short hb[2];
+      for (int z = 0; z < 2; ++z) {
+        const int he = 2 * (q0 - offs[c]) + z;
+        const int i = he & 7, lane = (he >> 3) & 63, part = (he >> 9) & 1, blk = he >> 10;
+        float w = 0.f;
+        if (c < 2) {  // conv 32->32: blk = tap * 2 + kc
+          const int kc = blk & 1, tap = blk >> 1;
+          w = d.conv_w[1 + c][((lane & 31) * 32 + 16 * kc + 8 * (lane >> 5) + i) * 9 + tap];
+        } else if (c == 2) {
+          w = d.conv_w[3][((lane & 15) * 32 + 8 * (lane >> 4) + i) * 9 + blk];
+        } else {
+          const int t = 16 * blk + 8 * (lane >> 5) + i;
+          w = t < 25 ? d.conv_w[0][(lane & 31) * 25 + t] : 0.f;
+        }
+        unsigned u = __float_as_uint(w);
+        u = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;  // finite weights: round to nearest even
+        hb[z] = part ? 0 : static_cast<unsigned short>(u);
+      }
+      v = __uint_as_float(static_cast<unsigned>(hb[0]) | (static_cast<unsigned>(hb[1]) << 16));
     } else if (q0 >= L.hs) {
       // fused path: stem (element i of lane (co, h) in k-step s = tap 16 s + 8 h + i, zero past 24) and
       // conv 32->16 in 16x16x32 fragments (element i of lane (co, q) for a tap = input channel 8 q + i)
@@ -769,7 +798,9 @@ extern "C" int mmf_image_encoder(const float* const* packed, int n_nets, const f
                                  int variant, int N, void* stream) {
   if (!packed || !images || !feat || !workspace) return MMF_EINVAL;
   if (n_nets < 1 || n_nets > kMaxNets || N < 0) return MMF_EINVAL;
-  if (precision != MMF_PREC_F32 && precision != MMF_PREC_F16X3) return MMF_EINVAL;
+  if (precision != MMF_PREC_F32 && precision != MMF_PREC_F16X3 && precision != MMF_PREC_BF16) return MMF_EINVAL;
+  const bool bf16 = precision == MMF_PREC_BF16;
+  if (bf16) precision = MMF_PREC_F16X3;  // conv 16->8 and the linear tail (6 % of the MACs) stay f16x3
   if (variant != MMF_ENCODER_DEFAULT && variant != MMF_ENCODER_SPANNING_POOL) return MMF_EINVAL;
   if (N == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -787,15 +818,15 @@ extern "C" int mmf_image_encoder(const float* const* packed, int n_nets, const f
   }
   c.N = N;
   int rc;
-  if (precision == MMF_PREC_F16X3 && !getenv("MMF_K4_UNFUSED")) {
+  if (precision == MMF_PREC_F16X3 && (bf16 || !getenv("MMF_K4_UNFUSED"))) {
     // fused path (image_encoder_fused.inc): image -> B (bufA), B -> D (bufB), D -> E (bufC)
     FusedArgs fa{};
     for (int i = 0; i < n_nets; ++i) fa.packed[i] = packed[i];
     fa.images = images; fa.N = N; fa.range_flag = range_flag;
     fa.out = bufA;
-    if ((rc = launch_fused(fa, n_nets, 0, s))) return rc;
+    if ((rc = launch_fused(fa, n_nets, 0, bf16, s))) return rc;
     fa.bin = bufA; fa.out = bufB;
-    if ((rc = launch_fused(fa, n_nets, 1, s))) return rc;
+    if ((rc = launch_fused(fa, n_nets, 1, bf16, s))) return rc;
     ConvHArgs hcv{};
     for (int i = 0; i < n_nets; ++i) hcv.packed[i] = packed[i];
     hcv.N = N; hcv.range_flag = range_flag;

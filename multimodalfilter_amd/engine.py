@@ -119,6 +119,22 @@ def set_default_precision(name: str):
     DEFAULT_PRECISION = name
 
 
+# Arithmetic of the image encoders (K4): None follows DEFAULT_PRECISION; "bf16" = single bf16
+# products with fp32 accumulation in the two fused convolution kernels (BASELINE config 5's "bf16
+# measurement CNN on MFMA"; a reduced-precision mode, ~1e-2 relative on the features -- opt-in).
+IMAGE_ENCODER_PRECISION = os.environ.get("MMF_K4_PRECISION") or None
+
+
+def set_image_encoder_precision(name):
+    global IMAGE_ENCODER_PRECISION
+    assert name is None or name in _abi.IMAGE_PRECISIONS, name
+    IMAGE_ENCODER_PRECISION = name
+
+
+def image_encoder_precision_code() -> int:
+    return _abi.IMAGE_PRECISIONS[IMAGE_ENCODER_PRECISION or DEFAULT_PRECISION]
+
+
 # Training: the HIP kernels are forward-only (K6, the backward kernels, are not built).  With
 # the training backend set to "autograd", modules in train() mode evaluate through ordinary
 # differentiable torch ops on the device instead, so the reference's curricula (30 particles,
@@ -529,7 +545,7 @@ def encode_images(encoders, images: torch.Tensor):
             chunk = images[c0:c0 + n]
             feat = torch.empty((len(grp), n, 64), dtype=torch.float32, device=images.device)
             ws = _image_workspace(images.device, n, len(grp))
-            prec = _abi.PRECISIONS[DEFAULT_PRECISION]
+            prec = image_encoder_precision_code()
             flag = range_flag(images.device)
             _timed("image_encoder", image_encoder_flops(n) * len(grp), 0.0,
                    lambda: _abi.image_encoder(packs, chunk, feat, ws, flag, prec, variant))

@@ -19,7 +19,8 @@ def main():
         encs = [layers.image_encoder(64).to(dev) for _ in range(nets)]
         img = (torch.randn((n_img, 32, 32), device=dev) * 0.5).clamp(-1, 1)
         outs = {}
-        for mode in ("fused", "unfused"):
+        for mode in ("fused", "bf16", "unfused"):
+            engine.set_image_encoder_precision("bf16" if mode == "bf16" else None)
             if mode == "unfused":
                 os.environ["MMF_K4_UNFUSED"] = "1"
             else:
@@ -39,8 +40,10 @@ def main():
             print(json.dumps({"mode": mode, "images": n_img, "nets": nets, "ms": round(ms, 4),
                               "ns_per_image_encoder": round(1e6 * ms / (n_img * nets), 1),
                               "algorithmic_tflops": round(flops / ms / 1e9, 1)}), flush=True)
-        err = float((outs["fused"] - outs["unfused"]).abs().max()) / max(1.0, float(outs["unfused"].abs().max()))
-        print(json.dumps({"images": n_img, "nets": nets, "fused_vs_unfused_max_rel": err}), flush=True)
+        scale = max(1.0, float(outs["unfused"].abs().max()))
+        print(json.dumps({"images": n_img, "nets": nets,
+                          "fused_vs_unfused_max_rel": float((outs["fused"] - outs["unfused"]).abs().max()) / scale,
+                          "bf16_vs_unfused_max_rel": float((outs["bf16"] - outs["unfused"]).abs().max()) / scale}), flush=True)
     os.environ.pop("MMF_K4_UNFUSED", None)
 
 

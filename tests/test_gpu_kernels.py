@@ -366,6 +366,38 @@ def test_k4_image_encoders_match_oracle(N, nets):
     assert _rel_err(engine.encode_images(encs[:1], img.to(dev))[0].cpu(), want) < 1e-4
 
 
+@pytest.mark.parametrize("N,nets", [(1, 1), (37, 2), (300, 3)])
+def test_k4_bf16_mode_is_a_reduced_precision_twin(N, nets):
+    """MMF_PREC_BF16 (BASELINE config 5: "bf16 measurement CNN on MFMA"): the two fused
+    convolution kernels with ONE bf16 product per MAC and fp32 accumulation.  Stated tolerance:
+    3e-2 relative on the 64 features (bf16 keeps 8 significant bits; five layers deep), and the
+    mode must differ from the default arithmetic (it is really running)."""
+    from multimodalfilter_amd import engine, layers
+
+    dev = _cuda()
+    g = torch.Generator().manual_seed(900 + N)
+    img = (torch.randn((N, 32, 32), generator=g) * 0.5).clamp(-1, 1)
+    oracles = [_seeded(om.image_encoder(64), seed=40 + k) for k in range(nets)]
+    encs = []
+    for o in oracles:
+        e = layers.image_encoder(64)
+        e.load_state_dict(o.state_dict())
+        encs.append(e.to(dev))
+    exact = engine.encode_images(encs, img.to(dev))
+    engine.set_image_encoder_precision("bf16")
+    try:
+        got = engine.encode_images(encs, img.to(dev))
+    finally:
+        engine.set_image_encoder_precision(None)
+    for o, gk, ek in zip(oracles, got, exact):
+        with torch.no_grad():
+            want = o(img[:, None])
+        err = _rel_err(gk.cpu(), want)
+        assert err < 3e-2, err
+        assert _rel_err(ek.cpu(), want) < 1e-4
+        assert not torch.equal(gk, ek)
+
+
 @pytest.mark.parametrize("N", [1, 5, 64])
 def test_k4_spanning_pool_variant_and_mixed_batches(N):
     """The push virtual sensor's stack (16->2 convolution, full-height / full-width average
