@@ -16,7 +16,8 @@ import sys
 
 OURS = ("particle_net_kernel", "pf_reweight_resample_kernel", "ekf_step_kernel", "conv_kernel",
         "conv_f16x3_kernel", "fc_partial_kernel", "fc_partial_f16x3_kernel", "fc_tail_kernel", "weight_grad_kernel", "pf_init_particles_kernel", "fuse_sensors_kernel", "traj_program_kernel",
-        "pack_particle_net_kernel", "pack_encoder_kernel")
+        "pack_particle_net_kernel", "pack_encoder_kernel", "stem_conv2a_kernel", "conv2b_conv3_kernel",
+        "ukf_sigma_points_kernel", "ukf_moments_kernel", "ekf_")
 
 
 def short(name: str) -> str:
@@ -75,7 +76,35 @@ def main(src, dst):
                     "read; 'hbm_bytes_corrected' doubles FETCH_SIZE. Image-encoder and K7 kernels: launches over the "
                     "warm-up (256 images) and the timed chunk (1024 images) are averaged together.",
             "kernels": kernels}, fh, indent=1)
-    for f in glob.glob(f"{src}/bench_*.json") + glob.glob(f"{src}/pytest_*.txt"):
+    # optional extras of the round script: f32-mode and EKF kernel stats, K4-alone traffic
+    for tag in ("f32", "ekf"):
+        hits = glob.glob(f"{src}/stats_{tag}/**/*_kernel_stats.csv", recursive=True)
+        if hits:
+            shutil.copy(max(hits, key=os.path.getmtime), f"{dst}/door_{'pf_f32_mode' if tag == 'f32' else 'ekf'}_kernel_stats.csv")
+    k4 = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        hits = glob.glob(f"{src}/pmc_k4_{counter}/**/*_counter_collection.csv", recursive=True)
+        if not hits:
+            continue
+        with open(max(hits, key=os.path.getmtime)) as fh:
+            for row in csv.DictReader(fh):
+                if any(k in row["Kernel_Name"] for k in OURS) and row["Counter_Name"] == counter:
+                    key = (short(row["Kernel_Name"]), row["Grid_Size_X"] if "Grid_Size_X" in row else row.get("Grid_Size", ""))
+                    k4.setdefault(key, {}).setdefault(counter, []).append(float(row["Counter_Value"]))
+    if k4:
+        rows = {}
+        for (name, grid), c in sorted(k4.items()):
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                f = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
+                w = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
+                rows[f"{name} grid={grid}"] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_corrected": (2.0 * f + w) * 1024.0,
+                                               "launches": len(c["FETCH_SIZE"])}
+        with open(f"{dst}/pmc_k4_traffic.json", "w") as fh:
+            json.dump({"command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace -- python3 scripts/bench_k4.py "
+                                  "(fused / bf16 / per-layer paths on 2048x2, 1024x3, 256x2, 32x3 image-encoders)",
+                       "note": "bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction); launches grouped by kernel and grid size",
+                       "kernels": rows}, fh, indent=1)
+    for f in glob.glob(f"{src}/bench_*.json") + glob.glob(f"{src}/pytest_*.txt") + glob.glob(f"{src}/bench_*.txt"):
         shutil.copy(f, dst)
     print("kept", sorted(os.listdir(dst)))
 
