@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 16
+#define MMF_ABI_VERSION 17
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -367,6 +367,19 @@ int mmf_ekf_step(const float* A, const float* mu_pred, const float* q_tril, cons
                  const float* r_tril, const float* fuse_w, float* mu, float* Sigma,
                  float* mu_f, float* Sigma_f, int N, int d, int K, int fusion, int feedback,
                  void* stream);
+
+/* K6: reverse mode of mmf_ekf_step without fusion (fusion = 0; the fusions of the K sub-filters
+ * are a handful of element-wise torch ops on (K, N, d) and keep their autograd form).  Inputs as
+ * the forward call's, Sigma_in = the covariances BEFORE the step; g_mu (K, N, d) / g_Sigma
+ * (K, N, d, d): gradients of the corrected beliefs (either may be null = zero).  Outputs (any may
+ * be null): g_A, g_mu_pred, g_z, g_r_tril, g_Sigma_in, shaped like their forward operands.
+ * Used by the "hip" training backend for every EKF the reference trains end to end
+ * (crossmodal/train_helpers.py:124-162; base_models/crossmodal_kf.py:88-151).
+ */
+int mmf_ekf_step_backward(const float* A, const float* mu_pred, const float* q_tril, const float* z,
+                          const float* r_tril, const float* Sigma_in, const float* g_mu,
+                          const float* g_Sigma, float* g_A, float* g_mu_pred, float* g_z,
+                          float* g_r_tril, float* g_Sigma_in, int N, int d, int K, void* stream);
 
 /* ---------------------------------------------------------------- unscented transform (UKF)
  * torchfilter's UnscentedKalmanFilter / VirtualSensorUnscentedKalmanFilter (absent, un-pinned

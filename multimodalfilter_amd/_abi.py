@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmmf_hip.so")
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 16
+ABI_VERSION = 17
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
 IMAGE_PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16": PREC_BF16}  # image encoder (K4)
@@ -91,6 +91,7 @@ SIGNATURES = {
     "mmf_pf_measure": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, c_int, _FP, c_int, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_dynamics_jacobian": (c_int, [_FP, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_ekf_step": (c_int, [_FP] * 10 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmf_ekf_step_backward": (c_int, [_FP] * 13 + [c_int, c_int, c_int, c_void_p]),
     "mmf_ukf_sigma_points": (c_int, [_FP, _FP, ctypes.c_float, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_ukf_moments": (c_int, [_FP, ctypes.c_float, ctypes.c_float, ctypes.c_float, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_pf_reweight_backward": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
@@ -222,6 +223,14 @@ def ekf_step(A, mu_pred, q_tril, z, r_tril, fuse_w, mu, Sigma, mu_f, Sigma_f, fu
         _check(load().mmf_ekf_step(ptr(A), ptr(mu_pred), ptr(q_tril), ptr(z), ptr(r_tril),
                                    ptr(fuse_w), ptr(mu), ptr(Sigma), ptr(mu_f), ptr(Sigma_f),
                                    N, d, K, fusion, feedback, stream_of(mu_pred)), "mmf_ekf_step")
+
+
+def ekf_step_backward(A, mu_pred, q_tril, z, r_tril, Sigma_in, g_mu, g_Sigma, g_A, g_mu_pred, g_z, g_r_tril, g_Sigma_in):
+    K, N, d = mu_pred.shape
+    with _on(mu_pred):
+        _check(load().mmf_ekf_step_backward(ptr(A), ptr(mu_pred), ptr(q_tril), ptr(z), ptr(r_tril), ptr(Sigma_in),
+                                            ptr(g_mu), ptr(g_Sigma), ptr(g_A), ptr(g_mu_pred), ptr(g_z), ptr(g_r_tril),
+                                            ptr(g_Sigma_in), N, d, K, stream_of(mu_pred)), "mmf_ekf_step_backward")
 
 
 def ukf_sigma_points(mu, Sigma, scale: float, points, not_pd):

@@ -258,6 +258,117 @@ __global__ __launch_bounds__(256) void ekf_step_kernel(
   }
 }
 
+// K6 (K3 backward): reverse mode of one sub-filter's predict + correct, one row per lane.
+// Forward (recomputed in registers):  AS = A S0;  Sp = AS A^T + L L^T;  Rm = T T^T;  Si = (Sp + Rm)^-1;
+//   G = Sp Si;  mu = mp + G (z - mp);  S = (I - G) Sp.
+// Reverse, given g_mu and g_S:
+//   g(I-G) = g_S Sp^T;  gSp = (I-G)^T g_S;  gG = g_mu (z - mp)^T - g(I-G);  g_z = G^T g_mu;  g_mp = g_mu - g_z;
+//   gSp += gG Si^T;  gSi = Sp^T gG;  gSinn = -Si^T gSi Si^T;  gSp += gSinn;  gT = (gSinn + gSinn^T) T;
+//   gA = gSp^T AS + (gSp A) S0^T;  gS0 = A^T (gSp A).
+template <int D>
+__device__ __forceinline__ Mat<D> transpose(const Mat<D>& x) {
+  Mat<D> r;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) r.a[i][j] = x.a[j][i];
+  return r;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void ekf_step_backward_kernel(
+    const float* __restrict__ A, const float* __restrict__ mu_pred, const float* __restrict__ q_tril,
+    const float* __restrict__ z, const float* __restrict__ r_tril, const float* __restrict__ Sigma_in,
+    const float* __restrict__ g_mu, const float* __restrict__ g_Sigma, float* __restrict__ g_A,
+    float* __restrict__ g_mu_pred, float* __restrict__ g_z, float* __restrict__ g_r_tril,
+    float* __restrict__ g_Sigma_in, int N, int K) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= K * N) return;
+  const int k = row / N;
+  const Mat<D> Ak = load_mat<D>(A + static_cast<size_t>(row) * D * D);
+  const Mat<D> S0 = load_mat<D>(Sigma_in + static_cast<size_t>(row) * D * D);
+  const Mat<D> L = load_mat<D>(q_tril + static_cast<size_t>(k) * D * D);
+  const Mat<D> T = load_mat<D>(r_tril + static_cast<size_t>(row) * D * D);
+  const Mat<D> AS = matmul<D>(Ak, S0);
+  Mat<D> Sp = matmul_nt<D>(AS, Ak);
+  const Mat<D> Q = matmul_nt<D>(L, L);
+  const Mat<D> Rm = matmul_nt<D>(T, T);
+  Mat<D> Sinn;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      Sp.a[i][j] += Q.a[i][j];
+      Sinn.a[i][j] = Sp.a[i][j] + Rm.a[i][j];
+    }
+  const Mat<D> Si = inverse<D>(Sinn);
+  const Mat<D> G = matmul<D>(Sp, Si);
+  float innov[D], gm[D];
+  Mat<D> ImG, gS;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    innov[i] = z[static_cast<size_t>(row) * D + i] - mu_pred[static_cast<size_t>(row) * D + i];
+    gm[i] = g_mu ? g_mu[static_cast<size_t>(row) * D + i] : 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      ImG.a[i][j] = ((i == j) ? 1.f : 0.f) - G.a[i][j];
+      gS.a[i][j] = g_Sigma ? g_Sigma[(static_cast<size_t>(row) * D + i) * D + j] : 0.f;
+    }
+  }
+  // S = ImG Sp
+  const Mat<D> gImG = matmul_nt<D>(gS, Sp);               // g_S Sp^T
+  Mat<D> gSp = matmul<D>(transpose<D>(ImG), gS);          // ImG^T g_S
+  // mu = mp + G innov
+  Mat<D> gG;
+  float gz[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      gG.a[i][j] = gm[i] * innov[j] - gImG.a[i][j];
+      s += G.a[j][i] * gm[j];
+    }
+    gz[i] = s;
+  }
+  // G = Sp Si
+  const Mat<D> gSp2 = matmul_nt<D>(gG, Si);               // gG Si^T
+  const Mat<D> gSi = matmul<D>(transpose<D>(Sp), gG);     // Sp^T gG
+  // Si = Sinn^-1:  gSinn = -Si^T gSi Si^T
+  const Mat<D> SiT = transpose<D>(Si);
+  const Mat<D> tmp = matmul<D>(SiT, gSi);
+  Mat<D> gSinn = matmul<D>(tmp, SiT);
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      gSinn.a[i][j] = -gSinn.a[i][j];
+      gSp.a[i][j] += gSp2.a[i][j] + gSinn.a[i][j];
+    }
+  // Rm = T T^T:  gT = (gSinn + gSinn^T) T
+  Mat<D> sym;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j < D; ++j) sym.a[i][j] = gSinn.a[i][j] + gSinn.a[j][i];
+  const Mat<D> gT = matmul<D>(sym, T);
+  // Sp = AS A^T (+ Q):  gAS = gSp A;  gA = gSp^T AS;  AS = A S0:  gA += gAS S0^T;  gS0 = A^T gAS
+  const Mat<D> gAS = matmul<D>(gSp, Ak);
+  Mat<D> gA = matmul<D>(transpose<D>(gSp), AS);
+  const Mat<D> gA2 = matmul_nt<D>(gAS, S0);
+  const Mat<D> gS0 = matmul<D>(transpose<D>(Ak), gAS);
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) gA.a[i][j] += gA2.a[i][j];
+    if (g_z) g_z[static_cast<size_t>(row) * D + i] = gz[i];
+    if (g_mu_pred) g_mu_pred[static_cast<size_t>(row) * D + i] = gm[i] - gz[i];
+  }
+  if (g_A) store_mat<D>(g_A + static_cast<size_t>(row) * D * D, gA);
+  if (g_r_tril) store_mat<D>(g_r_tril + static_cast<size_t>(row) * D * D, gT);
+  if (g_Sigma_in) store_mat<D>(g_Sigma_in + static_cast<size_t>(row) * D * D, gS0);
+}
+
 // R11: fusion of K virtual sensors BEFORE a single EKF, one trajectory per lane.
 //   mode 1  /root/reference/crossmodal/base_models/crossmodal_kf.py:291-359
 //           mu = sum_k w_k z_k / (sum_k w_k + 1e-9);  Sigma = (prod_k prod_i w_ki) sum_k T_k T_k^T;
@@ -385,6 +496,26 @@ extern "C" int mmf_ekf_step(const float* A, const float* mu_pred, const float* q
     MMF_K3(1) MMF_K3(2) MMF_K3(3) MMF_K3(4)
   }
 #undef MMF_K3
+  MMF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int mmf_ekf_step_backward(const float* A, const float* mu_pred, const float* q_tril, const float* z,
+                                     const float* r_tril, const float* Sigma_in, const float* g_mu,
+                                     const float* g_Sigma, float* g_A, float* g_mu_pred, float* g_z,
+                                     float* g_r_tril, float* g_Sigma_in, int N, int d, int K, void* stream) {
+  if (!A || !mu_pred || !q_tril || !z || !r_tril || !Sigma_in) return MMF_EINVAL;
+  if (N < 0 || K < 1 || d < 1 || d > MMF_MAX_STATE_DIM) return MMF_EINVAL;
+  if (N == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = (K * N + 255) / 256;
+#define MMF_K3B(D)                                                                                          \
+  case D:                                                                                                   \
+    ekf_step_backward_kernel<D><<<grid, 256, 0, s>>>(A, mu_pred, q_tril, z, r_tril, Sigma_in, g_mu, g_Sigma, \
+                                                     g_A, g_mu_pred, g_z, g_r_tril, g_Sigma_in, N, K);      \
+    break;
+  switch (d) { MMF_K3B(1) MMF_K3B(2) MMF_K3B(3) MMF_K3B(4) }
+#undef MMF_K3B
   MMF_CHECK_LAUNCH();
   return 0;
 }

@@ -380,6 +380,37 @@ class ReweightEstimateFunction(torch.autograd.Function):
         return d_a, d_a, d_states
 
 
+class EkfStepFunction(torch.autograd.Function):
+    """K6 (K3): one sub-filter's predict + correct, ``(A (N,d,d), mu_pred (N,d), q_tril (d,d), z (N,d),
+    r_tril (N,d,d), Sigma (N,d,d)) -> (mu (N,d), Sigma' (N,d,d))``; forward = ``mmf_ekf_step`` (fusion
+    0), backward = ``mmf_ekf_step_backward`` (closed-form adjoints, one trajectory per lane).  The
+    dynamics noise ``q_tril`` is a fixed parameter of the reference's models: no gradient."""
+
+    @staticmethod
+    def forward(ctx, A, mu_pred, q_tril, z, r_tril, Sigma):
+        require_device(mu_pred, "EkfStepFunction")
+        N, d = mu_pred.shape
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        A_, mp_, q_, z_, r_, S_ = f32(A).view(1, N, d, d), f32(mu_pred).view(1, N, d), f32(q_tril).view(1, d, d), \
+            f32(z).view(1, N, d), f32(r_tril).view(1, N, d, d), f32(Sigma).view(1, N, d, d)
+        mu = torch.empty((1, N, d), dtype=torch.float32, device=mu_pred.device)
+        S_out = S_.clone()
+        _abi.ekf_step(A_, mp_, q_, z_, r_, None, mu, S_out, None, None, fusion=0, feedback=0)
+        ctx.save_for_backward(A_, mp_, q_, z_, r_, S_)
+        return mu[0], S_out[0]
+
+    @staticmethod
+    def backward(ctx, g_mu, g_Sigma):
+        A_, mp_, q_, z_, r_, S_ = ctx.saved_tensors
+        _, N, d = mp_.shape
+        c = lambda g, shape: None if g is None else g.to(torch.float32).contiguous().view(shape)
+        g_A, g_r, g_S = torch.empty_like(A_), torch.empty_like(r_), torch.empty_like(S_)
+        g_mp, g_z = torch.empty_like(mp_), torch.empty_like(z_)
+        _abi.ekf_step_backward(A_, mp_, q_, z_, r_, S_, c(g_mu, (1, N, d)), c(g_Sigma, (1, N, d, d)),
+                               g_A, g_mp, g_z, g_r, g_S)
+        return g_A[0], g_mp[0], None, g_z[0], g_r[0], g_S[0]
+
+
 def run_dynamics(net: PackedParticleNet, states: torch.Tensor, traj_bias: torch.Tensor,
                  noise, scale_tril, out: torch.Tensor = None) -> torch.Tensor:
     """``states`` ``(N, M, d)`` or ``(R, d)`` with ``traj_bias`` ``(N, 64)``."""

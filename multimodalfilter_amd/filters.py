@@ -443,6 +443,11 @@ class VirtualSensorExtendedKalmanFilter(base.Filter):
         z, r_tril = self.virtual_sensor_model(observations=observations)
         mu_pred, L = self.dynamics_model(initial_states=mu, controls=controls)
         A = self.dynamics_model.jacobian(initial_states=mu, controls=controls)
+        if engine.use_hip_backward():
+            # K6: the Kalman algebra forward (K3) and backward (closed-form adjoints) in HIP; the
+            # networks around it (sensor, dynamics, Jacobian) keep their autograd form
+            self._belief_mean, self._belief_covariance = engine.EkfStepFunction.apply(A, mu_pred, L[0], z, r_tril, Sigma)
+            return self._belief_mean
         Sp = A @ Sigma @ A.transpose(-1, -2) + L @ L.transpose(-1, -2)
         K = Sp @ torch.inverse(Sp + r_tril @ r_tril.transpose(-1, -2))
         self._belief_mean = mu_pred + (K @ (z - mu_pred)[:, :, None]).squeeze(-1)

@@ -101,8 +101,15 @@ def test_particle_filter_training_step_matches_oracle(training_backend, tname, c
 @pytest.mark.parametrize("tname,cls,kw", [("door", "DoorCrossmodalKalmanFilter", {}),
                                           ("push", "PushUnimodalKalmanFilter", {}),
                                           ("door", "DoorKalmanFilter", {})])
-def test_kalman_filter_training_step_matches_oracle(autograd_backend, tname, cls, kw):
+def test_kalman_filter_training_step_matches_oracle(training_backend, tname, cls, kw):
+    """"autograd": torch ops throughout; "hip": every sub-filter's Kalman algebra through K3
+    forward + ``mmf_ekf_step_backward`` (``engine.EkfStepFunction``)."""
     import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine
+
+    calls = []
+    real = engine.EkfStepFunction.apply
+    engine.EkfStepFunction.apply = lambda *a: (calls.append(1), real(*a))[1]
 
     dev = torch.device("cuda:0")
     task = om.TASKS[tname]
@@ -118,9 +125,46 @@ def test_kalman_filter_training_step_matches_oracle(autograd_backend, tname, cls
     eng.load_state_dict(oracle.state_dict())
     eng.to(dev).train()
     eng.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
-    pred = eng.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
+    try:
+        pred = eng.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
+    finally:
+        engine.EkfStepFunction.apply = real
+    assert (len(calls) >= T) == (training_backend == "hip")
     loss_e = torch.mean((pred - target.to(dev)) ** 2)
     _compare_grads(oracle, eng, loss_o, loss_e)
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4])
+def test_k6_ekf_step_function_matches_fp64_autograd(d):
+    """K3 backward: every gradient of ``engine.EkfStepFunction`` (A, mu_pred, z, r_tril, Sigma)
+    against fp64 torch autograd through the same algebra, 1e-4 relative, ragged N."""
+    from multimodalfilter_amd import engine
+
+    dev = torch.device("cuda:0")
+    N = 301
+    g = torch.Generator().manual_seed(60 + d)
+    A = (torch.eye(d) + 0.2 * torch.randn((N, d, d), generator=g))
+    mp, z = torch.randn((N, d), generator=g), torch.randn((N, d), generator=g)
+    q = torch.diag(0.1 + 0.2 * torch.rand((d,), generator=g))
+    T = torch.diag_embed(0.2 + torch.rand((N, d), generator=g)) + 0.05 * torch.randn((N, d, d), generator=g)
+    B = torch.randn((N, d, d), generator=g)
+    S = 0.1 * torch.eye(d) + 0.05 * B @ B.transpose(-1, -2)
+    gm, gS = torch.randn((N, d), generator=g), torch.randn((N, d, d), generator=g)
+    leaves = [A, mp, z, T, S]
+    dv = [t.to(dev).requires_grad_(True) for t in leaves]
+    mu, Sn = engine.EkfStepFunction.apply(dv[0], dv[1], q.to(dev), dv[2], dv[3], dv[4])
+    got = torch.autograd.grad([mu, Sn], dv, [gm.to(dev), gS.to(dev)])
+    r = [t.double().requires_grad_(True) for t in leaves]
+    A6, mp6, z6, T6, S6 = r
+    Sp = A6 @ S6 @ A6.transpose(-1, -2) + (q @ q.T).double()
+    K = Sp @ torch.inverse(Sp + T6 @ T6.transpose(-1, -2))
+    mu6 = mp6 + (K @ (z6 - mp6)[:, :, None]).squeeze(-1)
+    S6n = (torch.eye(d, dtype=torch.float64) - K) @ Sp
+    want = torch.autograd.grad([mu6, S6n], r, [gm.double(), gS.double()])
+    assert float((mu.detach().cpu().double() - mu6.detach()).abs().max()) < 1e-4
+    for name, a, b in zip("A mu_pred z r_tril Sigma".split(), got, want):
+        scale = max(1e-6, float(b.abs().max()))
+        assert float((a.cpu().double() - b).abs().max()) / scale < 1e-4, name
 
 
 def test_eval_mode_stays_on_the_hip_path(autograd_backend):
