@@ -61,11 +61,32 @@ def pmc_traffic(kernel_key: str):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
     collected in separate runs of this same command; FETCH_SIZE doubled as the gfx950 note of
     MI355X_MICROARCH.md prescribes).  ``None`` when no profile of this workload is committed."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02", "pmc_hbm_traffic.json")
     try:
         with open(path) as fh:
-            k = json.load(fh)["kernels"][kernel_key]
-        return k["hbm_bytes_corrected"]
+            kernels = json.load(fh)["kernels"]
+        hits = [v for name, v in kernels.items() if name.startswith(kernel_key)]
+        return hits[0]["hbm_bytes_corrected"] if hits else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def pmc_traffic_k4_sequence(n_images: int, nets: int):
+    """HBM bytes of ONE fused image-encoder launch sequence (stem+conv2a, conv2b+conv3, conv 16->8,
+    linear partials + tail) from the committed K4 PMC passes (``scripts/bench_k4.py`` under
+    rocprofv3, ``profiles/r02/pmc_k4_traffic.json``), for the launch shape that was profiled."""
+    path = os.path.join(ROOT, "profiles", "r02", "pmc_k4_traffic.json")
+    shapes = {(2048, 2): ("131072", "131072", "131072", "131072", "262144"), (1024, 3): ("130560", "130560", "130560", "98304", "196608")}
+    if (n_images, nets) not in shapes:
+        return None
+    g = shapes[(n_images, nets)]
+    try:
+        with open(path) as fh:
+            k = json.load(fh)["kernels"]
+        names = (f"stem_conv2a_kernel<false> grid={g[0]}", f"conv2b_conv3_kernel<false> grid={g[1]}",
+                 f"conv_f16x3_kernel<16, 8, false, false, 8> grid={g[2]}", f"fc_partial_f16x3_kernel grid={g[3]}",
+                 f"fc_tail_kernel<false> grid={g[4]}")
+        return sum(k[n]["hbm_bytes_corrected"] for n in names)
     except (OSError, KeyError, ValueError):
         return None
 
@@ -530,7 +551,7 @@ def main():
                    "world_size_seen": world,
                    "parallelism": f"trajectory-sharded x{world}"},
         "posterior_rmse_vs_truth": [float(x) for x in rmse],
-        "traffic_source": "profiles/r01/pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+        "traffic_source": "profiles/r02/pmc_hbm_traffic.json, pmc_k4_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                           "separate passes; bytes per launch = 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction)",
     }
 
@@ -565,13 +586,14 @@ def main():
             # (stem + four 3x3 convolutions + linear tail) is the dominant "kernel"
             dom = ks["image_encoder"]
             ach = dom["flops_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "image encoder launch sequence (conv_kernel<1,32,5>, 4 x conv_f16x3_kernel, "
-                                         "fc_partial_kernel, fc_tail_kernel) per chunk of images",
+            out["roofline"] = {"kernel": "image encoder launch sequence (stem_conv2a_kernel, conv2b_conv3_kernel, "
+                                         "conv_f16x3_kernel<16,8>, fc_partial_f16x3_kernel, fc_tail_kernel) per chunk of images",
                                "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK["f16x3"], "unit": "TFLOP/s",
-                               "frac": ach / MFMA_PEAK["f16x3"], "traffic": None,
-                               "note": "ALGORITHMIC fp32 FLOPs (26.12 MMAC per image per encoder); the 3x3 convolutions "
-                                       "execute 3 f16 MFMA products per product and move fp32 activations between "
-                                       "layers through HBM/L2, which is what bounds them today (DESIGN.md K4)"}
+                               "frac": ach / MFMA_PEAK["f16x3"],
+                               "traffic": pmc_traffic_k4_sequence(1024, 3) if (B == 1024 and args.workload == "door_ekf") else None,
+                               "note": "ALGORITHMIC fp32 FLOPs (26.12 MMAC per image per encoder); every product is 3 f16 MFMA "
+                                       "products (executed-MFMA fraction = 3 x frac); traffic = one launch sequence over 1024 "
+                                       "images x 3 encoders (DESIGN.md K4)"}
     if "roofline" not in out:
         out["roofline"] = None
 
