@@ -240,16 +240,16 @@ def cpu_baseline_pf(wl, engine_filter, state_dim, cores, sample_batch=32, sample
         },
     }
     # also a single-thread figure and upstream's multinomial resampling (bounded: ~3 steps each)
-    def small(batch, mode, threads, seed):
+    def small(batch, mode, threads, seed, steps=3):
         torch.set_num_threads(threads)
-        tr = synthetic.make_trajectories(state_dim=state_dim, T=4, N=batch, seed=seed)
-        e0, e, u = synthetic.draw_filter_noise(T=4, N=batch, M=M, state_dim=state_dim, seed=seed + 1, mode=mode)
+        tr = synthetic.make_trajectories(state_dim=state_dim, T=steps + 1, N=batch, seed=seed)
+        e0, e, u = synthetic.draw_filter_noise(T=steps + 1, N=batch, M=M, state_dim=state_dim, seed=seed + 1, mode=mode)
         _, t, _ = oracle_pf_run(wl["cls"], sd, tr, e0, e, u, M, mode=mode, warm=1, keep_beliefs=False)
         torch.set_num_threads(cores)
-        return {"value": batch * M * 3 / t, "unit": "particle-steps/s", "cores": threads, "resample": mode,
-                "sample": f"batch {batch} x {M} particles x 3 steps after 1 warm-up, {t:.1f} s"}
+        return {"value": batch * M * steps / t, "unit": "particle-steps/s", "cores": threads, "resample": mode,
+                "sample": f"batch {batch} x {M} particles x {steps} steps after 1 warm-up, {t:.1f} s"}
 
-    extra = {"single_thread": small(4, "systematic", 1, 5151),
+    extra = {"single_thread": small(sample_batch, "systematic", 1, 5151, steps=6),
              "multinomial": small(sample_batch, "multinomial", cores, 5252)}
     return {"value": cpu_rate, "unit": "particle-steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle PF (oracle/), {wl['cls']}, batch {sample_batch} x {M} particles x "
