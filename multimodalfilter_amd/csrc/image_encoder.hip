@@ -1,28 +1,23 @@
-// K4: the 32x32 image encoder (R5) as implicit-GEMM convolutions on v_mfma_f32_16x16x4_f32.
+// K4: the 32x32 image encoder (R5).
 //
 // Replaces nn.Sequential(Conv 1->32 k5, ReLU, ResConv 32 k3, Conv 32->16 k3, ReLU,
 // Conv 16->8 k3, Flatten, Linear 8192->64, ReLU, ResLinear 64) of
-//   /root/reference/crossmodal/door_models/layers.py:43-63  (push_models/layers.py:91-104)
+//   /root/reference/crossmodal/door_models/layers.py:43-63  (push_models/layers.py:77-104)
 // which the reference runs as ~12 stock torch launches per encoder (26.1 M MAC per image, 72 %
-// of it in the two 32->32 3x3 convolutions).
+// of it in the two 32->32 3x3 convolutions).  All encoders of a step are batched on blockIdx.y
+// (they share the input image but not the weights).
 //
-// One launch per layer, all encoders of a step batched on blockIdx.y (they share the input
-// image but not the weights).  A workgroup owns a 16-row band of one image:
-//   * the band (+halo, zero padded) of every input channel is staged in LDS as
-//     [ci][row][40] floats; 18 rows * 40 = 720 floats per channel == 16 (mod 32) banks, so the
-//     two channel groups that share a 32-lane LDS access land on disjoint bank halves
-//   * the layer's weights sit next to it in MFMA-fragment order (packed once on the device)
-//   * GEMM view: M = output channels (16 per tile), N = 16 pixels of one image row,
-//     K = (tap, 4 input channels): lane (j, q) feeds pixel j of channel 4cg+q, a plain
-//     conflict-free ds_read_b32 at a compile-time offset per (tap, channel group)
-//   * bias is the accumulator initialiser; skip-add and ReLU are fused in the epilogue.
-// Activations between layers go through global memory but stay L2 / Infinity-Cache
-// resident (256 images * 128 KiB).  The 8192->64 linear is a split-K MFMA GEMM reading W and
-// the activations in their natural row-major layouts (k order permuted identically on both
-// operands), followed by a one-wave-per-image tail (bias, ReLU, ResLinear 64).
-//
-// Roofline: 2 * 26.12 MFLOP per image against ~0.9 MB of L2-resident activation traffic:
-// compute-bound on the f32 MFMA peak (157.3 TFLOP/s); DESIGN.md section 3.
+// Three paths, selected by `precision`:
+//   MMF_PREC_F32    one launch per layer, fp32 activations in HBM, exact fp32 products on
+//                   v_mfma_f32_16x16x4_f32 (conv_kernel below: M = output channels, N = 16 pixels of a
+//                   row, K = (tap, 4 input channels); input band + zero halo in LDS as [ci][row][40]).
+//   MMF_PREC_F16X3  (default) image_encoder_fused.inc: stem + conv 32->32 and conv 32->32 + skip +
+//                   conv 32->16 as two fused persistent kernels with the activations in LDS as split
+//                   f16 planes; then conv_f16x3_kernel<16,8> and the split-K linear tail below.
+//   MMF_PREC_BF16   the same two fused kernels with single bf16 products.
+// The per-layer f16x3 kernels (conv_f16x3_kernel<32,...>) remain for A/B runs (MMF_K4_UNFUSED=1).
+// The 8192->64 linear is a split-K MFMA GEMM followed by a one-wave-per-image tail (bias, ReLU,
+// ResLinear 64).  Rooflines and measurements: DESIGN.md section 3, K4.
 #include <hip/hip_fp16.h>
 
 #include "mmf_common.h"

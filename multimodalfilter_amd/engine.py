@@ -135,11 +135,13 @@ def image_encoder_precision_code() -> int:
     return _abi.IMAGE_PRECISIONS[IMAGE_ENCODER_PRECISION or DEFAULT_PRECISION]
 
 
-# Training: the HIP kernels are forward-only (K6, the backward kernels, are not built).  With
-# the training backend set to "autograd", modules in train() mode evaluate through ordinary
-# differentiable torch ops on the device instead, so the reference's curricula (30 particles,
-# batch 32, subsequences of 2-16 steps: launch-bound sizes) can run unchanged.  It is opt-in:
-# nothing switches paths silently, and eval() always means the HIP path.
+# Training is opt-in: nothing switches paths silently, and eval() always means the forward-only HIP
+# path.  With a training backend set, modules in train() mode evaluate differentiably:
+#   "hip"       the N*M-row work (per-particle dynamics / measurement networks: ParticleNetFunction;
+#               reweight + estimate: ReweightEstimateFunction) and every EKF's Kalman algebra
+#               (EkfStepFunction) run forward AND backward in HIP (K6); the per-trajectory networks
+#               (encoders, CNNs, weight models, Jacobians) through torch autograd
+#   "autograd"  torch ops throughout (the reference's own formulation; the cross-check)
 TRAINING_BACKEND = os.environ.get("MMF_TRAINING_BACKEND") or None
 
 
