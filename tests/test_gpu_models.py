@@ -186,7 +186,8 @@ def test_particle_filter_tracks_oracle(tname, kind, cls, mode):
 
     # free-running engine, step by step and through forward_loop (observation encoders batched
     # over T*N): identical to each other bit for bit, and -- with these flat random-init
-    # likelihoods -- within 1e-3 of the oracle's free run
+    # likelihoods, where a flipped ancestor moves an estimate by ~spread / M -- within 1e-2 of the
+    # oracle's free run (whether a flip happens at all depends on the box's host CPU)
     engine.noise = mmf.ReplayNoise([eps0] + eps, us)
     engine.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
     steps = torch.stack([engine(observations={k: v[t].to(dev) for k, v in obs.items()}, controls=ctrl[t].to(dev))
@@ -195,7 +196,7 @@ def test_particle_filter_tracks_oracle(tname, kind, cls, mode):
     engine.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
     loop = engine.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
     assert torch.equal(loop, steps)
-    torch.testing.assert_close(loop.cpu(), torch.stack(want), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(loop.cpu(), torch.stack(want), rtol=1e-2, atol=1e-2)
 
     # ... and so does the native step loop (mmf_pf_forward_loop: record_indices off, zero-copy
     # noise blocks), bit for bit against the step-by-step engine path, including the belief
