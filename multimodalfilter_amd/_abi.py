@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_float, c_int, c_int32, c_size_t, c_void
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmf_hip.so")
+LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so")  # override: experiment builds only
 
 MMF_UNITS = 64
 MMF_MAX_RES = 3

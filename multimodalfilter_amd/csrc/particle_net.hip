@@ -248,9 +248,13 @@ using half2v = __attribute__((ext_vector_type(2))) _Float16;
 using f32x2v = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ void split_pair(float x0, float x1, float neg_one, unsigned& hi, unsigned& lo) {
   const half2v h = __builtin_convertvector(f32x2v{x0, x1}, half2v);  // v_cvt_pk_f16_f32: round to nearest even
+#ifdef MMF_EXP_NO_SPLIT_LO  // scripts/k2_experiments.sh: what do the 3 residual instructions cost? (wrong results)
+  const half2v l = h;
+#else
   const float r0 = __builtin_fmaf(static_cast<float>(h[0]), neg_one, x0);
   const float r1 = __builtin_fmaf(static_cast<float>(h[1]), neg_one, x1);
   const half2v l = __builtin_convertvector(f32x2v{r0, r1}, half2v);
+#endif
   hi = __builtin_bit_cast(unsigned, h);
   lo = __builtin_bit_cast(unsigned, l);
 }
@@ -373,12 +377,14 @@ __device__ __forceinline__ void split_half(const Act<2>& x, SplitAct<2>& o, floa
         h[p] = hh;
         l[p] = ll;
       }
+#ifndef MMF_EXP_NO_RANGE  // scripts/k2_experiments.sh: what does range tracking cost?
       constexpr unsigned kMask = SIGNED ? 0x7fff7fffu : 0xffffffffu;
       const short2v m01 = __builtin_elementwise_max(__builtin_bit_cast(short2v, h[0] & kMask),
                                                     __builtin_bit_cast(short2v, h[1] & kMask));
       const short2v m23 = __builtin_elementwise_max(__builtin_bit_cast(short2v, h[2] & kMask),
                                                     __builtin_bit_cast(short2v, h[3] & kMask));
       amax = __builtin_elementwise_max(amax, __builtin_elementwise_max(m01, m23));
+#endif
       o.hi[2 * tp + u][C] = __builtin_bit_cast(half8, h);
       o.lo[2 * tp + u][C] = __builtin_bit_cast(half8, l);
     }
@@ -427,7 +433,9 @@ __device__ __forceinline__ void mfma_half(const float* __restrict__ Wl, const fl
       const FragPair nxt = g < 7 ? load_frag(Wl, lane, g + 1) : load_frag(next, lane, 0);
       acc.v[t][C] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.hi, in.hi[s][C], acc.v[t][C], 0, 0, 0);
       acc.v[t][C] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.hi, in.lo[s][C], acc.v[t][C], 0, 0, 0);
+#ifndef MMF_EXP_TWO_PRODUCTS  // scripts/k2_experiments.sh: what does the third MFMA cost?
       acc.v[t][C] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.lo, in.hi[s][C], acc.v[t][C], 0, 0, 0);
+#endif
       cur = nxt;
     }
 }
@@ -503,6 +511,34 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
   const int waves_total = gridDim.x * kWavesPerBlock;
   const int ntiles = (a.R + TILE - 1) / TILE;
 
+  // The inputs of a tile's first layer (the particle states: up to (D+2)/2 floats per lane and
+  // column) are requested one tile ahead: a tile opens with a dependent HBM access otherwise
+  // (~1-2 k cycles with nothing else to issue), 8 times per wave at the headline size.
+  constexpr int KS0 = (D + 2) / 2;
+  auto first_layer_inputs = [&](int tile, float (&b)[KS0][CT]) {
+    const int base = tile * TILE;
+#pragma unroll
+    for (int s = 0; s < KS0; ++s) {
+      const int comp = 2 * s + h;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        int row = base + 32 * c + j;
+        row = row < a.R ? row : a.R - 1;
+        float v;
+        if (JAC) {
+          const int role = row & 3;
+          if (role == 0) v = comp < D ? a.states_in[(row >> 2) * D + comp] : (comp == D ? 1.f : 0.f);
+          else v = (comp == role - 1) ? 1.f : 0.f;  // tangent e_{role-1}; role > D: zero column
+        } else {
+          v = comp < D ? a.states_in[static_cast<size_t>(row) * D + comp] : (comp == D ? 1.f : 0.f);
+        }
+        b[s][c] = v;
+      }
+    }
+  };
+  float bnext[KS0][CT];
+  if (wave_global < ntiles) first_layer_inputs(wave_global, bnext);
+
   for (int tile = wave_global; tile < ntiles; tile += waves_total) {
     const int base = tile * TILE;
     // column -> row / trajectory bookkeeping for the CT columns this lane feeds
@@ -526,29 +562,21 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
       for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int r = 0; r < 16; ++r) X.v[t][c][r] = 0.f;
-    constexpr int KS0 = (D + 2) / 2;
+    float bcur[KS0][CT];
+#pragma unroll
+    for (int s = 0; s < KS0; ++s)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) bcur[s][c] = bnext[s][c];
+    if (tile + waves_total < ntiles) first_layer_inputs(tile + waves_total, bnext);
 #pragma unroll
     for (int s = 0; s < KS0; ++s) {
       const int comp = 2 * s + h;
-      float b[CT];
-#pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        float v;
-        if (JAC) {
-          const int role = col_row[c] & 3;
-          if (role == 0) v = comp < D ? a.states_in[col_traj[c] * D + comp] : (comp == D ? 1.f : 0.f);
-          else v = (comp == role - 1) ? 1.f : 0.f;  // tangent e_{role-1}; role > D: zero column
-        } else {
-          v = comp < D ? a.states_in[static_cast<size_t>(col_row[c]) * D + comp] : (comp == D ? 1.f : 0.f);
-        }
-        b[c] = v;
-      }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const float w = lds[off_w0() + (32 * t + j) * kW0Cols + comp];
 #pragma unroll
         for (int c = 0; c < CT; ++c)
-          X.v[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b[c], X.v[t][c], 0, 0, 0);
+          X.v[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, bcur[s][c], X.v[t][c], 0, 0, 0);
       }
     }
     relu<CT, JAC>(X, primal);
