@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 17
+#define MMF_ABI_VERSION 18
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -257,6 +257,29 @@ int mmf_pack_image_encoder(const MmfImageEncoderDesc* desc /* host */, float* pa
 int mmf_image_encoder(const float* const* packed, int n_nets, const float* images, float* feat,
                       void* workspace, int32_t* range_flag, int precision, int variant, int N,
                       void* stream);
+
+/* K6 for the image encoder's convolution stack (door_models/layers.py:43-58) -- what torch
+ * autograd / MIOpen do under torchfilter.train.* (crossmodal/train_helpers.py:76-162).  One
+ * encoder per call, exact fp32, MMF_ENCODER_DEFAULT only.
+ *  mmf_image_convs_train_forward   images (N,32,32) -> a1 (N,32,32,32) stem, h (N,32,..) ResConv hidden,
+ *                                  a2 (N,32,..) ResConv out, a3 (N,16,..), a4 (N,8,32,32) = input of the
+ *                                  flatten + linear; `packed` = mmf_pack_image_encoder's blob
+ *  mmf_image_convs_train_backward  g_a4 -> pre-activation gradients g3 (N,16,..), g2, gh, g1 (N,32,..):
+ *                                  the forward conv kernel on transposed + flipped weights
+ *                                  (`packed_bwd` = mmf_pack_image_convs_backward), ReLU masks fused
+ *  mmf_conv_weight_grads           dW[tap][co][ci] partials of one 3x3 layer from its output gradient g
+ *                                  (N,co,32,32) and input act (N,ci,32,32): (co,ci) in {(32,32),(16,32),(8,16)};
+ *                                  partial (n_blocks*8, 9, 32, 32), summed over dim 0 by the caller
+ */
+size_t mmf_image_convs_backward_floats(void);
+int mmf_pack_image_convs_backward(const MmfImageEncoderDesc* desc, float* packed_bwd, void* stream);
+int mmf_image_convs_train_forward(const float* packed, const float* images, float* a1, float* h,
+                                  float* a2, float* a3, float* a4, int N, void* stream);
+int mmf_image_convs_train_backward(const float* packed_bwd, const float* a1, const float* h,
+                                   const float* a2, const float* a3, const float* g_a4, float* g1,
+                                   float* gh, float* g2, float* g3, int N, void* stream);
+int mmf_conv_weight_grads(const float* g, const float* act, float* partial, int N, int co, int ci,
+                          int n_blocks, void* stream);
 
 /* ---------------------------------------------------------------- particle-filter step loop
  * Replaces the Python loop of torchfilter's Filter.forward_loop (call site

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 17
+ABI_VERSION = 18
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
 IMAGE_PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16": PREC_BF16}  # image encoder (K4)
@@ -108,6 +108,11 @@ SIGNATURES = {
     "mmf_image_encoder_floats": (c_size_t, []),
     "mmf_image_encoder_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mmf_pack_image_encoder": (c_int, [POINTER(MmfImageEncoderDesc), _FP, c_void_p]),
+    "mmf_image_convs_backward_floats": (c_size_t, []),
+    "mmf_pack_image_convs_backward": (c_int, [POINTER(MmfImageEncoderDesc), _FP, c_void_p]),
+    "mmf_image_convs_train_forward": (c_int, [_FP] * 7 + [c_int, c_void_p]),
+    "mmf_image_convs_train_backward": (c_int, [_FP] * 10 + [c_int, c_void_p]),
+    "mmf_conv_weight_grads": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_image_encoder": (c_int, [POINTER(c_void_p), c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
 }
 
@@ -223,6 +228,35 @@ def ekf_step(A, mu_pred, q_tril, z, r_tril, fuse_w, mu, Sigma, mu_f, Sigma_f, fu
         _check(load().mmf_ekf_step(ptr(A), ptr(mu_pred), ptr(q_tril), ptr(z), ptr(r_tril),
                                    ptr(fuse_w), ptr(mu), ptr(Sigma), ptr(mu_f), ptr(Sigma_f),
                                    N, d, K, fusion, feedback, stream_of(mu_pred)), "mmf_ekf_step")
+
+
+def image_convs_train_forward(packed, images, a1, h, a2, a3, a4):
+    with _on(images):
+        _check(load().mmf_image_convs_train_forward(ptr(packed), ptr(images), ptr(a1), ptr(h), ptr(a2), ptr(a3), ptr(a4),
+                                                    images.shape[0], stream_of(images)), "mmf_image_convs_train_forward")
+
+
+def image_convs_train_backward(packed_bwd, a1, h, a2, a3, g_a4, g1, gh, g2, g3):
+    with _on(g_a4):
+        _check(load().mmf_image_convs_train_backward(ptr(packed_bwd), ptr(a1), ptr(h), ptr(a2), ptr(a3), ptr(g_a4), ptr(g1),
+                                                     ptr(gh), ptr(g2), ptr(g3), g_a4.shape[0], stream_of(g_a4)),
+               "mmf_image_convs_train_backward")
+
+
+def conv_weight_grads(g, act, partial, n_blocks: int):
+    with _on(g):
+        _check(load().mmf_conv_weight_grads(ptr(g), ptr(act), ptr(partial), g.shape[0], g.shape[1], act.shape[1], n_blocks,
+                                            stream_of(g)), "mmf_conv_weight_grads")
+
+
+def image_convs_backward_floats() -> int:
+    return int(load().mmf_image_convs_backward_floats())
+
+
+def pack_image_convs_backward(desc: MmfImageEncoderDesc, packed: torch.Tensor):
+    with _on(packed):
+        _check(load().mmf_pack_image_convs_backward(ctypes.byref(desc), ptr(packed), stream_of(packed)),
+               "mmf_pack_image_convs_backward")
 
 
 def ekf_step_backward(A, mu_pred, q_tril, z, r_tril, Sigma_in, g_mu, g_Sigma, g_A, g_mu_pred, g_z, g_r_tril, g_Sigma_in):

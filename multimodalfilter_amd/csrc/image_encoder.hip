@@ -246,6 +246,7 @@ __global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ o
 struct ConvArgs {
   const float* packed[kMaxNets];  // encoder blobs
   const float* in;                // (nets?, N, CIN, 32, 32)
+  const float* mask;              // MASK: (nets, N, COUT, 32, 32); the output is zeroed where mask <= 0 (ReLU backward)
   const float* skip;              // (nets, N, COUT, 32, 32) or null
   float* out;                     // (nets, N, COUT, 32, 32)
   long long in_net_stride;        // 0 when every net reads the same input (layer 1)
@@ -253,7 +254,7 @@ struct ConvArgs {
   int woff, boff;
 };
 
-template <int CIN, int COUT, int KS, bool RELU, bool SKIP>
+template <int CIN, int COUT, int KS, bool RELU, bool SKIP, bool MASK = false>
 __global__ __launch_bounds__(kConvThreads) void conv_kernel(ConvArgs a) {
   constexpr int HALO = KS / 2;
   constexpr int RB = kBand + 2 * HALO;
@@ -351,6 +352,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(ConvArgs a) {
           float v = acc[mt][pt][r];
           if (SKIP) v += a.skip[o];
           if (RELU) v = fmaxf(v, 0.f);
+          if (MASK) v = a.mask[o] > 0.f ? v : 0.f;
           a.out[o] = v;
         }
       }
@@ -747,12 +749,12 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcArgs a) {
   a.feat[(static_cast<size_t>(net) * a.N + img) * kFeat + lane] = fmaxf(y, 0.f);
 }
 
-template <int CIN, int COUT, int KS, bool RELU, bool SKIP>
+template <int CIN, int COUT, int KS, bool RELU, bool SKIP, bool MASK = false>
 int launch_conv(const ConvArgs& a, int nets, hipStream_t s) {
   constexpr int RB = kBand + 2 * (KS / 2);
   constexpr size_t lds = (static_cast<size_t>(CIN) * RB * kWP + mtiles(COUT) * ksteps(CIN, KS) * 64) * sizeof(float);
   static_assert(lds <= 160 * 1024, "conv tile + weights must fit LDS");
-  auto k = conv_kernel<CIN, COUT, KS, RELU, SKIP>;
+  auto k = conv_kernel<CIN, COUT, KS, RELU, SKIP, MASK>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -761,6 +763,99 @@ int launch_conv(const ConvArgs& a, int nets, hipStream_t s) {
   k<<<dim3(2 * a.N, nets), kConvThreads, lds, s>>>(a);
   MMF_CHECK_LAUNCH();
   return 0;
+}
+
+
+// ---- K6 for the image encoder: training forward with every activation kept, backward data path
+// (the forward conv kernel on transposed + flipped weights, ReLU masks in its epilogue) and the
+// weight gradients as split-K MFMA correlations.  Exact fp32 (f32 MFMA), one encoder per call.
+// Replaces torch autograd / MIOpen through the convolution stack of
+//   /root/reference/crossmodal/door_models/layers.py:43-58  in  torchfilter.train.* (train_helpers.py:76-162);
+// the 8192 -> 64 linear and the ResLinear behind it stay library GEMMs (rocBLAS through torch).
+struct BwdLayout {
+  int w4t, w3t, w2bt, w2at, zeros, total;  // dgrad weights in conv_kernel's fragment layout; 32 zero biases
+};
+__host__ __device__ constexpr BwdLayout bwd_layout() {
+  BwdLayout L{};
+  int o = 0;
+  L.w4t = o; o += conv_w_floats(8, 16, 3);     // dgrad of conv 16->8: a convolution 8 -> 16
+  L.w3t = o; o += conv_w_floats(16, 32, 3);    // dgrad of conv 32->16: 16 -> 32
+  L.w2bt = o; o += conv_w_floats(32, 32, 3);
+  L.w2at = o; o += conv_w_floats(32, 32, 3);
+  L.zeros = o; o += 32;
+  L.total = o;
+  return L;
+}
+
+// dgrad weights: W'[ci_fwd][co_fwd][ky][kx] = W[co_fwd][ci_fwd][2 - ky][2 - kx]
+__global__ void pack_convs_backward_kernel(MmfImageEncoderDesc d, float* __restrict__ out) {
+  constexpr BwdLayout L = bwd_layout();
+  const int offs[5] = {L.w4t, L.w3t, L.w2bt, L.w2at, L.zeros};
+  const int cin_b[4] = {8, 16, 32, 32}, cout_b[4] = {16, 32, 32, 32};  // of the BACKWARD convolution
+  const int src[4] = {4, 3, 2, 1};                                      // forward conv index in desc
+  for (int q0 = blockIdx.x * blockDim.x + threadIdx.x; q0 < L.total; q0 += gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (q0 < L.zeros) {
+      int c = 0;
+      while (q0 >= offs[c + 1]) ++c;
+      const int e = q0 - offs[c];
+      const int ksub = e & 3, lane = (e >> 2) & 63, rest = e >> 8;
+      const int S4 = ksteps(cin_b[c], 3) / 4;
+      const int s4 = rest % S4, mt = rest / S4;
+      const int s = 4 * s4 + ksub, i = lane & 15, q = lane >> 4;
+      const int co_b = 16 * mt + i;  // backward output channel = forward input channel
+      int ci_b, ky, kx;              // backward input channel = forward output channel
+      if (co_b < cout_b[c] && kdecode(cin_b[c], 3, s, q, &ci_b, &ky, &kx))
+        v = d.conv_w[src[c]][((ci_b * cout_b[c] + co_b) * 3 + (2 - ky)) * 3 + (2 - kx)];
+    }
+    out[q0] = v;
+  }
+}
+
+// dW[tap][co][ci] = sum over images, rows, pixels of g[n][co][y][x] * act[n][ci][y + ky - 1][x + kx - 1]
+// as v_mfma_f32_32x32x2_f32: A = g (rows = co, k = pixel), B = shifted act (k = pixel, cols = ci).  A wave
+// owns output rows y = wave, wave + 8, ... of its images and keeps all nine taps' 32x32 accumulators
+// in registers; k-step s of a row pairs pixels (s, 16 + s), so the A fragment of a row is 16
+// consecutive pixels per lane and is reused by the nine taps.  Per-wave partials, summed by the caller.
+template <int CO, int CI>
+__global__ __launch_bounds__(512) void conv_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ act,
+                                                         float* __restrict__ partial, int N) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, kk = lane >> 5;
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    const float* gn = g + (static_cast<size_t>(n) * CO + (i < CO ? i : 0)) * kImg * kImg;
+    const float* an = act + (static_cast<size_t>(n) * CI + (i < CI ? i : 0)) * kImg * kImg;
+    for (int y = wave; y < kImg; y += 8) {
+      float a[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) a[s] = i < CO ? gn[y * kImg + 16 * kk + s] : 0.f;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap % 3;
+        const int yy = y + ky - 1;
+        if (yy < 0 || yy >= kImg) continue;  // wave-uniform
+        float b[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const int x = 16 * kk + s + kx - 1;
+          b[s] = (i < CI && x >= 0 && x < kImg) ? an[yy * kImg + x] : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc[tap], 0, 0, 0);
+      }
+    }
+  }
+  // lane (column ci = i, half kk), register r -> row co = (r & 3) + 8 (r >> 2) + 4 kk
+  float* p = partial + (static_cast<size_t>(blockIdx.x) * 8 + wave) * 9 * 32 * 32;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[(tap * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * 32 + i] = acc[tap][r];
 }
 
 #include "image_encoder_fused.inc"
@@ -878,6 +973,80 @@ extern "C" int mmf_image_encoder(const float* const* packed, int n_nets, const f
   }
   MMF_CHECK_LAUNCH();
   fc_tail_kernel<false><<<dim3((N + 3) / 4, n_nets), 256, 0, s>>>(f);
+  MMF_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------ K6: image-encoder training
+extern "C" size_t mmf_image_convs_backward_floats(void) { return static_cast<size_t>(bwd_layout().total); }
+
+extern "C" int mmf_pack_image_convs_backward(const MmfImageEncoderDesc* d, float* packed, void* stream) {
+  if (!d || !packed) return MMF_EINVAL;
+  for (int i = 1; i < 5; ++i)
+    if (!d->conv_w[i]) return MMF_EINVAL;
+  if (d->variant != MMF_ENCODER_DEFAULT) return MMF_EINVAL;
+  const int total = bwd_layout().total;
+  pack_convs_backward_kernel<<<(total + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(*d, packed);
+  MMF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int mmf_image_convs_train_forward(const float* packed, const float* images, float* a1, float* h,
+                                             float* a2, float* a3, float* a4, int N, void* stream) {
+  if (!packed || !images || !a1 || !h || !a2 || !a3 || !a4 || N < 0) return MMF_EINVAL;
+  if (N == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  constexpr Layout L = layout();
+  ConvArgs c{};
+  c.packed[0] = packed;
+  c.N = N;
+  int rc;
+  c.in = images; c.in_net_stride = 0; c.out = a1; c.woff = L.w1; c.boff = L.b1;
+  if ((rc = launch_conv<1, 32, 5, true, false>(c, 1, s))) return rc;
+  c.in = a1; c.out = h; c.woff = L.w2a; c.boff = L.b2a;
+  if ((rc = launch_conv<32, 32, 3, true, false>(c, 1, s))) return rc;
+  c.in = h; c.skip = a1; c.out = a2; c.woff = L.w2b; c.boff = L.b2b;
+  if ((rc = launch_conv<32, 32, 3, true, true>(c, 1, s))) return rc;
+  c.in = a2; c.skip = nullptr; c.out = a3; c.woff = L.w3; c.boff = L.b3;
+  if ((rc = launch_conv<32, 16, 3, true, false>(c, 1, s))) return rc;
+  c.in = a3; c.out = a4; c.woff = L.w4; c.boff = L.b4;
+  return launch_conv<16, 8, 3, false, false>(c, 1, s);
+}
+
+extern "C" int mmf_image_convs_train_backward(const float* packed_bwd, const float* a1, const float* h,
+                                              const float* a2, const float* a3, const float* g_a4, float* g1,
+                                              float* gh, float* g2, float* g3, int N, void* stream) {
+  if (!packed_bwd || !a1 || !h || !a2 || !a3 || !g_a4 || !g1 || !gh || !g2 || !g3 || N < 0) return MMF_EINVAL;
+  if (N == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  constexpr BwdLayout B = bwd_layout();
+  ConvArgs c{};
+  c.packed[0] = packed_bwd;
+  c.N = N;
+  c.boff = B.zeros;
+  int rc;
+  // g3 = dgrad(conv 16->8)(g_a4) where a3 > 0
+  c.in = g_a4; c.mask = a3; c.out = g3; c.woff = B.w4t;
+  if ((rc = launch_conv<8, 16, 3, false, false, true>(c, 1, s))) return rc;
+  // g2 = dgrad(conv 32->16)(g3) where a2 > 0
+  c.in = g3; c.mask = a2; c.out = g2; c.woff = B.w3t;
+  if ((rc = launch_conv<16, 32, 3, false, false, true>(c, 1, s))) return rc;
+  // gh = dgrad(ResConv block2)(g2) where h > 0
+  c.in = g2; c.mask = h; c.out = gh; c.woff = B.w2bt;
+  if ((rc = launch_conv<32, 32, 3, false, false, true>(c, 1, s))) return rc;
+  // g1 = (g2 + dgrad(ResConv block1)(gh)) where a1 > 0
+  c.in = gh; c.skip = g2; c.mask = a1; c.out = g1; c.woff = B.w2at;
+  return launch_conv<32, 32, 3, false, true, true>(c, 1, s);
+}
+
+extern "C" int mmf_conv_weight_grads(const float* g, const float* act, float* partial, int N, int co, int ci,
+                                     int n_blocks, void* stream) {
+  if (!g || !act || !partial || N < 0 || n_blocks < 1) return MMF_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (co == 32 && ci == 32) conv_wgrad_kernel<32, 32><<<n_blocks, 512, 0, s>>>(g, act, partial, N);
+  else if (co == 16 && ci == 32) conv_wgrad_kernel<16, 32><<<n_blocks, 512, 0, s>>>(g, act, partial, N);
+  else if (co == 8 && ci == 16) conv_wgrad_kernel<8, 16><<<n_blocks, 512, 0, s>>>(g, act, partial, N);
+  else return MMF_EINVAL;
   MMF_CHECK_LAUNCH();
   return 0;
 }

@@ -524,6 +524,83 @@ class PackedImageEncoder:
         return blob
 
 
+class ImageConvsFunction(torch.autograd.Function):
+    """K6 for the image encoder: the convolution stack of a default ``observation_image_layers``
+    (``door_models/layers.py:43-58``: stem, ResConv, 32->16, 16->8) forward with every activation kept
+    (``mmf_image_convs_train_forward``), backward data path on transposed + flipped weights with the
+    ReLU masks fused (``mmf_image_convs_train_backward``) and the 3x3 weight gradients as split-K MFMA
+    correlations (``mmf_conv_weight_grads``): no MIOpen kernel in a training step.  Exact fp32.
+    ``apply(seq, images (N, 32, 32), *conv weights and biases) -> (N, 8, 32, 32)``; the flatten + linear
+    + ResLinear behind it stay torch modules (library GEMMs).  The 5x5 stem's weight gradient
+    (3 % of the MACs, one input channel) is an unfold + batched GEMM; bias gradients are sums."""
+
+    @staticmethod
+    def forward(ctx, seq, images, *params):
+        require_device(images, "ImageConvsFunction")
+        if not hasattr(seq, "_mmf_packed"):
+            object.__setattr__(seq, "_mmf_packed", PackedImageEncoder(seq))
+        blob = seq._mmf_packed.blob()
+        img = images.detach().to(torch.float32).contiguous()
+        N = img.shape[0]
+        mk = lambda c: torch.empty((N, c, 32, 32), dtype=torch.float32, device=img.device)
+        a1, h, a2, a3, a4 = mk(32), mk(32), mk(32), mk(16), mk(8)
+        _abi.image_convs_train_forward(blob, img, a1, h, a2, a3, a4)
+        ctx.seq = seq
+        ctx.save_for_backward(img, a1, h, a2, a3)
+        return a4
+
+    @staticmethod
+    def backward(ctx, g_a4):
+        seq = ctx.seq
+        img, a1, h, a2, a3 = ctx.saved_tensors
+        N = img.shape[0]
+        src = seq._mmf_packed._sources()
+        stamp = tuple((t.data_ptr(), t._version) for t in src[1:5])
+        cached = getattr(seq, "_mmf_packed_bwd", None)
+        if cached is None or cached[0] != stamp:
+            keep = [t.detach().to(torch.float32).contiguous() for t in src[:5]]
+            d = _abi.MmfImageEncoderDesc()
+            for i in range(5):
+                d.conv_w[i] = ctypes.c_void_p(keep[i].data_ptr())
+            d.variant = _abi.ENCODER_DEFAULT
+            blob_b = torch.empty(_abi.image_convs_backward_floats(), dtype=torch.float32, device=img.device)
+            _abi.pack_image_convs_backward(d, blob_b)
+            cached = (stamp, blob_b)
+            object.__setattr__(seq, "_mmf_packed_bwd", cached)
+        g_a4 = g_a4.to(torch.float32).contiguous()
+        g1, gh, g2 = torch.empty_like(a1), torch.empty_like(a1), torch.empty_like(a1)
+        g3 = torch.empty_like(a3)
+        _abi.image_convs_train_backward(cached[1], a1, h, a2, a3, g_a4, g1, gh, g2, g3)
+        blocks = max(1, min(N, 128))
+        partial = torch.empty((blocks * 8, 9, 32, 32), dtype=torch.float32, device=img.device)
+
+        def wgrad(g, act):
+            co, ci = g.shape[1], act.shape[1]
+            _abi.conv_weight_grads(g, act, partial, blocks)
+            return partial.sum(0)[:, :co, :ci].permute(1, 2, 0).reshape(co, ci, 3, 3).contiguous()
+
+        gw4, gw3, gw2b, gw2a = wgrad(g_a4, a3), wgrad(g3, a2), wgrad(g2, h), wgrad(gh, a1)
+        cols = torch.nn.functional.unfold(img[:, None], kernel_size=5, padding=2)      # (N, 25, 1024)
+        gw1 = torch.einsum("ncp,ntp->ct", g1.reshape(N, 32, 1024), cols).reshape(32, 1, 5, 5)
+        bsum = lambda g: g.sum(dim=(0, 2, 3))
+        # parameter order = PackedImageEncoder._sources()[:10]: w1 w2a w2b w3 w4 | b1 b2a b2b b3 b4
+        return (None, None, gw1, gw2a, gw2b, gw3, gw4, bsum(g1), bsum(gh), bsum(g2), bsum(g3), bsum(g_a4))
+
+
+def image_features_autograd(seq, images: torch.Tensor) -> torch.Tensor:
+    """Differentiable ``observation_image_layers(images[:, None])``: with the "hip" training backend
+    and a default stack the convolutions run forward and backward in HIP (``ImageConvsFunction``),
+    the linear tail in torch; otherwise the torch module as it stands."""
+    if use_hip_backward() and images.is_cuda and _image_encoder_variant(seq) == _abi.ENCODER_DEFAULT:
+        params = PackedImageEncoder(seq)._sources()[:10] if not hasattr(seq, "_mmf_packed") else seq._mmf_packed._sources()[:10]
+        a4 = ImageConvsFunction.apply(seq, images, *params)
+        x = a4.flatten(1)
+        for layer in list(seq)[7:]:
+            x = layer(x)
+        return x
+    return seq(images[:, None, :, :])
+
+
 _IMAGE_WORKSPACES = {}
 _MAX_NETS = 4
 _IMAGE_CHUNK = int(os.environ.get("MMF_IMAGE_CHUNK", "2048"))  # images per K4 launch sequence (workspace ~0.8 GB per encoder)

@@ -102,7 +102,7 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             """Differentiable torch evaluation of the encoders (training backend "autograd")."""
             obs = []
             if "image" in self.modalities:
-                obs.append(self.observation_image_layers(observations["image"][:, None, :, :]))
+                obs.append(engine.image_features_autograd(self.observation_image_layers, observations["image"]))
             if "pos" in self.modalities:
                 obs.append(self.observation_pos_layers(observations["gripper_pos"]))
             if "sensors" in self.modalities:
