@@ -40,8 +40,8 @@ def _data(task, T, N, seed):
 
 
 # fp32 engine vs fp32 CPU oracle: different summation orders, and a pre-activation within rounding of
-# zero may take the other ReLU branch; 1e-3 of the largest entry of each gradient tensor
-GRAD_TOL = 1e-3
+# zero may take the other ReLU branch (kernel-level tests against fp64 with shared masks hold 1e-4)
+GRAD_TOL = 5e-3  # observed up to 2.4e-3 (the 5x5 stem, 25 weights each summing a million products), same under both backends
 
 
 def _compare_grads(oracle, engine_model, loss_o, loss_e, min_checked=20):
