@@ -18,6 +18,7 @@ MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
 ABI_VERSION = 18
+KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
 IMAGE_PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16": PREC_BF16}  # image encoder (K4)

@@ -333,6 +333,9 @@ class ParticleNetFunction(torch.autograd.Function):
         pb = torch.empty((NL + 1, S, U), dtype=torch.float32, device=st.device)
         _abi.particle_net_weight_grads(dz, stash, pw, pb, NL + 1, R, S)
         dW, db = pw.sum(1), pb.sum(1)                    # (NL + 1, 64, 64), (NL + 1, 64)
+        quad = kind == _abi.KIND_JACOBIAN
+        if quad:  # tangent rows carry no bias: bias gradients come from the primal row of each group
+            db = dz[:, 0::4, :].sum(1)
         # (64 x R) @ (R x d) and (n_out x R) @ (R x 64) with d, n_out <= 4 are column-scaled sums;
         # as GEMMs they are the library's worst shapes (0.6-2 ms each at R = 262k)
         grads[0] = torch.stack([(dz[NL] * st[:, i:i + 1]).sum(0) for i in range(d)], dim=1)  # first layer (64, d)
@@ -342,15 +345,43 @@ class ParticleNetFunction(torch.autograd.Function):
         off = net.join_state_off
         gj[:, off:off + U] = dW[2]
         grads[6] = gj
-        d_traj_bias = dz[2].view(N, M, U).sum(1)
+        d_traj_bias = dz[2][0::4] if quad else dz[2].view(N, M, U).sum(1)
         for i in range(net.n_res):
             for k in range(2):
                 layer = 3 + 2 * i + k
                 grads[7 + 4 * i + 2 * k] = dW[layer]
                 grads[8 + 4 * i + 2 * k] = db[layer]
         grads[-2] = torch.stack([(stash[NL] * d_out[:, o:o + 1]).sum(0) for o in range(d_out.shape[1])], dim=0)
-        grads[-1] = d_out.sum(0)
+        grads[-1] = d_out[0::4].sum(0) if quad else d_out.sum(0)
         return (None, None, None, None, d_states, d_traj_bias, *grads)
+
+
+def dynamics_with_jacobian_autograd(net: PackedParticleNet, x: torch.Tensor, traj_bias: torch.Tensor):
+    """K6 for K5: differentiable ``(x' (N, d), A (N, d, d))`` of a dynamics network
+    ``x' = x + dir(x) * sigmoid(gate(x))``.  The primal and the ``d`` tangent columns ``e_j`` of every
+    trajectory go through ``ParticleNetFunction`` as one group of four rows (tangents: no biases,
+    the primal's ReLU masks), whose raw head outputs are ``(dir, gate)`` and the columns of their
+    Jacobians; the sigmoid-gate algebra on top is a few element-wise torch ops on ``N`` rows.
+    Gradients reach the weights and ``traj_bias`` through both ``x'`` and ``A``, ``x`` through ``x'``."""
+    N, d = x.shape
+    assert d <= 3, "groups are {primal, e_1, e_2, e_3}"
+    # x' keeps its dependence on x ...
+    out = ParticleNetFunction.apply(net, _abi.KIND_DYNAMICS, N, 1, x, traj_bias, *net._sources())
+    x_next = x + out[:, :d] * torch.sigmoid(out[:, d:])
+    # ... the Jacobian is evaluated AT x, as upstream's default ``DynamicsModel.jacobian`` does (it
+    # differentiates a detached copy of the states: gradients reach the weights and the controls
+    # through A, not the belief mean)
+    eye = torch.zeros((N, 3, d), dtype=x.dtype, device=x.device)
+    eye[:, :d, :] = torch.eye(d, dtype=x.dtype, device=x.device)
+    rows = torch.cat([x.detach()[:, None, :], eye], dim=1).reshape(4 * N, d)
+    raw = ParticleNetFunction.apply(net, _abi.KIND_JACOBIAN, N, 4, rows, traj_bias, *net._sources()).view(N, 4, d + 1)
+    dirp, gate = raw[:, 0, :d], raw[:, 0, d:]
+    sg = torch.sigmoid(gate)
+    J_dir = raw[:, 1:1 + d, :d].transpose(1, 2)          # [n, i, j] = d dir_i / d x_j
+    J_gate = raw[:, 1:1 + d, d]                          # [n, j]    = d gate / d x_j
+    A = torch.eye(d, dtype=x.dtype, device=x.device) + sg[:, :, None] * J_dir \
+        + (dirp * sg * (1.0 - sg))[:, :, None] * J_gate[:, None, :]
+    return x_next, A
 
 
 class ReweightEstimateFunction(torch.autograd.Function):

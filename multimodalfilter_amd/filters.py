@@ -441,8 +441,14 @@ class VirtualSensorExtendedKalmanFilter(base.Filter):
         assert self._initialized, "Kalman filter not initialized!"
         mu, Sigma = self._belief_mean, self._belief_covariance
         z, r_tril = self.virtual_sensor_model(observations=observations)
-        mu_pred, L = self.dynamics_model(initial_states=mu, controls=controls)
-        A = self.dynamics_model.jacobian(initial_states=mu, controls=controls)
+        dyn = self.dynamics_model
+        if engine.use_hip_backward() and hasattr(dyn, "predict_with_jacobian_autograd"):
+            # K6: dynamics network + forward-mode Jacobian forward and backward in HIP
+            mu_pred, A = dyn.predict_with_jacobian_autograd(mu, controls)
+            L = dyn.scale_tril()[None]
+        else:
+            mu_pred, L = dyn(initial_states=mu, controls=controls)
+            A = dyn.jacobian(initial_states=mu, controls=controls)
         if engine.use_hip_backward():
             # K6: the Kalman algebra forward (K3) and backward (closed-form adjoints) in HIP; the
             # networks around it (sensor, dynamics, Jacobian) keep their autograd form

@@ -184,6 +184,11 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             join = self.shared_layers[0]
             return self.control_layers(controls) @ join.weight[:, :self.units].t() + join.bias
 
+        def predict_with_jacobian_autograd(self, mean, controls):
+            """Differentiable ``(mu- (N, d), A (N, d, d))`` with the network and its forward-mode
+            Jacobian forward AND backward in HIP (``engine.dynamics_with_jacobian_autograd``)."""
+            return engine.dynamics_with_jacobian_autograd(self._net, mean, self.encode_controls_autograd(controls))
+
         def forward_particles(self, *, states, controls=None, bias=None):
             """Differentiable one-step prediction (no noise) of ``(N, M, d)`` particles under
             per-trajectory ``controls (N, 7)`` (or their pre-computed ``bias``) with the

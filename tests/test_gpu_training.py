@@ -535,3 +535,49 @@ def test_k6_image_convs_function_matches_fp64_autograd(N):
     for name, a, b in zip("w1 w2a w2b w3 w4 b1 b2a b2b b3 b4".split(), got, want):
         scale = max(1e-6, float(b.abs().max()))
         assert float((a.cpu().double() - b).abs().max()) / scale < 1e-4, name
+
+
+@pytest.mark.parametrize("tname", ["door", "push"])
+@pytest.mark.parametrize("N", [3, 50])
+def test_k6_dynamics_with_jacobian_matches_fp64_autograd(tname, N):
+    """K6 for K5: ``predict_with_jacobian_autograd`` (primal + tangent rows through the K6 kernels in
+    groups of four, tangents following the primal's ReLU masks) against the oracle's dynamics model in
+    fp64 with its autograd Jacobian (``create_graph``): ``x'``, ``A`` and the gradients of a random
+    linear functional of both with respect to every weight, ``x`` and the controls, 1e-4 relative."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine
+
+    dev = torch.device("cuda:0")
+    task = om.TASKS[tname]
+    d = task.state_dim
+    g = torch.Generator().manual_seed(80 + N)
+    x, u = torch.randn((N, d), generator=g), torch.randn((N, 7), generator=g)
+    gm, gA = torch.randn((N, d), generator=g), torch.randn((N, d, d), generator=g)
+    o = om.DynamicsModel(task)
+    o.load_state_dict(om.seeded_state_dict(o, seed=15, gain=1.0))
+    o = o.double()
+    x6, u6 = x.double().requires_grad_(True), u.double().requires_grad_(True)
+    mu6, _ = o(initial_states=x6, controls=u6)
+    A6 = o.jacobian(initial_states=x6, controls=u6)
+    loss6 = (mu6 * gm.double()).sum() + (A6 * gA.double()).sum()
+    names = [n for n, p in o.named_parameters() if p.requires_grad]
+    want = torch.autograd.grad(loss6, [x6, u6] + [p for p in o.parameters() if p.requires_grad])
+
+    ns = mmf.door_models if tname == "door" else mmf.push_models
+    e = getattr(ns, tname.capitalize() + "DynamicsModel")()
+    e.load_state_dict({k: v.float() for k, v in o.state_dict().items()})
+    e.to(dev).train()
+    engine.set_training_backend("hip")
+    try:
+        xe, ue = x.to(dev).requires_grad_(True), u.to(dev).requires_grad_(True)
+        mu, A = e.predict_with_jacobian_autograd(xe, ue)
+        loss = (mu * gm.to(dev)).sum() + (A * gA.to(dev)).sum()
+        ep = dict(e.named_parameters())
+        got = torch.autograd.grad(loss, [xe, ue] + [ep[n] for n in names])
+    finally:
+        engine.set_training_backend(None)
+    assert float((mu.detach().cpu().double() - mu6.detach()).abs().max()) < 1e-4 * max(1.0, float(mu6.abs().max()))
+    assert float((A.detach().cpu().double() - A6.detach()).abs().max()) < 1e-4 * max(1.0, float(A6.abs().max()))
+    for name, a, b in zip(["x", "controls"] + names, got, want):
+        scale = max(1e-6, float(b.abs().max()))
+        assert float((a.cpu().double() - b).abs().max()) / scale < 1e-4, name
