@@ -30,6 +30,7 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using half2v = __attribute__((ext_vector_type(2))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 
 constexpr int kImg = 32;         // images are 32 x 32
 constexpr int kBand = 16;        // output rows per workgroup
@@ -56,6 +57,7 @@ struct Layout {
   int hs;                // f16x3 5x5 stem as 2 k-steps of 16 taps: [k-step][hi|lo][lane][8 halves]
   int g3;                // f16x3 conv 32->16 for v_mfma_f32_16x16x32_f16: [tap][hi|lo][lane][8 halves]
   int q2a, q2b, q3, qs;  // MMF_PREC_BF16 twins of h2a / h2b / g3 / hs: same fragment order, slot "hi" = bf16(w), slot "lo" unused
+  int g4;                // f16x3 conv 16->8 for v_mfma_f32_16x16x32_f16, two taps per MFMA: [tap pair][hi|lo][lane][8 halves]
   int total;
 };
 // floats (= halves / 2) of a 3x3 conv in f16x3 fragment order [tap][kc][hi|lo][lane][8 halves]
@@ -90,6 +92,7 @@ __host__ __device__ constexpr Layout layout() {
   L.q2b = o; o += conv_h_floats(32);
   L.q3 = o; o += 9 * 2 * 64 * 8 / 2;
   L.qs = o; o += 2 * 2 * 64 * 8 / 2;
+  L.g4 = o; o += 5 * 2 * 64 * 8 / 2;
   L.total = o;
   return L;
 }
@@ -162,9 +165,22 @@ __global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ o
       v = d.res_w[1][o * kFeat + k];
     } else if (q0 < L.h2a) {
       v = d.res_b[1][q0 - L.r2b];
+    } else if (q0 >= L.g4) {
+      // conv 16->8 in 16x16x32 fragments: element i of lane (co, q) for tap pair p = input channel
+      // 8 (q & 1) + i of tap 2 p + (q >> 1) (the tenth tap is zero)
+      unsigned short hb[2];
+      for (int z = 0; z < 2; ++z) {
+        const int he = 2 * (q0 - L.g4) + z;
+        const int i = he & 7, lane = (he >> 3) & 63, part = (he >> 9) & 1, pair = he >> 10;
+        const int co = lane & 15, q = lane >> 4, tap = 2 * pair + (q >> 1);
+        const float w = co < cout4 && tap < 9 ? d.conv_w[4][(co * 16 + 8 * (q & 1) + i) * 9 + tap] : 0.f;
+        const __half hi = __float2half_rn(w);
+        hb[z] = part ? __half_as_ushort(__float2half_rn(w - __half2float(hi))) : __half_as_ushort(hi);
+      }
+      v = __uint_as_float(static_cast<unsigned>(hb[0]) | (static_cast<unsigned>(hb[1]) << 16));
     } else if (q0 >= L.q2a) {
       // bf16 twins (round to nearest even): same index -> weight maps as h2a / h2b / g3 / hs, "lo" slots zero
-      const int offs[5] = {L.q2a, L.q2b, L.q3, L.qs, L.total};
+      const int offs[5] = {L.q2a, L.q2b, L.q3, L.qs, L.g4};
       int c = 0;
       while (q0 >= offs[c + 1]) ++c;
       unsigned short hb[2];
@@ -917,11 +933,10 @@ extern "C" int mmf_image_encoder(const float* const* packed, int n_nets, const f
     if ((rc = launch_fused(fa, n_nets, 0, bf16, s))) return rc;
     fa.bin = bufA; fa.out = bufB;
     if ((rc = launch_fused(fa, n_nets, 1, bf16, s))) return rc;
-    ConvHArgs hcv{};
-    for (int i = 0; i < n_nets; ++i) hcv.packed[i] = packed[i];
-    hcv.N = N; hcv.range_flag = range_flag;
-    hcv.in = bufB; hcv.skip = nullptr; hcv.out = bufC; hcv.hoff = L.h4; hcv.boff = L.b4;
-    if ((rc = launch_conv_h<16, 8, false, false>(hcv, n_nets, s))) return rc;
+    Conv4Args c4{};
+    for (int i = 0; i < n_nets; ++i) c4.packed[i] = packed[i];
+    c4.N = N; c4.din = reinterpret_cast<const unsigned char*>(bufB); c4.out = bufC;
+    if ((rc = launch_conv4(c4, n_nets, s))) return rc;
     bufB = bufC;  // the linear tail reads E
   } else if (precision == MMF_PREC_F16X3) {
     c.in = images; c.in_net_stride = 0; c.skip = nullptr; c.out = bufA; c.woff = L.w1; c.boff = L.b1;

@@ -311,6 +311,53 @@ def test_train_filter_step_descends_and_matches_manual_sgd():
         engine.set_training_backend(None)
 
 
+def test_training_step_at_config_c5_particle_count():
+    """SURVEY.md 8d config C5 at its particle count (push, unimodal, 8,192 particles, train mode,
+    forward + backward): the "hip" backend's loss and gradients against the "autograd" backend's on
+    the same weights and noise; batch and length cut to what the autograd backend's saved activations fit
+    in a test (``scripts/bench_train.py`` times the 32 x 16 shape)."""
+    import copy
+
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine, synthetic, train
+
+    dev = torch.device("cuda:0")
+    d, L, N, M = 2, 4, 4, 8192
+    batch = {k: v.to(dev) for k, v in synthetic.make_trajectories(state_dim=d, T=L - 1, N=N, seed=5).items()}
+    cov = torch.eye(d, device=dev) * 0.1
+    torch.manual_seed(2)
+    f = mmf.push_models.PushUnimodalParticleFilter().to(dev).train()
+    f.num_particles = M
+    g = copy.deepcopy(f)
+    eps_init = torch.randn((N, d))
+
+    def noise():  # the initial-belief perturbation; the particle noise is the filters' own (equal seeds)
+        return mmf.ReplayNoise([eps_init], [])
+
+    try:
+        engine.set_training_backend("hip")
+        loss_hip = train.filter_loss(f, batch, initial_covariance=cov, noise=noise())
+        loss_hip.backward()
+        engine.set_training_backend("autograd")
+        loss_ref = train.filter_loss(g, batch, initial_covariance=cov, noise=noise())
+        assert abs(float(loss_hip) - float(loss_ref)) < 1e-4 * max(1.0, abs(float(loss_ref)))
+        loss_ref.backward()
+        checked = 0
+        for (n, p), q in zip(f.named_parameters(), g.parameters()):
+            if q.grad is None or float(q.grad.abs().max()) == 0.0:
+                continue
+            scale = float(q.grad.abs().max())
+            assert float((p.grad - q.grad).abs().max()) / scale < GRAD_TOL, n
+            checked += 1
+        assert checked > 20
+        engine.set_training_backend("hip")
+        opt = torch.optim.SGD(f.parameters(), lr=1e-3)
+        # the filter's own particle noise has advanced: a different draw of the same loss
+        assert train.train_filter_step(f, batch, opt, initial_covariance=cov, noise=noise()) == pytest.approx(float(loss_hip), rel=0.2)
+    finally:
+        engine.set_training_backend(None)
+
+
 @pytest.mark.parametrize("N,M,d", [(1, 1, 3), (4, 30, 3), (3, 1000, 2), (2, 8192, 3)])
 def test_k6_reweight_estimate_function_matches_autograd(N, M, d):
     """K6 (K1 no-resample path): estimate, normalised log-weights and the gradients w.r.t.
