@@ -84,7 +84,7 @@ def pmc_traffic_k4_sequence(n_images: int, nets: int):
         with open(path) as fh:
             k = json.load(fh)["kernels"]
         names = (f"stem_conv2a_kernel<false> grid={g[0]}", f"conv2b_conv3_kernel<false> grid={g[1]}",
-                 f"conv_f16x3_kernel<16, 8, false, false, 8> grid={g[2]}", f"fc_partial_f16x3_kernel grid={g[3]}",
+                 f"conv4_kernel grid={g[2]}", f"fc_partial_f16x3_kernel grid={g[3]}",
                  f"fc_tail_kernel<false> grid={g[4]}")
         return sum(k[n]["hbm_bytes_corrected"] for n in names)
     except (OSError, KeyError, ValueError):
@@ -587,7 +587,7 @@ def main():
             dom = ks["image_encoder"]
             ach = dom["flops_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e12
             out["roofline"] = {"kernel": "image encoder launch sequence (stem_conv2a_kernel, conv2b_conv3_kernel, "
-                                         "conv_f16x3_kernel<16,8>, fc_partial_f16x3_kernel, fc_tail_kernel) per chunk of images",
+                                         "conv4_kernel, fc_partial_f16x3_kernel, fc_tail_kernel) per chunk of images",
                                "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK["f16x3"], "unit": "TFLOP/s",
                                "frac": ach / MFMA_PEAK["f16x3"],
                                "traffic": pmc_traffic_k4_sequence(1024, 3) if (B == 1024 and args.workload == "door_ekf") else None,

@@ -21,11 +21,14 @@ python scripts/bench_k1.py > $OUT/bench_k1.txt 2>> $OUT/bench.err
 # other SURVEY 8d configurations, for the record (C2: door PF N=256 M=1024; C3: push PF N=1024 M=4096; reference-sized eval)
 python bench.py --workload door_pf --particles 1024 --no-f32-mode --no-cpu-baseline --no-precision-study > $OUT/bench_c2_door_pf_n256_m1024.json 2>> $OUT/bench.err
 python bench.py --workload push_pf --batch 1024 --steps 64 --no-f32-mode --no-cpu-baseline --no-precision-study > $OUT/bench_c3_push_pf_n1024_m4096.json 2>> $OUT/bench.err
+# SURVEY 8d's headline trio is door PF at M=4096 with N in {32, 256, 1024}: the default bench is N=256
+python bench.py --workload door_pf --batch 32 --steps 64 --no-f32-mode --no-cpu-baseline --no-precision-study > $OUT/bench_door_pf_n32_m4096.json 2>> $OUT/bench.err
+python bench.py --workload door_pf --batch 1024 --steps 32 --no-f32-mode --no-cpu-baseline --no-precision-study > $OUT/bench_door_pf_n1024_m4096.json 2>> $OUT/bench.err
 python bench.py --workload door_pf --batch 32 --particles 300 --steps 200 --no-f32-mode --no-precision-study > $OUT/bench_door_pf_n32_m300.json 2>> $OUT/bench.err
 # the N > 1 launcher on one GPU (two gloo ranks sharing it): plumbing evidence, not a scaling number
 MMF_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 32 --warmup 8 --no-f32-mode --no-precision-study 2>> $OUT/bench.err | grep "^{" > $OUT/bench_gpus2_gloo_one_gpu.json
-MMF_PRECISION=f32 python -m pytest tests -m gpu -x -q 2>&1 | tail -2 > $OUT/pytest_gpu_f32_mode.txt
-python -m pytest tests -m gpu -q 2>&1 | tail -2 > $OUT/pytest_gpu.txt
+MMF_PRECISION=f32 python -m pytest tests -m gpu -q 2>&1 | grep -E '^E  |^FAILED|passed|failed' | tail -20 > $OUT/pytest_gpu_f32_mode.txt
+python -m pytest tests -m gpu -q 2>&1 | grep -E '^E  |^FAILED|passed|failed' | tail -20 > $OUT/pytest_gpu.txt
 # training step (K6 vs torch autograd), SURVEY 8d config C5 shape scaled to N*M = 2^18 per step
 python scripts/bench_train.py > $OUT/bench_train_push_unimodal_pf.json 2>> $OUT/bench.err
 find $OUT -name "*.csv" | head -30

@@ -3,7 +3,9 @@
 // between phase boundaries.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Imultimodalfilter_amd/csrc \
 //         -o scripts/ubench/k4_fused_phases scripts/ubench/k4_fused_phases.hip
+#ifndef NO_PHASE_CLOCKS  // -DNO_PHASE_CLOCKS: kernel times only (the clocks serialise what they measure)
 #define MMF_K4_PHASE_CLOCKS 1
+#endif
 #include "../../multimodalfilter_amd/csrc/image_encoder.hip"
 
 #include <cstdio>
@@ -36,27 +38,28 @@ int main(int argc, char** argv) {
   float* feat; hipMalloc(&feat, size_t(nets) * N * 64 * 4);
   void* ws; hipMalloc(&ws, mmf_image_encoder_workspace_bytes(N, nets));
   {  // per-kernel times (no clocks involved): the launchers of the fused path, one by one
-    constexpr Layout L = layout();
     const size_t act = size_t(nets) * N * 32 * kImg * kImg;
     float* bufA = static_cast<float*>(ws); float* bufB = bufA + act; float* bufC = bufB + act;
-    FusedArgs fa{}; ConvHArgs hc{};
-    for (int i = 0; i < nets; ++i) { fa.packed[i] = blobs[i]; hc.packed[i] = blobs[i]; }
-    fa.images = images; fa.N = N; hc.N = N;
+    FusedArgs fa{}; Conv4Args c4{};
+    for (int i = 0; i < nets; ++i) { fa.packed[i] = blobs[i]; c4.packed[i] = blobs[i]; }
+    fa.images = images; fa.N = N; c4.N = N;
+    const bool bf = getenv("BF16") != nullptr;
     hipEvent_t ev[4]; for (auto& e : ev) hipEventCreate(&e);
     float tA = 0, tB = 0, tC = 0; const int reps = 5;
     for (int rep = 0; rep < reps + 2; ++rep) {
       hipEventRecord(ev[0]);
-      fa.out = bufA; launch_fused(fa, nets, 0, nullptr);
+      fa.out = bufA; launch_fused(fa, nets, 0, bf, nullptr);
       hipEventRecord(ev[1]);
-      fa.bin = bufA; fa.out = bufB; launch_fused(fa, nets, 1, nullptr);
+      fa.bin = bufA; fa.out = bufB; launch_fused(fa, nets, 1, bf, nullptr);
       hipEventRecord(ev[2]);
-      hc.in = bufB; hc.out = bufC; hc.hoff = L.h4; hc.boff = L.b4; launch_conv_h<16, 8, false, false>(hc, nets, nullptr);
+      c4.din = reinterpret_cast<const unsigned char*>(bufB); c4.out = bufC; launch_conv4(c4, nets, nullptr);
       hipEventRecord(ev[3]); hipDeviceSynchronize();
       float a, b, c; hipEventElapsedTime(&a, ev[0], ev[1]); hipEventElapsedTime(&b, ev[1], ev[2]); hipEventElapsedTime(&c, ev[2], ev[3]);
       if (rep >= 2) { tA += a; tB += b; tC += c; }
     }
     printf("kernel times (us): stem_conv2a %.1f  conv2b_conv3 %.1f  conv4 %.1f\n", 1e3 * tA / reps, 1e3 * tB / reps, 1e3 * tC / reps);
   }
+#ifdef MMF_K4_PHASE_CLOCKS
   if (getenv("PHASES"))
   for (int rep = 0; rep < 3; ++rep) {
     long long zero[4][8] = {};
@@ -73,11 +76,11 @@ int main(int argc, char** argv) {
     printf("  stem_conv2a  us/image (x%d): wait-top %.2f commit+barrier %.2f stem %.2f barrier %.2f conv %.2f store %.2f\n", imgs,
            ph[0][0] * 0.01 / imgs, ph[0][1] * 0.01 / imgs, ph[0][2] * 0.01 / imgs, ph[0][3] * 0.01 / imgs,
            ph[0][4] * 0.01 / imgs, ph[0][5] * 0.01 / imgs);
-    for (int w = 0; w < 2; ++w)
-      printf("  conv2b_conv3 wave %d us/image (x%d): barrier-top %.2f prefetch-issue %.2f %s %.2f %s %.2f writeC %.2f barrier %.2f commit %.2f conv3+store %.2f\n", 4 * w, imgs,
-             ph[1 + 2 * w][0] * 0.01 / imgs, ph[1 + 2 * w][1] * 0.01 / imgs, w ? "conv2b" : "stem", ph[1 + 2 * w][2] * 0.01 / imgs,
-             w ? "stem" : "conv2b", ph[1 + 2 * w][3] * 0.01 / imgs,
-             ph[1 + 2 * w][4] * 0.01 / imgs, ph[1 + 2 * w][5] * 0.01 / imgs, ph[1 + 2 * w][6] * 0.01 / imgs, ph[1 + 2 * w][7] * 0.01 / imgs);
+    printf("  conv2b_conv3 X wave us/image (x%d): setup %.2f conv2b+gathers %.2f stem+writeC %.2f barrier %.2f\n", imgs,
+           ph[1][0] * 0.01 / imgs, ph[1][1] * 0.01 / imgs, ph[1][2] * 0.01 / imgs, ph[1][3] * 0.01 / imgs);
+    printf("  conv2b_conv3 Y wave us/image (x%d): stores %.2f conv3 %.2f commit+prefetch+image %.2f barrier %.2f\n", imgs,
+           ph[3][0] * 0.01 / imgs, ph[3][1] * 0.01 / imgs, ph[3][2] * 0.01 / imgs, ph[3][3] * 0.01 / imgs);
   }
+#endif
   return 0;
 }
