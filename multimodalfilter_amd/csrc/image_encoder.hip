@@ -11,10 +11,10 @@
 //   MMF_PREC_F32    one launch per layer, fp32 activations in HBM, exact fp32 products on
 //                   v_mfma_f32_16x16x4_f32 (conv_kernel below: M = output channels, N = 16 pixels of a
 //                   row, K = (tap, 4 input channels); input band + zero halo in LDS as [ci][row][40]).
-//   MMF_PREC_F16X3  (default) image_encoder_fused.inc: stem + conv 32->32 and conv 32->32 + skip +
-//                   conv 32->16 as two fused persistent kernels with the activations in LDS as split
-//                   f16 planes; then conv_f16x3_kernel<16,8> and the split-K linear tail below.
-//   MMF_PREC_BF16   the same two fused kernels with single bf16 products.
+//   MMF_PREC_F16X3  (default) image_encoder_fused.inc: stem + conv 32->32, conv 32->32 + skip +
+//                   conv 32->16, and conv 16->8 as three fused persistent kernels with the activations
+//                   in LDS as split f16 planes; then the split-K linear tail below.
+//   MMF_PREC_BF16   the first two of those kernels with single bf16 products.
 // The per-layer f16x3 kernels (conv_f16x3_kernel<32,...>) remain for A/B runs (MMF_K4_UNFUSED=1).
 // The 8192->64 linear is a split-K MFMA GEMM followed by a one-wave-per-image tail (bias, ReLU,
 // ResLinear 64).  Rooflines and measurements: DESIGN.md section 3, K4.
