@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 18
+#define MMF_ABI_VERSION 19
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -75,7 +75,18 @@ int mmf_pf_reweight_resample(const float* loglik, const float* logw_in, const fl
                              float* logw_out, int32_t* indices_out, int N, int M, int M_out,
                              int d, int mode, void* stream);
 
-/* Dynamic LDS bytes K1 will request for (M, mode) -- for occupancy planning / tests. */
+/* K1 with torchfilter's ``soft_resample_alpha`` option (upstream ParticleFilter._resample,
+ * an option the reference leaves at its default 1.0): ancestors are drawn from the mixture
+ * alpha * w + (1 - alpha) / M -- in fixed point, q'_i = ((A q_i << 8) + (2^24 - A) floor((Q << 8) / M)) >> 32
+ * with A = floor(alpha 2^24) -- and the survivors carry the importance weights w / mixture, normalised,
+ * instead of -log(M_out).  Same arguments as mmf_pf_reweight_resample; mode 1 or 2; 0 < alpha <= 1
+ * (alpha == 1 is the plain resampler).
+ */
+int mmf_pf_reweight_resample_soft(const float* loglik, const float* logw_in, const float* states_in,
+                                  const float* u, float* estimate, float* states_out,
+                                  float* logw_out, int32_t* indices_out, int N, int M, int M_out,
+                                  int d, int mode, float alpha, void* stream);
+
 /* Belief initialisation (replaces torchfilter's ParticleFilter.initialize_beliefs; call site
  * eval_helpers.py:125-131): states[n][m] = mean[n] + chol(covariance[n]) eps[n][m], logw = -log M.
  *  mean (N, d), covariance (N, d, d), eps (N, M, d) standard normal -> states (N, M, d), logw (N, M)
@@ -93,6 +104,7 @@ int mmf_pf_reweight_backward(const float* logw_out, const float* states, const f
                              const float* g_logw_out, float* d_a, float* d_states, int N, int M, int d,
                              void* stream);
 
+/* Dynamic LDS bytes K1 will request for (M, mode) -- for occupancy planning / tests. */
 size_t mmf_pf_reweight_resample_lds_bytes(int M, int mode);
 
 /* ---------------------------------------------------------------- K2: per-particle networks

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 18
+ABI_VERSION = 19
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
@@ -85,6 +85,8 @@ SIGNATURES = {
     "mmf_version": (c_int, []),
     "mmf_pf_reweight_resample": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP,
                                          c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmf_pf_reweight_resample_soft": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP,
+                                              c_int, c_int, c_int, c_int, c_int, ctypes.c_float, c_void_p]),
     "mmf_pf_reweight_resample_lds_bytes": (c_size_t, [c_int, c_int]),
     "mmf_particle_net_floats": (c_size_t, [c_int]),
     "mmf_pack_particle_net": (c_int, [POINTER(MmfParticleNetDesc), _FP, c_int, c_void_p]),
@@ -176,11 +178,19 @@ def stream_of(t: torch.Tensor):
 
 # ------------------------------------------------------------------ typed wrappers
 def pf_reweight_resample(loglik, logw_in, states_in, u, estimate, states_out, logw_out,
-                         indices_out, mode: int):
+                         indices_out, mode: int, soft_alpha: float = 1.0):
+    """K1; ``soft_alpha < 1`` (modes 1 / 2): torchfilter's soft resampling through
+    ``mmf_pf_reweight_resample_soft``."""
     N, M, d = states_in.shape
     M_out = logw_out.shape[1]
     assert loglik.shape == (N, M) and logw_in.shape == (N, M) and estimate.shape == (N, d)
     with _on(states_in):
+        if soft_alpha < 1.0 and mode != 0:
+            _check(load().mmf_pf_reweight_resample_soft(
+                ptr(loglik), ptr(logw_in), ptr(states_in), ptr(u), ptr(estimate), ptr(states_out),
+                ptr(logw_out), ptr(indices_out, dtype=torch.int32), N, M, M_out, d, mode, float(soft_alpha),
+                stream_of(states_in)), "mmf_pf_reweight_resample_soft")
+            return
         _check(load().mmf_pf_reweight_resample(
             ptr(loglik), ptr(logw_in), ptr(states_in), ptr(u), ptr(estimate), ptr(states_out),
             ptr(logw_out), ptr(indices_out, dtype=torch.int32), N, M, M_out, d, mode,

@@ -28,12 +28,16 @@ struct Scratch {  // lives behind the slots in dynamic LDS
 // STAGE: the particle states are kept in LDS next to the CDF (M * 4D more bytes), so the gather
 // of the resampling step reads LDS instead of going back to L2 / HBM for rows this workgroup
 // has just streamed through.
-template <int D, bool STAGE>
+// SOFT (torchfilter's ``soft_resample_alpha`` < 1): ancestors are drawn from the mixture
+// alpha * w_i + (1 - alpha) / M, in fixed point q'_i = ((A q_i << 8) + (2^24 - A) floor((Q << 8) / M)) >> 32
+// with A = floor(alpha 2^24) (so q'_i <= 2^24 and every bound of the integer scheme still holds), and the
+// survivors carry the importance weights w / mixture, normalised (oracle/resample.py).
+template <int D, bool STAGE, bool SOFT = false>
 __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
     const float* __restrict__ loglik, const float* __restrict__ logw_in,
     const float* __restrict__ states_in, const float* __restrict__ u,
     float* __restrict__ estimate, float* states_out, float* logw_out,
-    int32_t* __restrict__ indices_out, int M, int M_out, int mode) {
+    int32_t* __restrict__ indices_out, int M, int M_out, int mode, float alpha) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const bool need_cdf = mode != 0;
   const int slot_bytes = need_cdf ? 8 : 4;
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
   float S = 0.f, acc[D];
 #pragma unroll
   for (int c = 0; c < D; ++c) acc[c] = 0.f;
-  unsigned long long carry = 0;
+  unsigned long long carry = 0, qsum = 0;
   for (int base = 0; base < M; base += chunk) {
     const int i0 = base + tid * 4;
     float e[4];
@@ -145,7 +149,8 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
 #pragma unroll
       for (int c = 0; c < D; ++c) acc[c] += e[j] * st[j * D + c];
     }
-    if (need_cdf) {
+    qsum += tsum;
+    if (need_cdf && !SOFT) {
       const unsigned long long incl = mmf::wave_inclusive_scan(tsum, lane);
       if (lane == MMF_WAVE - 1) sc.wave_tot[wave] = incl;
       __syncthreads();
@@ -156,6 +161,48 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
         total += t;
       }
       unsigned long long run = before + incl - tsum;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        run += q[j];
+        if (i0 + j < M) cdf[i0 + j] = run;
+      }
+      carry += total;
+      __syncthreads();
+    }
+  }
+  if (SOFT && need_cdf) {
+    // Q first (the mixture needs it), then a second sweep: e and q again from the staged x_i (each
+    // thread re-reads only the slots it overwrites), mixture weights, inclusive scan -> CDF
+    const unsigned long long incl = mmf::wave_inclusive_scan(qsum, lane);
+    if (lane == MMF_WAVE - 1) sc.wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned long long Qall = 0;
+    for (int w = 0; w < nwaves; ++w) Qall += sc.wave_tot[w];
+    __syncthreads();
+    const unsigned long long A = static_cast<unsigned long long>(floorf(alpha * 16777216.0f));
+    const unsigned long long uni = (16777216ull - A) * ((Qall << 8) / static_cast<unsigned long long>(M));
+    for (int base = 0; base < M; base += chunk) {
+      const int i0 = base + tid * 4;
+      unsigned long long q[4], tsum = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        q[j] = 0;
+        if (i0 + j < M) {
+          const float e = mmf::detexp(x_load(i0 + j) - mx);
+          q[j] = (((A * static_cast<unsigned long long>(floorf(e * 16777216.0f))) << 8) + uni) >> (kFixBits + 8);
+        }
+        tsum += q[j];
+      }
+      const unsigned long long incl2 = mmf::wave_inclusive_scan(tsum, lane);
+      if (lane == MMF_WAVE - 1) sc.wave_tot[wave] = incl2;
+      __syncthreads();
+      unsigned long long before = carry, total = 0;
+      for (int w = 0; w < nwaves; ++w) {
+        const unsigned long long t = sc.wave_tot[w];
+        if (w < wave) before += t;
+        total += t;
+      }
+      unsigned long long run = before + incl2 - tsum;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         run += q[j];
@@ -214,11 +261,14 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
   int32_t* io = indices_out ? indices_out + static_cast<size_t>(n) * M_out : nullptr;
   const float* un = (mode == 2) ? u + static_cast<size_t>(n) * M_out : nullptr;
   const bool vec_out = (M_out & 3) == 0;
+  const float mix_uniform = (1.0f - alpha) * S / static_cast<float>(M);
+  float rsum = 0.f;
 
   for (int base = 0; base < M_out; base += chunk) {
     const int k0 = base + tid * 4;
     int idx[4];
     float g[4 * D];
+    float lr[4] = {log_uniform, log_uniform, log_uniform, log_uniform};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = k0 + j;
@@ -249,13 +299,19 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
         idx[j] = lo_i;
 #pragma unroll
         for (int c = 0; c < D; ++c) g[j * D + c] = STAGE ? xs_lds[lo_i * D + c] : xs[static_cast<size_t>(lo_i) * D + c];
+        if (SOFT) {  // importance weight of the survivor: w / (alpha w + (1 - alpha) / M), up to the common 1 / S
+          const float e = mmf::detexp((lw[lo_i] + ll[lo_i]) - mx);
+          const float r = e / (alpha * e + mix_uniform);
+          rsum += r;
+          lr[j] = logf(r);
+        }
       }
     }
     if (vec_out && k0 + 3 < M_out) {
       float4* p = reinterpret_cast<float4*>(so + static_cast<size_t>(k0) * D);
 #pragma unroll
       for (int k = 0; k < D; ++k) p[k] = make_float4(g[4 * k], g[4 * k + 1], g[4 * k + 2], g[4 * k + 3]);
-      *reinterpret_cast<float4*>(lo + k0) = make_float4(log_uniform, log_uniform, log_uniform, log_uniform);
+      *reinterpret_cast<float4*>(lo + k0) = make_float4(lr[0], lr[1], lr[2], lr[3]);
       if (io) *reinterpret_cast<int4*>(io + k0) = make_int4(idx[0], idx[1], idx[2], idx[3]);
     } else {
 #pragma unroll
@@ -264,11 +320,26 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
         if (k < M_out) {
 #pragma unroll
           for (int c = 0; c < D; ++c) so[static_cast<size_t>(k) * D + c] = g[j * D + c];
-          lo[k] = log_uniform;
+          lo[k] = lr[j];
           if (io) io[k] = idx[j];
         }
       }
     }
+  }
+  if (SOFT) {  // normalise the survivors' weights (every thread revisits the outputs it wrote)
+    rsum = mmf::wave_sum(rsum);
+    __syncthreads();
+    if (lane == 0) sc.red[wave][0] = rsum;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < nwaves; ++w) t += sc.red[w][0];
+    const float log_r = logf(t);
+    for (int base = 0; base < M_out; base += chunk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = base + tid * 4 + j;
+        if (k < M_out) lo[k] -= log_r;
+      }
   }
 }
 
@@ -287,18 +358,20 @@ size_t staged_lds_bytes(int M, int d, int mode) {
 }
 }  // namespace
 
-extern "C" int mmf_pf_reweight_resample(const float* loglik, const float* logw_in,
-                                        const float* states_in, const float* u, float* estimate,
-                                        float* states_out, float* logw_out, int32_t* indices_out,
-                                        int N, int M, int M_out, int d, int mode, void* stream) {
+namespace {
+int launch_reweight_resample(const float* loglik, const float* logw_in, const float* states_in, const float* u,
+                             float* estimate, float* states_out, float* logw_out, int32_t* indices_out, int N,
+                             int M, int M_out, int d, int mode, float alpha, void* stream) {
   if (!loglik || !logw_in || !states_in || !estimate || !logw_out) return MMF_EINVAL;
   if (N < 0 || M < 1 || M_out < 1 || d < 1 || d > MMF_MAX_STATE_DIM || mode < 0 || mode > 2) return MMF_EINVAL;
   if (mode != 0 && (!u || !states_out || states_out == states_in)) return MMF_EINVAL;
   if (mode == 0 && M_out != M) return MMF_EINVAL;
+  if (!(alpha > 0.f && alpha <= 1.f)) return MMF_EINVAL;
   if (M > 65536 || M_out > 65536) return MMF_ETOOLARGE;
   size_t lds = mmf_pf_reweight_resample_lds_bytes(M, mode);
   if (lds > 160 * 1024) return MMF_ETOOLARGE;
   if (N == 0) return 0;
+  const bool soft = mode != 0 && alpha < 1.f;
   // stage the states in LDS when occupancy does not pay for it: always if every trajectory gets
   // a CU of its own (N <= 256), otherwise only while two workgroups still fit a CU (<= 80 KB each)
   const size_t staged = staged_lds_bytes(M, d, mode);
@@ -308,20 +381,21 @@ extern "C" int mmf_pf_reweight_resample(const float* loglik, const float* logw_i
   int block = ((M + 3) / 4 + MMF_WAVE - 1) / MMF_WAVE * MMF_WAVE;
   if (block > kBlock) block = kBlock;
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define MMF_K1_LAUNCH(D, ST)                                                                   \
+#define MMF_K1_LAUNCH(D, ST, SO)                                                               \
   {                                                                                            \
     if (lds > 64 * 1024) {                                                                     \
       hipError_t e = hipFuncSetAttribute(                                                      \
-          reinterpret_cast<const void*>(&pf_reweight_resample_kernel<D, ST>),                  \
+          reinterpret_cast<const void*>(&pf_reweight_resample_kernel<D, ST, SO>),              \
           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));                  \
       if (e != hipSuccess) return static_cast<int>(e);                                         \
     }                                                                                          \
-    pf_reweight_resample_kernel<D, ST><<<N, block, lds, s>>>(loglik, logw_in, states_in, u,    \
-        estimate, states_out, logw_out, indices_out, M, M_out, mode);                          \
+    pf_reweight_resample_kernel<D, ST, SO><<<N, block, lds, s>>>(loglik, logw_in, states_in, u, \
+        estimate, states_out, logw_out, indices_out, M, M_out, mode, alpha);                   \
   }
 #define MMF_K1(D)                                                                              \
   case D: {                                                                                    \
-    if (stage) MMF_K1_LAUNCH(D, true) else MMF_K1_LAUNCH(D, false)                             \
+    if (soft) { if (stage) MMF_K1_LAUNCH(D, true, true) else MMF_K1_LAUNCH(D, false, true) }   \
+    else if (stage) MMF_K1_LAUNCH(D, true, false) else MMF_K1_LAUNCH(D, false, false)          \
   } break;
   switch (d) {
     MMF_K1(1) MMF_K1(2) MMF_K1(3) MMF_K1(4)
@@ -330,4 +404,23 @@ extern "C" int mmf_pf_reweight_resample(const float* loglik, const float* logw_i
 #undef MMF_K1_LAUNCH
   MMF_CHECK_LAUNCH();
   return 0;
+}
+}  // namespace
+
+extern "C" int mmf_pf_reweight_resample(const float* loglik, const float* logw_in,
+                                        const float* states_in, const float* u, float* estimate,
+                                        float* states_out, float* logw_out, int32_t* indices_out,
+                                        int N, int M, int M_out, int d, int mode, void* stream) {
+  return launch_reweight_resample(loglik, logw_in, states_in, u, estimate, states_out, logw_out, indices_out, N, M,
+                                  M_out, d, mode, 1.0f, stream);
+}
+
+extern "C" int mmf_pf_reweight_resample_soft(const float* loglik, const float* logw_in,
+                                             const float* states_in, const float* u, float* estimate,
+                                             float* states_out, float* logw_out, int32_t* indices_out,
+                                             int N, int M, int M_out, int d, int mode, float alpha,
+                                             void* stream) {
+  if (mode == 0) return MMF_EINVAL;
+  return launch_reweight_resample(loglik, logw_in, states_in, u, estimate, states_out, logw_out, indices_out, N, M,
+                                  M_out, d, mode, alpha, stream);
 }

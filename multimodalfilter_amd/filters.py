@@ -29,6 +29,9 @@ class ParticleFilter(base.Filter):
     """Bootstrap particle filter (T1).
 
     ``resample=None`` resamples iff ``not self.training`` (upstream behaviour).
+    ``soft_resample_alpha < 1`` (upstream option): ancestors are drawn from the
+    mixture ``alpha w + (1 - alpha) / M`` and keep the importance weights ``w / mixture``
+    (``mmf_pf_reweight_resample_soft``; evaluated step by step, not by the native loop).
     ``resample_mode``: ``"systematic"`` (low variance, one uniform per trajectory; what
     ``north_star`` asks for) or ``"multinomial"`` (upstream's distribution, one uniform per
     particle).  Both use the fixed-point CDF of ``csrc/pf_resample.hip``.
@@ -41,8 +44,10 @@ class ParticleFilter(base.Filter):
                  measurement_model: base.ParticleFilterMeasurementModel,
                  num_particles: int = 100, resample: Optional[bool] = None,
                  resample_mode: str = "systematic",
-                 estimation_method: str = "weighted_average"):
+                 estimation_method: str = "weighted_average", soft_resample_alpha: float = 1.0):
         super().__init__(state_dim=dynamics_model.state_dim)
+        assert 0.0 < soft_resample_alpha <= 1.0
+        self.soft_resample_alpha = soft_resample_alpha
         assert isinstance(dynamics_model, base.DynamicsModel)
         assert isinstance(measurement_model, base.ParticleFilterMeasurementModel)
         assert measurement_model.state_dim == self.state_dim
@@ -183,7 +188,7 @@ class ParticleFilter(base.Filter):
                 lw_in = self.particle_log_weights
                 _timed("pf_reweight_resample", 0.0, N * M * 4.0 * (2 + d) + N * Mo * 4.0 * d,
                        lambda: _abi.pf_reweight_resample(loglik, lw_in, states, u, estimate,
-                                                         out, logw_out, idx, mode))
+                                                         out, logw_out, idx, mode, self.soft_resample_alpha))
                 self._spare_states = states
                 self.last_resample_indices = idx
             else:
@@ -245,9 +250,22 @@ class ParticleFilter(base.Filter):
             out = torch.empty((N, Mo, d), dtype=torch.float32, device=states.device)
             logw_out = torch.empty((N, Mo), dtype=torch.float32, device=states.device)
             scratch = torch.empty((N, d), dtype=torch.float32, device=states.device)
+            soft = self.soft_resample_alpha < 1.0
+            idx = torch.empty((N, Mo), dtype=torch.int32, device=states.device) if soft else None
             with torch.no_grad():
                 _abi.pf_reweight_resample(torch.zeros_like(logw), logw.detach().contiguous(),
-                                          states.detach().contiguous(), u, scratch, out, logw_out, None, mode)
+                                          states.detach().contiguous(), u, scratch, out, logw_out, idx, mode,
+                                          self.soft_resample_alpha)
+            if soft:
+                # upstream's soft resampling is differentiable: the ancestors come from K1, the
+                # survivors' states and importance weights are re-derived with torch ops so that
+                # gradients reach the pre-resampling weights and particles
+                a = self.soft_resample_alpha
+                gi = idx.long()
+                mix = torch.logaddexp(logw + math.log(a), torch.full_like(logw, math.log((1.0 - a) / M)))
+                new = torch.gather(logw - mix, 1, gi)
+                out = torch.gather(states, 1, gi[:, :, None].expand(N, Mo, d))
+                logw_out = new - torch.logsumexp(new, dim=1, keepdim=True)
             self.particle_states, self.particle_log_weights = out, logw_out
         return estimate
 
@@ -265,6 +283,8 @@ class ParticleFilter(base.Filter):
         do_resample = (not self.training) if self.resample is None else bool(self.resample)
         if Nb != N or self.num_particles != M or len(nets) > _abi.LOOP_MAX_MEAS:
             return None
+        if do_resample and self.soft_resample_alpha < 1.0:
+            return None  # the native loop resamples with the plain K1
         assert self._initialized, "Particle filter not initialized!"
         mode = _MODES[self.resample_mode] if do_resample else 0
         like = self.particle_states

@@ -18,6 +18,16 @@ differs from the GPU's by an ulp.  So the *definition* of the resampler is integ
 
 6. ``index_k = #{i : cdf_i <= p_k}``  (first ``i`` whose inclusive CDF exceeds ``p_k``)
 
+Soft resampling (upstream's ``soft_resample_alpha`` < 1, an option the reference leaves at 1.0): the
+ancestors are drawn from the mixture ``alpha w_i + (1 - alpha) / M``; in fixed point, with
+``A = floor(alpha * 2**24)``::
+
+       q'_i = ((A * q_i << 8) + (2**24 - A) * ((Q << 8) // M)) >> 32     (<= 2**24: all bounds below hold;
+                                                                           the mean weight Q / M keeps 8 extra bits)
+
+replaces ``q_i`` in steps 4-6, and the survivors carry the importance weights
+``w_idx / (alpha w_idx + (1 - alpha) / M)``, normalised, instead of ``1 / M_out``.
+
 Every quantity fits u64 for ``M <= 65536`` (``Q <= 2**40``, ``U*Q < 2**64``,
 ``k*Q < 2**56``).  Upstream torchfilter resamples with
 ``Categorical(logits=logw).sample((M,))`` (multinomial, torch global RNG; SURVEY.md
@@ -75,7 +85,17 @@ def _fix_uniform(u) -> np.ndarray:
     return np.floor(u.astype(np.float64) * float(1 << FIX_BITS)).astype(np.uint64)
 
 
-def resample_indices(logw: np.ndarray, u: np.ndarray, mode: str, num_out: int = None) -> np.ndarray:
+def soft_mixture(q: np.ndarray, alpha: float) -> np.ndarray:
+    """Fixed-point weights of the soft-resampling mixture ``alpha w + (1 - alpha) / M``."""
+    A = np.uint64(np.floor(np.float64(_F(alpha)) * float(1 << FIX_BITS)))
+    one = np.uint64(1 << FIX_BITS)
+    M = np.uint64(q.shape[1])
+    Q = q.sum(axis=1, dtype=np.uint64)
+    e8 = np.uint64(8)
+    return (((A * q) << e8) + ((one - A) * ((Q << e8) // M))[:, None]) >> np.uint64(FIX_BITS + 8)
+
+
+def resample_indices(logw: np.ndarray, u: np.ndarray, mode: str, num_out: int = None, soft_alpha: float = 1.0) -> np.ndarray:
     """Resampling ancestor indices, ``(N, num_out)`` int32.
 
     ``mode="systematic"``: ``u`` has shape ``(N,)``; ``mode="multinomial"``: ``(N, num_out)``.
@@ -84,7 +104,10 @@ def resample_indices(logw: np.ndarray, u: np.ndarray, mode: str, num_out: int = 
     N, M = logw.shape
     num_out = M if num_out is None else int(num_out)
     assert 1 <= M <= MAX_PARTICLES and 1 <= num_out <= MAX_PARTICLES
+    assert 0.0 < soft_alpha <= 1.0
     q, _, _ = quantise(logw)
+    if soft_alpha < 1.0:
+        q = soft_mixture(q, soft_alpha)
     cdf = np.cumsum(q, axis=1, dtype=np.uint64)
     Q = cdf[:, -1]
     U = _fix_uniform(u)
@@ -106,7 +129,7 @@ def resample_indices(logw: np.ndarray, u: np.ndarray, mode: str, num_out: int = 
     return idx
 
 
-def reweight_resample(loglik, logw, states, u, mode: str, num_out: int = None):
+def reweight_resample(loglik, logw, states, u, mode: str, num_out: int = None, soft_alpha: float = 1.0):
     """What kernel K1 (``mmf_pf_reweight_resample``) computes, restated on the CPU.
 
     Follows the post-measurement half of upstream ``ParticleFilter.forward`` (SURVEY.md
@@ -129,7 +152,14 @@ def reweight_resample(loglik, logw, states, u, mode: str, num_out: int = None):
         logw_out = ((tot - m[:, None]).astype(np.float64) - np.log(S)[:, None]).astype(_F)
         return estimate, states.copy(), logw_out, None
     num_out = M if num_out is None else int(num_out)
-    idx = resample_indices(tot, u, mode, num_out)
+    idx = resample_indices(tot, u, mode, num_out, soft_alpha)
     states_out = np.take_along_axis(states, idx[:, :, None].astype(np.int64), axis=1)
-    logw_out = np.full((N, num_out), -np.log(_F(num_out)), dtype=_F)
+    if soft_alpha < 1.0:
+        a = np.float64(_F(soft_alpha))
+        ratio = w / (a * w + (1.0 - a) / M)                 # importance weight of every candidate
+        r = np.take_along_axis(ratio, idx.astype(np.int64), axis=1)
+        with np.errstate(divide="ignore"):
+            logw_out = (np.log(r) - np.log(r.sum(axis=1, keepdims=True))).astype(_F)
+    else:
+        logw_out = np.full((N, num_out), -np.log(_F(num_out)), dtype=_F)
     return estimate, states_out, logw_out, idx

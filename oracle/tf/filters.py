@@ -27,9 +27,12 @@ class ParticleFilter(base.Filter):
         resample: bool = None,
         resample_mode: str = "systematic",
         estimation_method: str = "weighted_average",
+        soft_resample_alpha: float = 1.0,
     ):
         super().__init__(state_dim=dynamics_model.state_dim)
         assert measurement_model.state_dim == self.state_dim
+        assert 0.0 < soft_resample_alpha <= 1.0
+        self.soft_resample_alpha = soft_resample_alpha
         self.dynamics_model = dynamics_model
         self.measurement_model = measurement_model
         self.num_particles = num_particles
@@ -115,15 +118,25 @@ class ParticleFilter(base.Filter):
             u = self.noise.uniform((N,), like=like)
         else:
             u = self.noise.uniform((N, Mo), like=like)
+        alpha = float(self.soft_resample_alpha)
         idx = _rs.resample_indices(
-            like.detach().cpu().numpy(), u.detach().cpu().numpy(), self.resample_mode, Mo
+            like.detach().cpu().numpy(), u.detach().cpu().numpy(), self.resample_mode, Mo, alpha
         )
         idx_t = torch.from_numpy(idx.astype(np.int64)).to(like.device)
         self.last_resample_indices = idx_t
         self.particle_states = torch.gather(
             self.particle_states, 1, idx_t[:, :, None].expand(N, Mo, d)
         )
-        self.particle_log_weights = like.new_full((N, Mo), -math.log(Mo))
+        if alpha < 1.0:
+            # upstream ``_resample``: survivors keep ``logw - log(mixture)``, re-normalised -- the
+            # importance weights that make the soft draw unbiased (and differentiable upstream)
+            lw = like - torch.logsumexp(like, dim=1, keepdim=True)
+            a = float(np.float32(alpha))
+            mix = torch.logaddexp(lw + math.log(a), torch.full_like(lw, math.log((1.0 - a) / M)))
+            new = torch.gather(lw - mix, 1, idx_t)
+            self.particle_log_weights = new - torch.logsumexp(new, dim=1, keepdim=True)
+        else:
+            self.particle_log_weights = like.new_full((N, Mo), -math.log(Mo))
 
 
 class _IdentityMeasurementModel(base.KalmanFilterMeasurementModel):

@@ -29,7 +29,7 @@ def _abi():
 
 
 # ------------------------------------------------------------------------------ K1
-def _k1(abi, ll, lw, x, u, mode, M_out=None, want_idx=True):
+def _k1(abi, ll, lw, x, u, mode, M_out=None, want_idx=True, soft_alpha=1.0):
     dev = _cuda()
     N, M, d = x.shape
     M_out = M if M_out is None else M_out
@@ -41,7 +41,7 @@ def _k1(abi, ll, lw, x, u, mode, M_out=None, want_idx=True):
         return est.cpu().numpy(), None, lw_out.cpu().numpy(), None
     xo = torch.empty((N, M_out, d), device=dev)
     idx = torch.empty((N, M_out), dtype=torch.int32, device=dev) if want_idx else None
-    abi.pf_reweight_resample(t(ll), t(lw), t(x), t(u), est, xo, lw_out, idx, mode)
+    abi.pf_reweight_resample(t(ll), t(lw), t(x), t(u), est, xo, lw_out, idx, mode, soft_alpha)
     torch.cuda.synchronize()
     return est.cpu().numpy(), xo.cpu().numpy(), lw_out.cpu().numpy(), None if idx is None else idx.cpu().numpy()
 
@@ -64,6 +64,36 @@ def test_k1_indices_bit_exact(N, M, d, mode):
     np.testing.assert_array_equal(xo, w_x)               # gathered particles are copies
     np.testing.assert_allclose(lwo, w_lw, rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(est, w_est, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("N,M,Mo,d", [(1, 1, 1, 3), (3, 7, 7, 2), (4, 30, 300, 3), (5, 300, 30, 3), (2, 1000, 1000, 2),
+                                      (3, 4096, 4096, 3), (2, 4099, 4099, 1), (2, 8192, 8192, 2), (1, 16384, 16384, 3)])
+@pytest.mark.parametrize("mode", ["systematic", "multinomial"])
+@pytest.mark.parametrize("alpha", [0.5, 0.9])
+def test_k1_soft_resampling_matches_oracle(N, M, Mo, d, mode, alpha):
+    """``soft_resample_alpha`` < 1 (``mmf_pf_reweight_resample_soft``): ancestors drawn from the
+    fixed-point mixture are bit-exact against the oracle, the survivors' importance weights agree to
+    1e-5 and are normalised; ``-inf`` log-likelihoods can only be reached through the uniform part."""
+    abi = _abi()
+    rng = np.random.RandomState(N * 977 + M + 13 * d + int(100 * alpha))
+    ll = (rng.standard_normal((N, M)) * 3).astype(np.float32)
+    if M >= 30:
+        ll[:, rng.randint(0, M, 3)] = -np.inf
+    lw = np.log(rng.dirichlet(np.ones(M) * 0.5, N) + 1e-30).astype(np.float32)
+    x = rng.standard_normal((N, M, d)).astype(np.float32)
+    u = rng.uniform(0, 1, (N,) if mode == "systematic" else (N, Mo)).astype(np.float32)
+    code = {"systematic": 1, "multinomial": 2}[mode]
+    est, xo, lwo, idx = _k1(abi, ll, lw, x, u, code, M_out=Mo, soft_alpha=alpha)
+    w_est, w_x, w_lw, w_idx = rs.reweight_resample(ll, lw, x, u, mode, Mo, soft_alpha=alpha)
+    np.testing.assert_array_equal(idx, w_idx)
+    np.testing.assert_array_equal(xo, w_x)
+    fin = np.isfinite(w_lw)
+    assert np.array_equal(fin, np.isfinite(lwo))
+    np.testing.assert_allclose(lwo[fin], w_lw[fin], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(est, w_est, rtol=1e-4, atol=1e-5)
+    assert abs(np.exp(lwo.astype(np.float64)).sum(1) - 1).max() < 1e-4
+    if M > 1:  # and it is a different draw from the plain resampler's
+        assert not np.array_equal(idx, rs.resample_indices(ll + lw, u, mode, Mo)) or M < 30
 
 
 @pytest.mark.parametrize("N,M,d", [(1, 1, 2), (4, 30, 3), (3, 300, 3), (2, 4096, 2), (2, 5001, 3), (1, 32768, 3)])

@@ -133,6 +133,103 @@ def test_engine_ekf_equals_kalman_closed_form(d, loop):
 
 
 @pytest.mark.parametrize("mode", ["systematic", "multinomial"])
+def test_engine_pf_soft_resampling_tracks_oracle_and_kalman(mode):
+    """``ParticleFilter(soft_resample_alpha=0.5)`` (upstream option; ``mmf_pf_reweight_resample_soft``)
+    with forward-only user models: teacher-forced, every step's posterior mean within 1e-4, ancestors
+    equal up to 1e-3 of them and the survivors' importance weights within 1e-4 of the oracle's;
+    free-running, both filters stay within Monte-Carlo distance of the Kalman closed form.  In train
+    mode with ``resample=True`` the soft draw is differentiable (gradients reach the dynamics)."""
+    import multimodalfilter_amd as mmf
+
+    dev = _dev()
+    d = 3
+    A, B, L, Rt = _system(d, r_scale=3.0)
+    N, T, M = 3, 4, 8192
+    g = torch.Generator().manual_seed(5)
+    us = torch.randn(T, N, 7, generator=g)
+    zs = 0.3 * torch.randn(T, N, d, generator=g)
+    mu0 = 0.2 * torch.randn(N, d, generator=g)
+    cov0 = (0.1 * torch.eye(d))[None].expand(N, d, d)
+    eps0 = torch.randn((N, M, d), generator=g)
+    eps = [torch.randn((N, M, d), generator=g) for _ in range(T)]
+    uu = [torch.rand((N,) if mode == "systematic" else (N, M), generator=g) for _ in range(T)]
+
+    ODyn, _, OLik = _user_models(otf.base, A, B, L, Rt, "cpu")
+    o = otf.filters.ParticleFilter(dynamics_model=ODyn(), measurement_model=OLik(), num_particles=M,
+                                   resample_mode=mode, soft_resample_alpha=0.5)
+    o.eval()
+    o.noise = OReplay([eps0] + eps, uu)
+    o.initialize_beliefs(mean=mu0, covariance=cov0)
+    want, want_idx, want_lw, beliefs = [], [], [], []
+    for t in range(T):
+        beliefs.append((o.particle_states, o.particle_log_weights))
+        want.append(o(observations={"z": zs[t]}, controls=us[t]))
+        want_idx.append(o.last_resample_indices)
+        want_lw.append(o.particle_log_weights)
+    want = torch.stack(want)
+    assert float(want_lw[0].std()) > 1e-3  # soft resampling leaves non-uniform weights
+
+    Dyn, _, Lik = _user_models(mmf.base, A, B, L, Rt, dev)
+    f = mmf.filters.ParticleFilter(dynamics_model=Dyn(), measurement_model=Lik(), num_particles=M,
+                                   resample_mode=mode, soft_resample_alpha=0.5)
+    f.eval()
+    f.record_indices = True
+    f.noise = mmf.ReplayNoise([eps0], [])
+    f.initialize_beliefs(mean=mu0.to(dev), covariance=cov0.to(dev))
+    scale = max(1.0, float(want.abs().max()))
+    differ = 0
+    for t in range(T):
+        f.particle_states = beliefs[t][0].to(dev).contiguous()
+        f.particle_log_weights = beliefs[t][1].to(dev).contiguous()
+        f._spare_states = None
+        f.noise = mmf.ReplayNoise([eps[t]], [uu[t]])
+        est = f(observations={"z": zs[t].to(dev)}, controls=us[t].to(dev)).cpu()
+        assert float((est - want[t]).abs().max()) / scale < REL_TOL, t
+        same = f.last_resample_indices.cpu().long() == want_idx[t]
+        differ += int((~same).sum())
+        lw = f.particle_log_weights.cpu()
+        assert float((torch.logsumexp(lw, dim=1)).abs().max()) < 1e-4
+        assert float((lw - want_lw[t])[same].abs().max()) < 1e-4, t
+    assert differ <= 1e-3 * T * N * M, f"{differ} of {T * N * M} resample indices differ"
+
+    # free-running through forward_loop (the Python step loop: the native loop resamples with the plain K1)
+    f.noise = mmf.ReplayNoise([eps0] + eps, uu)
+    f.initialize_beliefs(mean=mu0.to(dev), covariance=cov0.to(dev))
+    got = f.forward_loop(observations={"z": zs.to(dev)}, controls=us.to(dev)).cpu()
+    for n in range(N):
+        kal = _kalman_closed_form(A, B, L, Rt, mu0[n], 0.1 * torch.eye(d), us[:, n], zs[:, n])
+        for t in range(T):
+            assert float((got[t, n].double() - kal[t][0]).abs().max()) < 0.06, (n, t)
+            assert float((want[t, n].double() - kal[t][0]).abs().max()) < 0.06, (n, t)
+
+    # differentiable soft resampling (training backend, resample forced on)
+    from multimodalfilter_amd import engine
+
+    class Learnable(Dyn):
+        def __init__(self):
+            super().__init__()
+            self.gain = torch.nn.Parameter(torch.ones(()))
+
+        def forward(self, *, initial_states, controls):
+            y, tril = super().forward(initial_states=initial_states, controls=controls)
+            return self.gain * y, tril
+
+    engine.set_training_backend("autograd")
+    try:
+        ft = mmf.filters.ParticleFilter(dynamics_model=Learnable(), measurement_model=Lik(), num_particles=256,
+                                        resample=True, resample_mode=mode, soft_resample_alpha=0.5).to(dev)
+        ft.train()
+        ft.noise = mmf.NoiseSource(1)
+        ft.initialize_beliefs(mean=mu0.to(dev), covariance=cov0.to(dev))
+        pred = ft.forward_loop(observations={"z": zs.to(dev)}, controls=us.to(dev))
+        assert ft.particle_log_weights.requires_grad and float(ft.particle_log_weights.std()) > 1e-3
+        pred.square().mean().backward()
+        assert ft.dynamics_model.gain.grad is not None and float(ft.dynamics_model.gain.grad.abs()) > 0
+    finally:
+        engine.set_training_backend(None)
+
+
+@pytest.mark.parametrize("mode", ["systematic", "multinomial"])
 def test_engine_pf_with_user_models_tracks_oracle_and_kalman(mode):
     """K1 behind ``ParticleFilter`` with forward-only user models on identical pre-drawn noise.
     Teacher-forced (engine re-synchronised to the oracle's belief before each of 4 resampling

@@ -253,3 +253,81 @@ def test_unscented_filter_equals_kalman_filter_on_linear_system():
             torch.testing.assert_close(f._belief_covariance[n], want[-1][1], rtol=1e-4, atol=1e-5)
         wc, wm = strategy.compute_sigma_weights(d)
         assert abs(float(wm.sum()) - 1.0) < 1e-5
+
+
+# ------------------------------------------------------------------------------ soft resampling
+def test_soft_resampling_mixture_is_alpha_w_plus_uniform():
+    """Fixed-point mixture weights: proportional to ``alpha w + (1 - alpha) / M`` to the scheme's
+    resolution (every weight is floored to a multiple of 2^-24 of the LARGEST one, so a probability
+    is off by at most M 2^-24), bounded by 2^24 each, and ``alpha = 1`` is the plain resampler."""
+    from oracle import resample as rs
+
+    rng = np.random.RandomState(3)
+    N, M = 5, 777
+    logw = (rng.standard_normal((N, M)) * 3).astype(np.float32)
+    logw[:, 10] = -np.inf
+    q, e, _ = rs.quantise(logw)
+    for alpha in (0.25, 0.5, 0.9):
+        qm = rs.soft_mixture(q, alpha)
+        assert qm.max() <= (1 << 24)
+        w = e.astype(np.float64) / e.astype(np.float64).sum(1, keepdims=True)
+        want = alpha * w + (1 - alpha) / M
+        got = qm.astype(np.float64) / qm.astype(np.float64).sum(1, keepdims=True)
+        assert np.abs(got - want).max() < M * 2.0 ** -24
+        assert (qm[:, 10] > 0).all()  # a zero-weight particle is reachable through the uniform part
+    u = rng.uniform(0, 1, N).astype(np.float32)
+    np.testing.assert_array_equal(rs.resample_indices(logw, u, "systematic", soft_alpha=1.0),
+                                  rs.resample_indices(logw, u, "systematic"))
+
+
+def test_soft_resampling_is_unbiased():
+    """Importance weights ``w / mixture`` undo the mixture: over many trajectories the weighted mean
+    of the survivors equals the posterior mean (same inputs, independent uniforms)."""
+    from oracle import resample as rs
+
+    rng = np.random.RandomState(4)
+    N, M, d = 4000, 64, 2
+    ll = np.tile((rng.standard_normal((1, M)) * 2).astype(np.float32), (N, 1))
+    lw = np.full((N, M), -np.log(M), np.float32)
+    x = np.tile(rng.standard_normal((1, M, d)).astype(np.float32), (N, 1, 1))
+    u = rng.uniform(0, 1, (N, M)).astype(np.float32)
+    est, xo, lwo, _ = rs.reweight_resample(ll, lw, x, u, "multinomial", soft_alpha=0.5)
+    assert abs(np.exp(lwo.astype(np.float64)).sum(1) - 1).max() < 1e-5
+    # self-normalised importance sampling: ratio of means (its bias is O(1 / M) of the per-draw ratio)
+    w = np.exp(lwo.astype(np.float64))
+    per_traj = (w[:, :, None] * xo).sum(1)
+    spread = x[0].std(0)
+    assert np.abs(per_traj.mean(0) - est[0]).max() < 0.05 * spread.max()
+    # the plain resampler's survivors, equally weighted, agree too
+    _, xo1, _, _ = rs.reweight_resample(ll, lw, x, u, "multinomial")
+    assert np.abs(xo1.mean(1).mean(0) - est[0]).max() < 0.05 * spread.max()
+
+
+def test_oracle_particle_filter_soft_resampling_weights():
+    """``oracle.tf.filters.ParticleFilter(soft_resample_alpha=0.5)``: after a resampling step the
+    log-weights are the normalised ``logw - log(mixture)`` of the ancestors (upstream ``_resample``),
+    and they equal ``oracle.resample.reweight_resample``'s."""
+    A, B, L, Rt = _system(2)
+    dyn, lik = LinearDynamics(A, B, L), GaussianLik(2, Rt @ Rt.T)
+    M, N = 200, 3
+    f = tf.filters.ParticleFilter(dynamics_model=dyn, measurement_model=lik, num_particles=M,
+                                  resample_mode="systematic", soft_resample_alpha=0.5)
+    f.eval()
+    g = torch.Generator().manual_seed(0)
+    eps0, eps1 = torch.randn((N, M, 2), generator=g), torch.randn((N, M, 2), generator=g)
+    u = torch.rand((N,), generator=g)
+    f.noise = ReplayNoise([eps0, eps1], [u])
+    f.initialize_beliefs(mean=torch.zeros(N, 2), covariance=(0.1 * torch.eye(2))[None].expand(N, 2, 2))
+    states0, lw0 = f.particle_states.clone(), f.particle_log_weights.clone()
+    z, ctrl = 0.3 * torch.randn((N, 2), generator=g), torch.randn((N, 7), generator=g)
+    f(observations={"z": z}, controls=ctrl)
+    lw = f.particle_log_weights
+    assert float((torch.logsumexp(lw, dim=1)).abs().max()) < 1e-5
+    assert float(lw.std()) > 1e-3  # not the uniform reset of the plain resampler
+    # the same step through the normative numpy restatement
+    pred, tril = dyn(initial_states=states0.reshape(N * M, 2), controls=ctrl.repeat_interleave(M, 0))
+    states = (pred + torch.einsum("rij,rj->ri", tril, eps1.reshape(N * M, 2))).reshape(N, M, 2)
+    ll = lik(states=states, observations={"z": z})
+    _, xo, lwo, idx = rs.reweight_resample(ll.numpy(), lw0.numpy(), states.numpy(), u.numpy(), "systematic", soft_alpha=0.5)
+    np.testing.assert_array_equal(f.last_resample_indices.numpy(), idx)
+    np.testing.assert_allclose(lw.numpy(), lwo, rtol=1e-5, atol=1e-5)
