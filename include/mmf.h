@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 19
+#define MMF_ABI_VERSION 20
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -227,6 +227,20 @@ int mmf_particle_net_train_backward(const float* packed_t, const float* head_w, 
 int mmf_particle_net_weight_grads(const float* dz, const float* stash, float* partial_w,
                                   float* partial_b, int n_layers, int R, int n_splits, void* stream);
 
+/* The narrow reductions of the same backward in one pass over the rows (as GEMMs they are the
+ * library's worst shapes, as torch reductions five passes over (R, 64) tensors):
+ *   first layer   dW0[c][i]  = sum_r dz_first[r][c] states[r][i]          (64, d)
+ *   head          dWh[o][c]  = sum_r d_out[r][o] h_last[r][c]             (n_out, 64),  dbh[o] = sum_r d_out[r][o]
+ *   join layer    d traj_bias[n][c] = sum_m dz_join[n M + m][c]           (N, 64)
+ * as per-slice partials over `n_slices` slices of every trajectory's M rows: p_first (N n_slices, 64, 4),
+ * p_head (N n_slices, 4, 64), p_dout (N n_slices, 4), p_traj (N n_slices, 64); the caller adds the
+ * slices.  dz_first, dz_join, h_last: (N M, 64); states (N M, d); d_out (N M, n_out); d, n_out <= 4.
+ */
+int mmf_particle_net_small_grads(const float* dz_first, const float* dz_join, const float* h_last,
+                                 const float* states, const float* d_out, float* p_first, float* p_head,
+                                 float* p_dout, float* p_traj, int N, int M, int d, int n_out,
+                                 int n_slices, void* stream);
+
 /* ---------------------------------------------------------------- K4: image encoder
  * Replaces observation_image_layers (crossmodal/door_models/layers.py:43-63;
  * push_models/layers.py:91-104, default variant): Conv 1->32 k5, ReLU, ResConv 32 k3,
@@ -281,7 +295,9 @@ int mmf_image_encoder(const float* const* packed, int n_nets, const float* image
  *                                  (`packed_bwd` = mmf_pack_image_convs_backward), ReLU masks fused
  *  mmf_conv_weight_grads           dW[tap][co][ci] partials of one 3x3 layer from its output gradient g
  *                                  (N,co,32,32) and input act (N,ci,32,32): (co,ci) in {(32,32),(16,32),(8,16)};
- *                                  partial (n_blocks*8, 9, 32, 32), summed over dim 0 by the caller
+ *                                  partial (n_blocks*8, 9, 32, 32), summed over dim 0 by the caller.
+ *                                  (co,ci) = (32,1): the 5x5 stem, act = images (N,32,32); the head of each
+ *                                  partial slot holds dW1 as [co 32][tap 32] (25 taps live)
  */
 size_t mmf_image_convs_backward_floats(void);
 int mmf_pack_image_convs_backward(const MmfImageEncoderDesc* desc, float* packed_bwd, void* stream);

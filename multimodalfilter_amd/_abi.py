@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 19
+ABI_VERSION = 20
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
@@ -107,6 +107,7 @@ SIGNATURES = {
                                             c_int, c_int, c_int, c_void_p]),
     "mmf_particle_net_train_forward": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_particle_net_weight_grads": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
+    "mmf_particle_net_small_grads": (c_int, [_FP] * 9 + [c_int] * 5 + [c_void_p]),
     "mmf_particle_net_train_backward": (c_int, [_FP, _FP, c_int, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_image_encoder_floats": (c_size_t, []),
     "mmf_image_encoder_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -311,6 +312,15 @@ def particle_net_weight_grads(dz, stash, partial_w, partial_b, n_layers: int, R:
         _check(load().mmf_particle_net_weight_grads(ptr(dz), ptr(stash), ptr(partial_w), ptr(partial_b),
                                                     n_layers, R, n_splits, stream_of(dz)),
                "mmf_particle_net_weight_grads")
+
+
+def particle_net_small_grads(dz_first, dz_join, h_last, states, d_out, p_first, p_head, p_dout, p_traj,
+                             N: int, M: int, n_slices: int):
+    with _on(dz_first):
+        _check(load().mmf_particle_net_small_grads(ptr(dz_first), ptr(dz_join), ptr(h_last), ptr(states), ptr(d_out),
+                                                   ptr(p_first), ptr(p_head), ptr(p_dout), ptr(p_traj), N, M,
+                                                   states.shape[1], d_out.shape[1], n_slices, stream_of(dz_first)),
+               "mmf_particle_net_small_grads")
 
 
 def fuse_virtual_sensors(z, tril, w, z_out, tril_out, mode: int):

@@ -874,6 +874,39 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const float* __restrict
     for (int r = 0; r < 16; ++r) p[(tap * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * 32 + i] = acc[tap][r];
 }
 
+// The 5x5 stem's weight gradient, same scheme with the 25 taps as the B columns:
+// dW1[co][t] = sum g1[n][co][y][x] * image[n][y + t / 5 - 2][x + t % 5 - 2]; one 32x32 accumulator
+// (co x tap, 7 columns idle) per wave, partial [co][32] at the head of the wave's slot.
+__global__ __launch_bounds__(512) void conv_wgrad_stem_kernel(const float* __restrict__ g, const float* __restrict__ images,
+                                                              float* __restrict__ partial, int N) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, kk = lane >> 5;
+  const int ty = i / 5 - 2, tx = i % 5 - 2;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    const float* gn = g + (static_cast<size_t>(n) * 32 + i) * kImg * kImg;
+    const float* im = images + static_cast<size_t>(n) * kImg * kImg;
+    for (int y = wave; y < kImg; y += 8) {
+      const int yy = y + ty;
+      const bool row_ok = i < 25 && yy >= 0 && yy < kImg;
+      float a[16], b[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        a[s] = gn[y * kImg + 16 * kk + s];
+        const int x = 16 * kk + s + tx;
+        b[s] = (row_ok && x >= 0 && x < kImg) ? im[yy * kImg + x] : 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    }
+  }
+  float* p = partial + (static_cast<size_t>(blockIdx.x) * 8 + wave) * 9 * 32 * 32;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2) + 4 * kk) * 32 + i] = acc[r];
+}
+
 #include "image_encoder_fused.inc"
 
 }  // namespace
@@ -1061,6 +1094,7 @@ extern "C" int mmf_conv_weight_grads(const float* g, const float* act, float* pa
   if (co == 32 && ci == 32) conv_wgrad_kernel<32, 32><<<n_blocks, 512, 0, s>>>(g, act, partial, N);
   else if (co == 16 && ci == 32) conv_wgrad_kernel<16, 32><<<n_blocks, 512, 0, s>>>(g, act, partial, N);
   else if (co == 8 && ci == 16) conv_wgrad_kernel<8, 16><<<n_blocks, 512, 0, s>>>(g, act, partial, N);
+  else if (co == 32 && ci == 1) conv_wgrad_stem_kernel<<<n_blocks, 512, 0, s>>>(g, act, partial, N);
   else return MMF_EINVAL;
   MMF_CHECK_LAUNCH();
   return 0;

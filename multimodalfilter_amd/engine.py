@@ -328,31 +328,50 @@ class ParticleNetFunction(torch.autograd.Function):
         # every reduction over the R particles of the 64x64 layers in one launch: dW_l = dz_l^T
         # stash_l and db_l = column sums, as per-slice partials (slot NL of dW pairs unrelated
         # tensors and is ignored; its db is the first layer's bias gradient)
-        S = max(1, min(256, R // 512))
+        S = max(1, min(128, R // 512))  # 32 x 8192 particles: 64 slices 51.8 ms / training step, 128 49.9, 256 49.9
         pw = torch.empty((NL + 1, S, U, U), dtype=torch.float32, device=st.device)
         pb = torch.empty((NL + 1, S, U), dtype=torch.float32, device=st.device)
         _abi.particle_net_weight_grads(dz, stash, pw, pb, NL + 1, R, S)
         dW, db = pw.sum(1), pb.sum(1)                    # (NL + 1, 64, 64), (NL + 1, 64)
         quad = kind == _abi.KIND_JACOBIAN
-        if quad:  # tangent rows carry no bias: bias gradients come from the primal row of each group
+        n_out = d_out.shape[1]
+        if quad:
+            # tangent rows carry no bias: bias gradients come from the primal row of each group of four
+            # (N rows in all: plain torch reductions)
             db = dz[:, 0::4, :].sum(1)
-        # (64 x R) @ (R x d) and (n_out x R) @ (R x 64) with d, n_out <= 4 are column-scaled sums;
-        # as GEMMs they are the library's worst shapes (0.6-2 ms each at R = 262k)
-        grads[0] = torch.stack([(dz[NL] * st[:, i:i + 1]).sum(0) for i in range(d)], dim=1)  # first layer (64, d)
+            g_first = torch.stack([(dz[NL] * st[:, i:i + 1]).sum(0) for i in range(d)], dim=1)
+            g_head = torch.stack([(stash[NL] * d_out[:, o:o + 1]).sum(0) for o in range(n_out)], dim=0)
+            g_head_b = d_out[0::4].sum(0)
+            d_traj_bias = dz[2][0::4]
+        else:
+            # the narrow reductions -- (64 x R) @ (R x d), (n_out x R) @ (R x 64), column sums of d_out and
+            # the per-trajectory sums of the join layer's dz -- in one pass over the rows
+            # (mmf_particle_net_small_grads; as GEMMs they are the library's worst shapes, as torch
+            # reductions five passes over (R, 64) tensors)
+            SL = max(1, min(16, M // 256))
+            pf = torch.empty((N * SL, U, 4), dtype=torch.float32, device=st.device)
+            ph = torch.empty((N * SL, 4, U), dtype=torch.float32, device=st.device)
+            pd = torch.empty((N * SL, 4), dtype=torch.float32, device=st.device)
+            pt = torch.empty((N * SL, U), dtype=torch.float32, device=st.device)
+            _abi.particle_net_small_grads(dz[NL], dz[2], stash[NL], st, d_out, pf, ph, pd, pt, N, M, SL)
+            g_first = pf.sum(0)[:, :d]
+            g_head = ph.sum(0)[:n_out]
+            g_head_b = pd.sum(0)[:n_out]
+            d_traj_bias = pt.view(N, SL, U).sum(1)
+        grads[0] = g_first                               # first layer (64, d)
         grads[1] = db[NL]
         grads[2], grads[3], grads[4], grads[5] = dW[0], db[0], dW[1], db[1]  # encoder residual block
         gj = torch.zeros_like(params[6], dtype=torch.float32)  # join: only the state columns are ours
         off = net.join_state_off
         gj[:, off:off + U] = dW[2]
         grads[6] = gj
-        d_traj_bias = dz[2][0::4] if quad else dz[2].view(N, M, U).sum(1)
         for i in range(net.n_res):
             for k in range(2):
                 layer = 3 + 2 * i + k
                 grads[7 + 4 * i + 2 * k] = dW[layer]
                 grads[8 + 4 * i + 2 * k] = db[layer]
-        grads[-2] = torch.stack([(stash[NL] * d_out[:, o:o + 1]).sum(0) for o in range(d_out.shape[1])], dim=0)
-        grads[-1] = d_out[0::4].sum(0) if quad else d_out.sum(0)
+        grads[-2] = g_head
+        grads[-1] = g_head_b
         return (None, None, None, None, d_states, d_traj_bias, *grads)
 
 
@@ -562,8 +581,7 @@ class ImageConvsFunction(torch.autograd.Function):
     ReLU masks fused (``mmf_image_convs_train_backward``) and the 3x3 weight gradients as split-K MFMA
     correlations (``mmf_conv_weight_grads``): no MIOpen kernel in a training step.  Exact fp32.
     ``apply(seq, images (N, 32, 32), *conv weights and biases) -> (N, 8, 32, 32)``; the flatten + linear
-    + ResLinear behind it stay torch modules (library GEMMs).  The 5x5 stem's weight gradient
-    (3 % of the MACs, one input channel) is an unfold + batched GEMM; bias gradients are sums."""
+    + ResLinear behind it stay torch modules (library GEMMs); bias gradients are sums."""
 
     @staticmethod
     def forward(ctx, seq, images, *params):
@@ -611,8 +629,8 @@ class ImageConvsFunction(torch.autograd.Function):
             return partial.sum(0)[:, :co, :ci].permute(1, 2, 0).reshape(co, ci, 3, 3).contiguous()
 
         gw4, gw3, gw2b, gw2a = wgrad(g_a4, a3), wgrad(g3, a2), wgrad(g2, h), wgrad(gh, a1)
-        cols = torch.nn.functional.unfold(img[:, None], kernel_size=5, padding=2)      # (N, 25, 1024)
-        gw1 = torch.einsum("ncp,ntp->ct", g1.reshape(N, 32, 1024), cols).reshape(32, 1, 5, 5)
+        _abi.conv_weight_grads(g1, img[:, None], partial, blocks)                       # the 5x5 stem: [co][tap]
+        gw1 = partial.view(blocks * 8, -1)[:, :1024].sum(0).view(32, 32)[:, :25].reshape(32, 1, 5, 5).contiguous()
         bsum = lambda g: g.sum(dim=(0, 2, 3))
         # parameter order = PackedImageEncoder._sources()[:10]: w1 w2a w2b w3 w4 | b1 b2a b2b b3 b4
         return (None, None, gw1, gw2a, gw2b, gw3, gw4, bsum(g1), bsum(gh), bsum(g2), bsum(g3), bsum(g_a4))
