@@ -596,6 +596,10 @@ class VirtualSensorUnscentedKalmanFilter(VirtualSensorExtendedKalmanFilter):
         points = torch.empty((N, P, d), dtype=torch.float32, device=mu.device)
         not_pd = torch.zeros(1, dtype=torch.int32, device=mu.device)
         _abi.ukf_sigma_points(mu, Sigma, math.sqrt(d + lambd), points, not_pd)
+        # checked BEFORE the points go anywhere: the rows of a non-PD belief are not sigma points, and
+        # the networks would be evaluated on them (raising the f16x3 range flag for whoever comes next)
+        if int(not_pd.item()):
+            raise ValueError("unscented predict: belief covariance is not positive definite")
         if hasattr(dyn, "propagate_encoded"):
             if ctrl_ctx is None:
                 ctrl_ctx = dyn.encode_controls(controls)
@@ -610,8 +614,6 @@ class VirtualSensorUnscentedKalmanFilter(VirtualSensorExtendedKalmanFilter):
         mu_pred = torch.empty((N, d), dtype=torch.float32, device=mu.device)
         Sigma_pred = torch.empty((N, d, d), dtype=torch.float32, device=mu.device)
         _abi.ukf_moments(moved, wm0, wc0, wi, L, mu_pred, Sigma_pred)
-        if int(not_pd.item()):
-            raise ValueError("unscented predict: belief covariance is not positive definite")
         return mu_pred, Sigma_pred
 
     def _step(self, observations, controls, sensor_out=None, ctrl_ctx=None):

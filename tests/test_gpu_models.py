@@ -170,10 +170,10 @@ def test_particle_filter_tracks_oracle(tname, kind, cls, mode):
     assert float((engine.particle_states.cpu() - beliefs[0][0]).abs().max()) < 1e-5
     # Teacher-forced: the engine steps from the belief the oracle held.  Whether a position lands on
     # the other side of a CDF boundary hinges on the last ulp of a log-likelihood, i.e. on the host
-    # CPU's torch kernels as much as on the GPU's.  A log-likelihood error delta moves a CDF boundary
-    # by ~delta against a position spacing of 1 / M, so about delta * M of the indices flip: ~1e-4 of
-    # them in exact-f32 mode, up to ~1e-3 with f16x3 products (delta ~ 1e-6); the bound is 5e-3
-    # (normally none differ), means to 1e-4.  Bit-exactness of K1 itself is test_k1_indices_bit_exact.
+    # CPU's torch kernels as much as on the GPU's: indices are required equal up to 1e-3 of them
+    # (normally all), means to 1e-4.  Bit-exactness of K1 itself is test_k1_indices_bit_exact.
+    # (This test used to fail on some boxes with "f16x3 operand range": a range flag left raised by
+    # an earlier test's deliberately non-PD unscented step -- see conftest._range_flag_hygiene.)
     differ = 0
     for t in range(T):
         engine.particle_states = beliefs[t][0].to(dev).contiguous()
@@ -184,13 +184,12 @@ def test_particle_filter_tracks_oracle(tname, kind, cls, mode):
         scale = max(1.0, float(want[t].abs().max()))
         assert float((est.cpu() - want[t]).abs().max()) / scale < REL_TOL, f"step {t}"
         differ += int((engine.last_resample_indices.cpu().long() != want_idx[t]).sum())
-    assert differ <= 5e-3 * T * N * M, f"{differ} of {T * N * M} resample indices differ"
+    assert differ <= 1e-3 * T * N * M, f"{differ} of {T * N * M} resample indices differ"
 
     # free-running engine, step by step and through forward_loop (observation encoders batched
     # over T*N): identical to each other bit for bit, and -- with these flat random-init
-    # likelihoods, where a flipped ancestor moves an estimate by ~spread / M and the two runs' particle
-    # sets then drift apart -- within 5e-2 (the Monte-Carlo error at M = 1024) of the oracle's free
-    # run (whether a flip happens at all depends on the box's host CPU)
+    # likelihoods, where a flipped ancestor moves an estimate by ~spread / M -- within 1e-2 of the
+    # oracle's free run (whether a flip happens at all depends on the box's host CPU)
     engine.noise = mmf.ReplayNoise([eps0] + eps, us)
     engine.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
     steps = torch.stack([engine(observations={k: v[t].to(dev) for k, v in obs.items()}, controls=ctrl[t].to(dev))
@@ -199,7 +198,7 @@ def test_particle_filter_tracks_oracle(tname, kind, cls, mode):
     engine.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
     loop = engine.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
     assert torch.equal(loop, steps)
-    torch.testing.assert_close(loop.cpu(), torch.stack(want), rtol=0, atol=5e-2)
+    torch.testing.assert_close(loop.cpu(), torch.stack(want), rtol=1e-2, atol=1e-2)
 
     # ... and so does the native step loop (mmf_pf_forward_loop: record_indices off, zero-copy
     # noise blocks), bit for bit against the step-by-step engine path, including the belief
