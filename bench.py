@@ -83,10 +83,13 @@ def pmc_traffic_k4_sequence(n_images: int, nets: int):
     try:
         with open(path) as fh:
             k = json.load(fh)["kernels"]
-        names = (f"stem_conv2a_kernel<false> grid={g[0]}", f"conv2b_conv3_kernel<false> grid={g[1]}",
-                 f"conv4_kernel grid={g[2]}", f"fc_partial_f16x3_kernel grid={g[3]}",
-                 f"fc_tail_kernel<false> grid={g[4]}")
-        return sum(k[n]["hbm_bytes_corrected"] for n in names)
+        want = (("stem_conv2a_kernel<false", g[0]), ("conv2b_conv3_kernel<false", g[1]), ("conv4_kernel", g[2]),
+                ("fc_partial_f16x3_kernel", g[3]), ("fc_tail_kernel<false", g[4]))
+        total = 0.0
+        for prefix, grid in want:
+            hits = [v for name, v in k.items() if name.startswith(prefix) and name.endswith(f"grid={grid}")]
+            total += hits[0]["hbm_bytes_corrected"]
+        return total
     except (OSError, KeyError, ValueError):
         return None
 

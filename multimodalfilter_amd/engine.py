@@ -186,6 +186,14 @@ def check_range(device):
             "filter steps are invalid; set MMF_PRECISION=f32 / engine.set_default_precision('f32')")
 
 
+def clear_range(device):
+    """Forget range reports of earlier work (another filter's failed step, say): a loop's check
+    speaks about its own launches."""
+    flag = _RANGE_FLAGS.get(str(device))
+    if flag is not None:
+        flag.zero_()
+
+
 class PackedParticleNet:
     """One per-particle network (``enc -> join -> res* -> head``, see ``include/mmf.h``)
     packed into MFMA-fragment order on the device.

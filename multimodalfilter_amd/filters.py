@@ -366,6 +366,7 @@ class ParticleFilter(base.Filter):
                     None if meas_all is None else {k: v[sl] for k, v in meas_all.items()}))
             return torch.stack(out, dim=0)
         obs_all = ctrl_all = None
+        engine.clear_range(self.particle_states.device if self.particle_states is not None else "cpu")
         with torch.no_grad():
             if hasattr(self.measurement_model, "forward_encoded"):
                 obs_all = self.measurement_model.encode_observations(tree_map(observations, flat))
