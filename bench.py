@@ -326,6 +326,41 @@ def precision_errors(wl, engine_filter, traj, batch, particles, chunk=64, raw_dy
     return out
 
 
+def image_encoder_precision_errors(wl, engine_filter, traj, n_images=512):
+    """Arithmetic error of every image encoder of the filter (K4) in each mode against an fp64
+    evaluation of the same stack (the oracle's torch module in double precision on the GPU; checker
+    only) on ``n_images`` of the workload's images; relative to max(1, max |fp64 feature|)."""
+    from multimodalfilter_amd import engine
+    from oracle import models as om
+
+    dev = next(engine_filter.parameters()).device
+    images = traj["image"].reshape((-1,) + tuple(traj["image"].shape[-2:]))[:n_images].contiguous()
+    oracle = om.build(wl["cls"])
+    oracle.load_state_dict({k: v.detach().cpu() for k, v in engine_filter.state_dict().items()})
+    oracle = oracle.double().to(dev).eval()
+    stacks_o = {n: m for n, m in oracle.named_modules() if n.endswith("observation_image_layers")}
+    stacks_e = {n: m for n, m in engine_filter.named_modules() if n.endswith("observation_image_layers")}
+    assert stacks_o.keys() == stacks_e.keys() and stacks_e
+    out = {"f32": {}, "f16x3": {}}
+    old = engine.DEFAULT_PRECISION
+    try:
+        with torch.no_grad():
+            want = {n: m(images[:, None].double()) for n, m in stacks_o.items()}
+            for mode in ("f32", "f16x3"):
+                engine.set_default_precision(mode)
+                for n, m in stacks_e.items():
+                    got = engine.encode_images([m], images)[0]
+                    e = (got.double() - want[n]).abs()
+                    scale = max(1.0, float(want[n].abs().max()))
+                    out[mode][n] = {"max_rel": float(e.max()) / scale, "rms_rel": float(e.pow(2).mean().sqrt()) / scale}
+    finally:
+        engine.set_default_precision(old)
+    out["f16x3_over_f32_max_err"] = {n: out["f16x3"][n]["max_rel"] / max(out["f32"][n]["max_rel"], 1e-12) for n in stacks_e}
+    out["images"] = int(images.shape[0])
+    out["reference"] = "fp64 evaluation (oracle modules in double precision on the device) of the same fp32 images"
+    return out
+
+
 def cpu_baseline_ekf(wl, engine_filter, state_dim, cores, sample_batch=256, sample_steps=6, warm=1):
     from multimodalfilter_amd import evaluation, synthetic
     from oracle import models as om
@@ -544,9 +579,11 @@ def main():
         "unit": "particle-steps/s" if wl["kind"] == "pf" else "trajectory-steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-        "dtype": "f32" if precision == "f32" or wl["kind"] != "pf" else
-                 "f32 via f16x3 (operands split into 2 f16 halves exact to 2^-22, 3 f16 MFMA products "
-                 "per product, f32 accumulate)",
+        "dtype": "f32" if precision == "f32" else
+                 ("f32 via f16x3 (operands split into 2 f16 halves exact to 2^-22, 3 f16 MFMA products "
+                  "per product, f32 accumulate)" if wl["kind"] == "pf" else
+                  "f32; image encoders f32 via f16x3 (operands split into 2 f16 halves exact to 2^-22, 3 f16 MFMA "
+                  "products per product, f32 accumulate)"),
         "data": "synthetic",
         "config": {"workload": workload_desc(wl, B, M, total_batch, world, scaling), "filter": wl["cls"],
                    "batch_per_gpu": B, "particles": M,
@@ -639,6 +676,20 @@ def main():
             out["dtype"] = ("f32-equivalent via f16x3: fp32 operands split into two round-to-nearest f16 halves "
                             "(x = hi + lo to 2^-22), 3 f16 MFMA products per product, f32 accumulate; error vs fp64 "
                             f"within {worst:.2f}x of the exact-f32-product mode on every network (precision_vs_fp64)")
+
+    if wl["kind"] != "pf" and not args.no_precision_study:
+        # the EKF's only non-f32 arithmetic is the image encoders' (K4 follows the engine's default mode)
+        study = image_encoder_precision_errors(wl, f, traj)
+        out["precision_vs_fp64"] = study
+        worst = max(study["f16x3_over_f32_max_err"].values())
+        out["precision_vs_fp64"]["rule"] = (
+            "f16x3 image encoders stand iff their max error against fp64 is <= 2x the f32-MFMA mode's on every "
+            f"encoder; worst ratio here {worst:.2f} -> " + ("holds" if worst <= 2.0 else "FAILS: run with MMF_PRECISION=f32"))
+        if precision != "f32":
+            out["dtype"] = ("f32 (Kalman algebra, Jacobians, per-trajectory networks: exact fp32 products); image "
+                            "encoders f32-equivalent via f16x3 (operands split into two round-to-nearest f16 halves, 3 f16 "
+                            f"MFMA products per product, f32 accumulate; error vs fp64 within {worst:.2f}x of the "
+                            "exact-f32-product mode on every encoder, precision_vs_fp64)")
 
     if world == 1 and not args.no_cpu_baseline:
         cores = min(CPU_THREADS, os.cpu_count() or 1)

@@ -279,6 +279,8 @@ int mmf_pack_image_encoder(const MmfImageEncoderDesc* desc /* host */, float* pa
  *             persistent kernels with the activations in LDS (csrc/image_encoder_fused.inc).
  *             MMF_PREC_BF16: the same two fused kernels with single bf16 products (94 % of the
  *             MACs); conv 16->8 and the linear tail stay f16x3.
+  * f16x3 / bf16 modes: the 3x3 convolution and linear weights are held as f16 fragments of 256 w
+ * (the split's "lo" half stays out of the f16 subnormals); |w| must stay below 255.
  */
 int mmf_image_encoder(const float* const* packed, int n_nets, const float* images, float* feat,
                       void* workspace, int32_t* range_flag, int precision, int variant, int N,

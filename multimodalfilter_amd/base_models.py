@@ -21,7 +21,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import _abi, base, filters
+from . import _abi, base, engine, filters
 from .engine import call_with_image_feat, encode_observation_images, require_device, use_autograd
 from .utils import tree_index, tree_leading_shape, tree_map
 
@@ -366,6 +366,7 @@ class _FusedKalmanFilters(base.Filter, _EnabledModels):
             f._belief_mean, f._belief_covariance = mu[k], Sigma[k]
         return est, (Sigma_f if fusion else None)
 
+    @engine.checked_loop
     def forward_loop(self, *, observations, controls):
         """Sensors, fusion weights and control encoders do not depend on the belief: they are
         evaluated ahead of the recursion for all ``T*N`` rows at once."""

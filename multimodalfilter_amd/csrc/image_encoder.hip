@@ -38,6 +38,12 @@ constexpr int kWP = 40;          // padded LDS row: 4 | 32 pixels | 4
 constexpr int kConvThreads = 512;
 constexpr int kMaxNets = 4;
 constexpr int kFeat = 64;
+// f16x3 weight fragments hold w * kWScale: a weight of 0.03 has its residual (2^-11 of it) deep in the
+// f16 subnormals, where the "lo" half keeps 3-4 bits instead of 11; scaled by 2^8 both halves are normal
+// for |w| >= 5e-4 and the split is exact to 2^-22 again.  Biases enter the accumulators scaled likewise
+// and every epilogue multiplies by 1 / kWScale (powers of two: exact).  Measured on the EKF's encoders:
+// max error against fp64 5.4e-7 -> see DESIGN.md K4 (the exact-f32-product mode: 1.6e-7).
+constexpr float kWScale = 256.0f, kWInv = 1.0f / 256.0f;
 constexpr int kFcK = 8 * kImg * kImg;  // 8192
 constexpr int kFcSplit = 16;
 
@@ -173,7 +179,7 @@ __global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ o
         const int he = 2 * (q0 - L.g4) + z;
         const int i = he & 7, lane = (he >> 3) & 63, part = (he >> 9) & 1, pair = he >> 10;
         const int co = lane & 15, q = lane >> 4, tap = 2 * pair + (q >> 1);
-        const float w = co < cout4 && tap < 9 ? d.conv_w[4][(co * 16 + 8 * (q & 1) + i) * 9 + tap] : 0.f;
+        const float w = kWScale * (co < cout4 && tap < 9 ? d.conv_w[4][(co * 16 + 8 * (q & 1) + i) * 9 + tap] : 0.f);
         const __half hi = __float2half_rn(w);
         hb[z] = part ? __half_as_ushort(__float2half_rn(w - __half2float(hi))) : __half_as_ushort(hi);
       }
@@ -215,7 +221,7 @@ __global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ o
           const int t = 16 * blk + 8 * (lane >> 5) + i;
           w = t < 25 ? d.conv_w[0][(lane & 31) * 25 + t] : 0.f;
         } else {
-          w = d.conv_w[3][((lane & 15) * 32 + 8 * (lane >> 4) + i) * 9 + blk];
+          w = kWScale * d.conv_w[3][((lane & 15) * 32 + 8 * (lane >> 4) + i) * 9 + blk];
         }
         const __half hi = __float2half_rn(w);
         hb[z] = part ? __half_as_ushort(__float2half_rn(w - __half2float(hi))) : __half_as_ushort(hi);
@@ -229,7 +235,7 @@ __global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ o
         const int i = he & 7, lane = (he >> 3) & 63, part = (he >> 9) & 1, tile = (he >> 10) & 1, rest = he >> 11;
         const int ks = rest % (kFcK / kFcSplit / 16), sp = rest / (kFcK / kFcSplit / 16);
         const int o = 32 * tile + (lane & 31), k = sp * (kFcK / kFcSplit) + 16 * ks + 8 * (lane >> 5) + i;
-        const float w = fc_in == kFcK ? d.fc_w[static_cast<size_t>(o) * kFcK + k] : 0.f;
+        const float w = kWScale * (fc_in == kFcK ? d.fc_w[static_cast<size_t>(o) * kFcK + k] : 0.f);
         const __half hi = __float2half_rn(w);
         hb[z] = part ? __half_as_ushort(__float2half_rn(w - __half2float(hi))) : __half_as_ushort(hi);
       }
@@ -248,7 +254,7 @@ __global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ o
         const int i = he & 7, lane = (he >> 3) & 63, part = (he >> 9) & 1, rest = he >> 10;
         const int kc = rest % KC, tap = rest / KC;
         const int co = lane & 31, ci = 16 * kc + 8 * (lane >> 5) + i;
-        const float w = co < cout ? W[(co * cin + ci) * 9 + tap] : 0.f;
+        const float w = kWScale * (co < cout ? W[(co * cin + ci) * 9 + tap] : 0.f);
         const __half hi = __float2half_rn(w);
         hb[z] = part ? __half_as_ushort(__float2half_rn(w - __half2float(hi))) : __half_as_ushort(hi);
       }
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(BAND * 32) void conv_f16x3_kernel(ConvHArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int ch = (r & 3) + 8 * (r >> 2) + 4 * h;
-    bias_r[r] = ch < COUT ? blob[a.boff + ch] : 0.f;
+    bias_r[r] = ch < COUT ? kWScale * blob[a.boff + ch] : 0.f;
   }
 
   int band = blockIdx.x;
@@ -556,7 +562,7 @@ __global__ __launch_bounds__(BAND * 32) void conv_f16x3_kernel(ConvHArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ch = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const float b = SKIP ? (ch < COUT ? blob[a.boff + ch] : 0.f) : bias_r[r];  // skip variant: fewer live registers
+      const float b = SKIP ? (ch < COUT ? kWScale * blob[a.boff + ch] : 0.f) : bias_r[r];  // skip variant: fewer live registers
       acc[0][r] = b;
       acc[1][r] = b;
       if (SKIP) {  // issued now, consumed after the MFMAs: the load latency hides under them
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(BAND * 32) void conv_f16x3_kernel(ConvHArgs a) {
         const int ch = (r & 3) + 8 * (r >> 2) + 4 * h;
         if (ch < COUT) {
           const size_t o = obase + (static_cast<size_t>(ch) * kImg + (y0 + r0 + rr)) * kImg + j;
-          float v = acc[rr][r];
+          float v = acc[rr][r] * kWInv;
           if (SKIP) v += skipv[rr][r];
           if (RELU) v = fmaxf(v, 0.f);
           a.out[o] = v;
@@ -717,8 +723,8 @@ __global__ __launch_bounds__(256) void fc_partial_f16x3_kernel(FcArgs a) {
     float* p = a.partial + ((static_cast<size_t>(net) * kFcSplit + split) * a.N + img0 + j) * kFeat + 4 * h;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 v0 = {acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]};
-      const f32x4 v1 = {acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]};
+      const f32x4 v0 = {acc0[4 * g] * kWInv, acc0[4 * g + 1] * kWInv, acc0[4 * g + 2] * kWInv, acc0[4 * g + 3] * kWInv};
+      const f32x4 v1 = {acc1[4 * g] * kWInv, acc1[4 * g + 1] * kWInv, acc1[4 * g + 2] * kWInv, acc1[4 * g + 3] * kWInv};
       *reinterpret_cast<f32x4*>(p + 8 * g) = v0;
       *reinterpret_cast<f32x4*>(p + 32 + 8 * g) = v1;
     }

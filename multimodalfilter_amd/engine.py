@@ -186,6 +186,28 @@ def check_range(device):
             "filter steps are invalid; set MMF_PRECISION=f32 / engine.set_default_precision('f32')")
 
 
+def checked_loop(fn):
+    """Decorator for ``forward_loop`` methods: the f16x3 range flag (raised by K2 / K4 launches whose
+    operands left the f16 range) is cleared on entry and checked on the way out, so a loop reports
+    its own launches -- one 4-byte device->host read per loop."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        dev = None
+        for p in self.parameters():
+            dev = p.device
+            break
+        if dev is None or dev.type != "cuda":
+            return fn(self, *args, **kwargs)
+        clear_range(dev)
+        out = fn(self, *args, **kwargs)
+        check_range(dev)
+        return out
+
+    return wrapper
+
+
 def clear_range(device):
     """Forget range reports of earlier work (another filter's failed step, say): a loop's check
     speaks about its own launches."""

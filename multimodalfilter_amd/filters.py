@@ -515,6 +515,7 @@ class VirtualSensorExtendedKalmanFilter(base.Filter):
         self._belief_mean, self._belief_covariance = mu[0], Sigma[0]
         return est
 
+    @engine.checked_loop
     def forward_loop(self, *, observations, controls):
         if use_autograd(self):
             return base.Filter.forward_loop(self, observations=observations, controls=controls)
@@ -640,6 +641,7 @@ class VirtualSensorUnscentedKalmanFilter(VirtualSensorExtendedKalmanFilter):
     def _native_loop(self, observations, ctrl_all, T, N, flat):
         return None  # the step is sigma points -> K2 -> moments -> K3: driven from Python, sensors batched over T*N
 
+    @engine.checked_loop
     def forward_loop(self, *, observations, controls):
         T, N = tree_leading_shape(controls)[:2]
         flat = lambda t: t.reshape((T * N,) + tuple(t.shape[2:]))
