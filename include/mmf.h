@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 20
+#define MMF_ABI_VERSION 21
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -279,8 +279,8 @@ int mmf_pack_image_encoder(const MmfImageEncoderDesc* desc /* host */, float* pa
  *             persistent kernels with the activations in LDS (csrc/image_encoder_fused.inc).
  *             MMF_PREC_BF16: the same two fused kernels with single bf16 products (94 % of the
  *             MACs); conv 16->8 and the linear tail stay f16x3.
-  * f16x3 / bf16 modes: the 3x3 convolution and linear weights are held as f16 fragments of 256 w
- * (the split's "lo" half stays out of the f16 subnormals); |w| must stay below 255.
+  * f16x3 products (the default mode, and conv 16->8 + the linear layer of the bf16 mode): weights are
+ * held as f16 fragments of 256 w (the split's "lo" half stays out of the f16 subnormals); |w| < 255.
  */
 int mmf_image_encoder(const float* const* packed, int n_nets, const float* images, float* feat,
                       void* workspace, int32_t* range_flag, int precision, int variant, int N,
@@ -291,7 +291,12 @@ int mmf_image_encoder(const float* const* packed, int n_nets, const float* image
  * encoder per call, exact fp32, MMF_ENCODER_DEFAULT only.
  *  mmf_image_convs_train_forward   images (N,32,32) -> a1 (N,32,32,32) stem, h (N,32,..) ResConv hidden,
  *                                  a2 (N,32,..) ResConv out, a3 (N,16,..), a4 (N,8,32,32) = input of the
- *                                  flatten + linear; `packed` = mmf_pack_image_encoder's blob
+ *                                  flatten + linear; `packed` = mmf_pack_image_encoder's blob.  precision
+ *                                  MMF_PREC_F32: exact fp32 products; MMF_PREC_BF16 (BASELINE config 5's
+ *                                  "bf16 measurement CNN"): the two 32->32 convolutions with bf16 products,
+ *                                  conv 32->16 / 16->8 f16x3, stem fp32; MMF_PREC_F16X3: f16x3 throughout.
+ *                                  The backward differentiates the exact network through the saved
+ *                                  (rounded-forward) activations
  *  mmf_image_convs_train_backward  g_a4 -> pre-activation gradients g3 (N,16,..), g2, gh, g1 (N,32,..):
  *                                  the forward conv kernel on transposed + flipped weights
  *                                  (`packed_bwd` = mmf_pack_image_convs_backward), ReLU masks fused
@@ -304,7 +309,8 @@ int mmf_image_encoder(const float* const* packed, int n_nets, const float* image
 size_t mmf_image_convs_backward_floats(void);
 int mmf_pack_image_convs_backward(const MmfImageEncoderDesc* desc, float* packed_bwd, void* stream);
 int mmf_image_convs_train_forward(const float* packed, const float* images, float* a1, float* h,
-                                  float* a2, float* a3, float* a4, int N, void* stream);
+                                  float* a2, float* a3, float* a4, int32_t* range_flag, int precision,
+                                  int N, void* stream);
 int mmf_image_convs_train_backward(const float* packed_bwd, const float* a1, const float* h,
                                    const float* a2, const float* a3, const float* g_a4, float* g1,
                                    float* gh, float* g2, float* g3, int N, void* stream);

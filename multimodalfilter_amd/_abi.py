@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 20
+ABI_VERSION = 21
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
@@ -114,7 +114,7 @@ SIGNATURES = {
     "mmf_pack_image_encoder": (c_int, [POINTER(MmfImageEncoderDesc), _FP, c_void_p]),
     "mmf_image_convs_backward_floats": (c_size_t, []),
     "mmf_pack_image_convs_backward": (c_int, [POINTER(MmfImageEncoderDesc), _FP, c_void_p]),
-    "mmf_image_convs_train_forward": (c_int, [_FP] * 7 + [c_int, c_void_p]),
+    "mmf_image_convs_train_forward": (c_int, [_FP] * 8 + [c_int, c_int, c_void_p]),
     "mmf_image_convs_train_backward": (c_int, [_FP] * 10 + [c_int, c_void_p]),
     "mmf_conv_weight_grads": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_image_encoder": (c_int, [POINTER(c_void_p), c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
@@ -242,9 +242,10 @@ def ekf_step(A, mu_pred, q_tril, z, r_tril, fuse_w, mu, Sigma, mu_f, Sigma_f, fu
                                    N, d, K, fusion, feedback, stream_of(mu_pred)), "mmf_ekf_step")
 
 
-def image_convs_train_forward(packed, images, a1, h, a2, a3, a4):
+def image_convs_train_forward(packed, images, a1, h, a2, a3, a4, range_flag=None, precision: int = PREC_F32):
     with _on(images):
         _check(load().mmf_image_convs_train_forward(ptr(packed), ptr(images), ptr(a1), ptr(h), ptr(a2), ptr(a3), ptr(a4),
+                                                    ptr(range_flag, dtype=torch.int32), precision,
                                                     images.shape[0], stream_of(images)), "mmf_image_convs_train_forward")
 
 

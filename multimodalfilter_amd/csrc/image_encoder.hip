@@ -426,7 +426,10 @@ __device__ long long g_phase[4][8];  // [3x3 layer][phase]
 // the other stages / stores, which a single lock-stepped workgroup per CU cannot overlap
 // (measured per 16-row band, one workgroup per CU: stage 3.6 us + MFMA 4.0 us + store 2.2 us in
 // series; scripts/ubench/k4_phases.hip).
-template <int CIN, int COUT, bool RELU, bool SKIP, int BAND>
+// BF: one bf16 product per MAC (operands rounded to bf16, fp32 accumulation, weights from the bf16
+// twins in the same fragment order): the training forward of MMF_PREC_BF16, which needs every
+// layer's activations in HBM anyway.
+template <int CIN, int COUT, bool RELU, bool SKIP, int BAND, bool BF = false>
 __global__ __launch_bounds__(BAND * 32) void conv_f16x3_kernel(ConvHArgs a) {
   constexpr int THREADS = BAND * 32;
   constexpr int RB = BAND + 2;
@@ -513,17 +516,23 @@ __global__ __launch_bounds__(BAND * 32) void conv_f16x3_kernel(ConvHArgs a) {
             const float x0 = inside ? pf[it][2 * p][px] : 0.f, x1 = inside ? pf[it][2 * p + 1][px] : 0.f;
             amax = fmaxf(amax, fmaxf(fabsf(x0), fabsf(x1)));
             const f32x2 xs = {x0, x1};
-            const half2v hh = __builtin_convertvector(xs, half2v);  // round to nearest even
-            const f32x2 hf = {static_cast<float>(hh[0]), static_cast<float>(hh[1])};
-            const f32x2 r = xs - hf;
-            const half2v ll = __builtin_convertvector(r, half2v);
-            hv[p] = __builtin_bit_cast(unsigned, hh);
-            lv[p] = __builtin_bit_cast(unsigned, ll);
+            if constexpr (BF) {
+              using bf2 = __attribute__((ext_vector_type(2))) __bf16;
+              hv[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(xs, bf2));
+              lv[p] = 0u;
+            } else {
+              const half2v hh = __builtin_convertvector(xs, half2v);  // round to nearest even
+              const f32x2 hf = {static_cast<float>(hh[0]), static_cast<float>(hh[1])};
+              const f32x2 r = xs - hf;
+              const half2v ll = __builtin_convertvector(r, half2v);
+              hv[p] = __builtin_bit_cast(unsigned, hh);
+              lv[p] = __builtin_bit_cast(unsigned, ll);
+            }
           }
           const int cc = 4 * it_xg[it] + px + 1;
           const int off = (it_rr[it] * kWPh + cc) * PIX + 16 * (it_cg[it] ^ swz<CIN>(cc));
           *reinterpret_cast<u32x4*>(tile_hi + off) = hv;
-          *reinterpret_cast<u32x4*>(tile_lo + off) = lv;
+          if constexpr (!BF) *reinterpret_cast<u32x4*>(tile_lo + off) = lv;
         }
       }
     }
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(BAND * 32) void conv_f16x3_kernel(ConvHArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int ch = (r & 3) + 8 * (r >> 2) + 4 * h;
-    bias_r[r] = ch < COUT ? kWScale * blob[a.boff + ch] : 0.f;
+    bias_r[r] = ch < COUT ? (BF ? 1.0f : kWScale) * blob[a.boff + ch] : 0.f;
   }
 
   int band = blockIdx.x;
@@ -562,7 +571,7 @@ __global__ __launch_bounds__(BAND * 32) void conv_f16x3_kernel(ConvHArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ch = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const float b = SKIP ? (ch < COUT ? kWScale * blob[a.boff + ch] : 0.f) : bias_r[r];  // skip variant: fewer live registers
+      const float b = SKIP ? (ch < COUT ? (BF ? 1.0f : kWScale) * blob[a.boff + ch] : 0.f) : bias_r[r];  // skip variant: fewer live registers
       acc[0][r] = b;
       acc[1][r] = b;
       if (SKIP) {  // issued now, consumed after the MFMAs: the load latency hides under them
@@ -586,10 +595,15 @@ __global__ __launch_bounds__(BAND * 32) void conv_f16x3_kernel(ConvHArgs a) {
         for (int rr = 0; rr < 2; ++rr) {
           const int off = ((r0 + rr + ky) * kWPh + col) * PIX + 16 * chunk;
           const half8 bhi = *reinterpret_cast<const half8*>(tile_hi + off);
-          const half8 blo = *reinterpret_cast<const half8*>(tile_lo + off);
-          acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[rr], 0, 0, 0);
-          acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc[rr], 0, 0, 0);
-          acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc[rr], 0, 0, 0);
+          if constexpr (BF) {
+            using bf8 = __attribute__((ext_vector_type(8))) __bf16;
+            acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, ahi), __builtin_bit_cast(bf8, bhi), acc[rr], 0, 0, 0);
+          } else {
+            const half8 blo = *reinterpret_cast<const half8*>(tile_lo + off);
+            acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[rr], 0, 0, 0);
+            acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc[rr], 0, 0, 0);
+            acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc[rr], 0, 0, 0);
+          }
         }
       }
     }
@@ -602,7 +616,7 @@ __global__ __launch_bounds__(BAND * 32) void conv_f16x3_kernel(ConvHArgs a) {
         const int ch = (r & 3) + 8 * (r >> 2) + 4 * h;
         if (ch < COUT) {
           const size_t o = obase + (static_cast<size_t>(ch) * kImg + (y0 + r0 + rr)) * kImg + j;
-          float v = acc[rr][r] * kWInv;
+          float v = acc[rr][r] * (BF ? 1.0f : kWInv);
           if (SKIP) v += skipv[rr][r];
           if (RELU) v = fmaxf(v, 0.f);
           a.out[o] = v;
@@ -610,16 +624,16 @@ __global__ __launch_bounds__(BAND * 32) void conv_f16x3_kernel(ConvHArgs a) {
       }
     K4_CLOCK(5);
   }
-  if (a.range_flag != nullptr && !(amax < 65504.0f)) atomicOr(a.range_flag, 1);
+  if (!BF && a.range_flag != nullptr && !(amax < 65504.0f)) atomicOr(a.range_flag, 1);
 }
 
-template <int CIN, int COUT, bool RELU, bool SKIP>
+template <int CIN, int COUT, bool RELU, bool SKIP, bool BF = false>
 int launch_conv_h(const ConvHArgs& a, int nets, hipStream_t s) {
   constexpr int BAND = 8;
   constexpr size_t lds = 2 * (BAND + 2) * kWPh * CIN * 2 + 9 * (CIN / 16) * 2 * 64 * 16;
   constexpr int per_cu = static_cast<int>(160 * 1024 / lds) < 2 ? 1 : 2;  // co-resident workgroups
   static_assert(lds <= 160 * 1024, "f16 planes + weights must fit LDS");
-  auto k = conv_f16x3_kernel<CIN, COUT, RELU, SKIP, BAND>;
+  auto k = conv_f16x3_kernel<CIN, COUT, RELU, SKIP, BAND, BF>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   if (e != hipSuccess) return static_cast<int>(e);
@@ -1046,8 +1060,10 @@ extern "C" int mmf_pack_image_convs_backward(const MmfImageEncoderDesc* d, float
 }
 
 extern "C" int mmf_image_convs_train_forward(const float* packed, const float* images, float* a1, float* h,
-                                             float* a2, float* a3, float* a4, int N, void* stream) {
+                                             float* a2, float* a3, float* a4, int32_t* range_flag, int precision,
+                                             int N, void* stream) {
   if (!packed || !images || !a1 || !h || !a2 || !a3 || !a4 || N < 0) return MMF_EINVAL;
+  if (precision != MMF_PREC_F32 && precision != MMF_PREC_F16X3 && precision != MMF_PREC_BF16) return MMF_EINVAL;
   if (N == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   constexpr Layout L = layout();
@@ -1055,8 +1071,25 @@ extern "C" int mmf_image_convs_train_forward(const float* packed, const float* i
   c.packed[0] = packed;
   c.N = N;
   int rc;
+  // the 5x5 stem (3 % of the MACs, one input channel): exact fp32 in every mode
   c.in = images; c.in_net_stride = 0; c.out = a1; c.woff = L.w1; c.boff = L.b1;
   if ((rc = launch_conv<1, 32, 5, true, false>(c, 1, s))) return rc;
+  if (precision != MMF_PREC_F32) {
+    // per-layer MFMA kernels with the activations in HBM (what the backward reads): the two 32->32
+    // convolutions (72 % of the MACs) with bf16 or f16x3 products, conv 32->16 and 16->8 f16x3
+    ConvHArgs hc{};
+    hc.packed[0] = packed;
+    hc.N = N; hc.range_flag = range_flag;
+    const bool bf = precision == MMF_PREC_BF16;
+    hc.in = a1; hc.skip = nullptr; hc.out = h; hc.hoff = bf ? L.q2a : L.h2a; hc.boff = L.b2a;
+    if ((rc = bf ? launch_conv_h<32, 32, true, false, true>(hc, 1, s) : launch_conv_h<32, 32, true, false>(hc, 1, s))) return rc;
+    hc.in = h; hc.skip = a1; hc.out = a2; hc.hoff = bf ? L.q2b : L.h2b; hc.boff = L.b2b;
+    if ((rc = bf ? launch_conv_h<32, 32, true, true, true>(hc, 1, s) : launch_conv_h<32, 32, true, true>(hc, 1, s))) return rc;
+    hc.in = a2; hc.skip = nullptr; hc.out = a3; hc.hoff = L.h3; hc.boff = L.b3;
+    if ((rc = launch_conv_h<32, 16, true, false>(hc, 1, s))) return rc;
+    hc.in = a3; hc.out = a4; hc.hoff = L.h4; hc.boff = L.b4;
+    return launch_conv_h<16, 8, false, false>(hc, 1, s);
+  }
   c.in = a1; c.out = h; c.woff = L.w2a; c.boff = L.b2a;
   if ((rc = launch_conv<32, 32, 3, true, false>(c, 1, s))) return rc;
   c.in = h; c.skip = a1; c.out = a2; c.woff = L.w2b; c.boff = L.b2b;

@@ -607,7 +607,8 @@ class PackedImageEncoder:
 class ImageConvsFunction(torch.autograd.Function):
     """K6 for the image encoder: the convolution stack of a default ``observation_image_layers``
     (``door_models/layers.py:43-58``: stem, ResConv, 32->16, 16->8) forward with every activation kept
-    (``mmf_image_convs_train_forward``), backward data path on transposed + flipped weights with the
+    (``mmf_image_convs_train_forward``: exact fp32 products, or -- ``set_image_encoder_precision("bf16")``,
+    BASELINE config 5 -- bf16 products in the two 32->32 convolutions), backward data path on transposed + flipped weights with the
     ReLU masks fused (``mmf_image_convs_train_backward``) and the 3x3 weight gradients as split-K MFMA
     correlations (``mmf_conv_weight_grads``): no MIOpen kernel in a training step.  Exact fp32.
     ``apply(seq, images (N, 32, 32), *conv weights and biases) -> (N, 8, 32, 32)``; the flatten + linear
@@ -623,7 +624,11 @@ class ImageConvsFunction(torch.autograd.Function):
         N = img.shape[0]
         mk = lambda c: torch.empty((N, c, 32, 32), dtype=torch.float32, device=img.device)
         a1, h, a2, a3, a4 = mk(32), mk(32), mk(32), mk(16), mk(8)
-        _abi.image_convs_train_forward(blob, img, a1, h, a2, a3, a4)
+        # exact fp32 unless the image-encoder precision was set explicitly (BASELINE config 5:
+        # set_image_encoder_precision("bf16")); the engine-wide default does not reach training
+        prec = _abi.IMAGE_PRECISIONS[IMAGE_ENCODER_PRECISION] if IMAGE_ENCODER_PRECISION else _abi.PREC_F32
+        _abi.image_convs_train_forward(blob, img, a1, h, a2, a3, a4,
+                                       range_flag(img.device) if prec != _abi.PREC_F32 else None, prec)
         ctx.seq = seq
         ctx.save_for_backward(img, a1, h, a2, a3)
         return a4

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--model", default="PushUnimodalParticleFilter")
     ap.add_argument("--backends", default="hip,autograd")
+    ap.add_argument("--cnn-precision", default=None, choices=[None, "f32", "f16x3", "bf16"],
+                    help="image-encoder training forward (hip backend): default exact fp32; bf16 = BASELINE config 5")
     args = ap.parse_args()
 
     import multimodalfilter_amd as mmf
@@ -41,6 +43,7 @@ def main():
         f = mmf.model_types(task)[args.model]().to(dev).train()
         f.num_particles = M
         engine.set_training_backend(backend)
+        engine.set_image_encoder_precision(args.cnn_precision if backend == "hip" else None)
         opt = torch.optim.SGD(f.parameters(), lr=1e-4)
         f.noise = mmf.NoiseSource(seed=5)
         times, losses = [], []
@@ -52,12 +55,14 @@ def main():
             torch.cuda.synchronize()
             times.append(time.perf_counter() - t0)
         best = min(times[1:])
-        print(json.dumps({"backend": backend, "model": args.model, "batch": N, "particles": M, "length": L,
+        print(json.dumps({"backend": backend, "cnn_forward": (args.cnn_precision or "f32") if backend == "hip" else "torch",
+                          "model": args.model, "batch": N, "particles": M, "length": L,
                           "ms_per_train_step": 1e3 * best,
                           "particle_steps_per_s_fwd_bwd": N * M * (L - 1) / best,
                           "peak_memory_GB": torch.cuda.max_memory_allocated() / 2 ** 30,
                           "loss_first_last": [losses[0], losses[-1]]}), flush=True)
         engine.set_training_backend(None)
+        engine.set_image_encoder_precision(None)
         del f, opt
         torch.cuda.empty_cache()
 

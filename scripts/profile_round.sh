@@ -31,4 +31,6 @@ MMF_PRECISION=f32 python -m pytest tests -m gpu -q 2>&1 | grep -E '^E  |^FAILED|
 python -m pytest tests -m gpu -q 2>&1 | grep -E '^E  |^FAILED|passed|failed' | tail -20 > $OUT/pytest_gpu.txt
 # training step (K6 vs torch autograd), SURVEY 8d config C5 shape scaled to N*M = 2^18 per step
 python scripts/bench_train.py > $OUT/bench_train_push_unimodal_pf.json 2>> $OUT/bench.err
+# ... and config C5 as specified: bf16 measurement CNN in the training forward
+python scripts/bench_train.py --backends hip --cnn-precision bf16 >> $OUT/bench_train_push_unimodal_pf.json 2>> $OUT/bench.err
 find $OUT -name "*.csv" | head -30

@@ -358,6 +358,58 @@ def test_training_step_at_config_c5_particle_count():
         engine.set_training_backend(None)
 
 
+@pytest.mark.parametrize("precision,loss_tol,grad_tol", [("bf16", 5e-3, 5e-2), ("f16x3", 1e-5, 1e-3)])
+def test_config_c5_training_step_with_reduced_precision_cnn(precision, loss_tol, grad_tol):
+    """BASELINE config 5 as specified, on one GPU: push unimodal PF, 8,192 particles, train mode,
+    **bf16 measurement CNN on MFMA**, forward + backward + optimiser step.  The image encoder's
+    training forward runs its two 32->32 convolutions with bf16 products
+    (``set_image_encoder_precision("bf16")`` -> ``mmf_image_convs_train_forward(MMF_PREC_BF16)``), the
+    backward differentiates through the saved activations in fp32.  Against the exact-fp32 forward on
+    the same weights and noise: loss within 5e-3, every gradient within 5e-2 of its tensor's largest
+    entry (a reduced-precision mode: stated tolerance); the f16x3 forward is held to 1e-5 / 1e-3."""
+    import copy
+
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine, synthetic, train
+
+    dev = torch.device("cuda:0")
+    d, L, N, M = 2, 4, 4, 8192
+    batch = {k: v.to(dev) for k, v in synthetic.make_trajectories(state_dim=d, T=L - 1, N=N, seed=5).items()}
+    cov = torch.eye(d, device=dev) * 0.1
+    torch.manual_seed(2)
+    f = mmf.push_models.PushUnimodalParticleFilter().to(dev).train()
+    f.num_particles = M
+    g = copy.deepcopy(f)
+    eps_init = torch.randn((N, d))
+    noise = lambda: mmf.ReplayNoise([eps_init], [])
+    calls = []
+    real = mmf._abi.image_convs_train_forward
+    try:
+        engine.set_training_backend("hip")
+        loss_ref = train.filter_loss(g, batch, initial_covariance=cov, noise=noise())
+        loss_ref.backward()
+        engine.set_image_encoder_precision(precision)
+        mmf._abi.image_convs_train_forward = lambda *a: (calls.append(a[-1]), real(*a))[1]
+        loss = train.filter_loss(f, batch, initial_covariance=cov, noise=noise())
+        loss.backward()
+        assert calls and all(c == mmf._abi.IMAGE_PRECISIONS[precision] for c in calls)
+        assert abs(float(loss) - float(loss_ref)) < loss_tol * max(1.0, abs(float(loss_ref)))
+        assert precision == "f16x3" or float(loss) != float(loss_ref)  # bf16 really ran
+        checked = 0
+        for (n, p), q in zip(f.named_parameters(), g.parameters()):
+            if q.grad is None or float(q.grad.abs().max()) == 0.0:
+                continue
+            assert float((p.grad - q.grad).abs().max()) / float(q.grad.abs().max()) < grad_tol, n
+            checked += 1
+        assert checked > 20
+        opt = torch.optim.SGD(f.parameters(), lr=1e-3)
+        assert train.train_filter_step(f, batch, opt, initial_covariance=cov, noise=noise()) == pytest.approx(float(loss), rel=0.2)
+    finally:
+        mmf._abi.image_convs_train_forward = real
+        engine.set_image_encoder_precision(None)
+        engine.set_training_backend(None)
+
+
 @pytest.mark.parametrize("N,M,d", [(1, 1, 3), (4, 30, 3), (3, 1000, 2), (2, 8192, 3)])
 def test_k6_reweight_estimate_function_matches_autograd(N, M, d):
     """K6 (K1 no-resample path): estimate, normalised log-weights and the gradients w.r.t.
