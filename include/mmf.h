@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 21
+#define MMF_ABI_VERSION 22
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -398,9 +398,12 @@ typedef struct MmfTrajInstr {
  *  weights  device blob the instructions index
  *  io       HOST array of MMF_TRAJ_MAX_IO device pointers (inputs and outputs; unused = null)
  *  R        rows
+ *  n_slots  LDS vector slots the program uses (1 + its largest slot index, <= MMF_TRAJ_SLOTS)
+ *  vec_width  64 when no vector of the program is wider, else 128: the launch sizes its LDS for
+ *           n_slots x vec_width (32 .. 128 KiB per workgroup -> 4 .. 1 workgroups per CU)
  */
 int mmf_traj_program(const MmfTrajInstr* prog, int n_instr, const float* weights,
-                     float* const* io, int R, void* stream);
+                     float* const* io, int R, int n_slots, int vec_width, void* stream);
 
 /* ---------------------------------------------------------------- K3: EKF algebra + fusion
  * Replaces torchfilter's EKF predict/update (A S A^T + L L^T; K = S-(S- + R)^-1;

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 21
+ABI_VERSION = 22
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
@@ -100,7 +100,7 @@ SIGNATURES = {
     "mmf_pf_reweight_backward": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_init_particles": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_forward_loop": (c_int, [POINTER(MmfPfLoopArgs), c_void_p]),
-    "mmf_traj_program": (c_int, [_FP, c_int, _FP, POINTER(c_void_p), c_int, c_void_p]),
+    "mmf_traj_program": (c_int, [_FP, c_int, _FP, POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
     "mmf_fuse_virtual_sensors": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_ekf_forward_loop": (c_int, [POINTER(MmfEkfLoopArgs), c_void_p]),
     "mmf_dynamics_jacobian_multi": (c_int, [POINTER(c_void_p), c_int, _FP, POINTER(c_void_p), _FP, _FP,
@@ -368,13 +368,15 @@ def image_encoder(blobs, images: torch.Tensor, feat: torch.Tensor, workspace: to
                "mmf_image_encoder")
 
 
-def traj_program(prog: torch.Tensor, n_instr: int, weights: torch.Tensor, io_tensors, R: int):
+def traj_program(prog: torch.Tensor, n_instr: int, weights: torch.Tensor, io_tensors, R: int,
+                 n_slots: int = TRAJ_SLOTS, vec_width: int = 128):
     """``prog``: uint8 device tensor holding ``n_instr`` MmfTrajInstr; ``io_tensors``: up to
-    TRAJ_MAX_IO float32 device tensors (``None`` = unused)."""
+    TRAJ_MAX_IO float32 device tensors (``None`` = unused); ``n_slots`` / ``vec_width``: what the
+    program uses (sizes the launch's LDS)."""
     arr = (c_void_p * TRAJ_MAX_IO)(*[ptr(t) for t in io_tensors] + [None] * (TRAJ_MAX_IO - len(io_tensors)))
     with _on(weights):
         _check(load().mmf_traj_program(ptr(prog, dtype=torch.uint8), n_instr, ptr(weights), arr, R,
-                                       stream_of(weights)), "mmf_traj_program")
+                                       n_slots, vec_width, stream_of(weights)), "mmf_traj_program")
 
 
 def pf_reweight_backward(logw_out, states, g_estimate, g_logw_out, d_a, d_states):

@@ -18,9 +18,12 @@
 namespace {
 
 constexpr int kRows = 8;     // rows per wave
-constexpr int kSlots = MMF_TRAJ_SLOTS;
-constexpr int kVec = 128;    // max vector width
-constexpr int kWaves = 4;    // waves per workgroup: 4 * 8 slots * 8 rows * 128 * 4 B = 128 KiB LDS
+constexpr int kMaxSlots = MMF_TRAJ_SLOTS;
+constexpr int kMaxVec = 128; // max vector width
+constexpr int kWaves = 4;    // waves per workgroup: at most 4 * 8 slots * 8 rows * 128 * 4 B = 128 KiB LDS.
+// The launch sizes the slot file for what the program uses (n_slots, vector width 64 or 128): a
+// 4-slot, 64-wide program takes 32 KiB per workgroup, so four workgroups (16 waves) share a CU and
+// hide each other's L2 / LDS latency -- the kernel is a chain of dependent loads, not a FLOP problem.
 
 struct IoPtrs {
   float* p[MMF_TRAJ_MAX_IO];
@@ -36,10 +39,11 @@ __device__ __forceinline__ float activate(float v, int act, float fparam) {
 }
 
 __global__ __launch_bounds__(kWaves * MMF_WAVE) void traj_program_kernel(
-    const MmfTrajInstr* __restrict__ prog, int n_instr, const float* __restrict__ weights, IoPtrs io, int R) {
+    const MmfTrajInstr* __restrict__ prog, int n_instr, const float* __restrict__ weights, IoPtrs io, int R,
+    int n_slots, int kVec) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* slots = lds + wave * (kSlots * kRows * kVec);  // [slot][row][kVec]
+  float* slots = lds + wave * (n_slots * kRows * kVec);  // [slot][row][kVec]
   const int wave_global = blockIdx.x * kWaves + wave, waves_total = gridDim.x * kWaves;
 
   for (int task = wave_global; task * kRows < R; task += waves_total) {
@@ -164,21 +168,23 @@ __global__ __launch_bounds__(kWaves * MMF_WAVE) void traj_program_kernel(
 }  // namespace
 
 extern "C" int mmf_traj_program(const MmfTrajInstr* prog, int n_instr, const float* weights,
-                                float* const* io, int R, void* stream) {
+                                float* const* io, int R, int n_slots, int vec_width, void* stream) {
   if (!prog || !weights || !io || n_instr < 1 || R < 0) return MMF_EINVAL;
+  if (n_slots < 1 || n_slots > kMaxSlots || (vec_width != 64 && vec_width != kMaxVec)) return MMF_EINVAL;
   if (R == 0) return 0;
   IoPtrs p{};
   for (int i = 0; i < MMF_TRAJ_MAX_IO; ++i) p.p[i] = io[i];
-  constexpr size_t lds = static_cast<size_t>(kWaves) * kSlots * kRows * kVec * sizeof(float);
-  static_assert(lds <= 160 * 1024, "slots must fit LDS");
+  const size_t lds = static_cast<size_t>(kWaves) * n_slots * kRows * vec_width * sizeof(float);
+  static_assert(static_cast<size_t>(kWaves) * kMaxSlots * kRows * kMaxVec * sizeof(float) <= 160 * 1024, "slots must fit LDS");
   auto k = traj_program_kernel;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   if (e != hipSuccess) return static_cast<int>(e);
   const int tasks = (R + kRows - 1) / kRows;
   int grid = (tasks + kWaves - 1) / kWaves;
-  if (grid > 512) grid = 512;
-  k<<<grid, kWaves * MMF_WAVE, lds, static_cast<hipStream_t>(stream)>>>(prog, n_instr, weights, p, R);
+  const int per_cu = static_cast<int>((160 * 1024) / lds) < 8 ? static_cast<int>((160 * 1024) / lds) : 8;
+  if (grid > 256 * per_cu) grid = 256 * per_cu;
+  k<<<grid, kWaves * MMF_WAVE, lds, static_cast<hipStream_t>(stream)>>>(prog, n_instr, weights, p, R, n_slots, vec_width);
   MMF_CHECK_LAUNCH();
   return 0;
 }

@@ -132,6 +132,21 @@ class TrajProgram:
             host = torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8).clone()
             self._prog_dev = host.to(self._blob.device)
 
+    def _footprint(self):
+        """(slots used, vector width 64 | 128): the launch sizes its LDS slot file for these."""
+        slots, width = 1, 0
+        for I in self._instrs:
+            if I.op in (_abi.TRAJ_LOAD, _abi.TRAJ_LINEAR):
+                slots = max(slots, I.dst + 1)
+                width = max(width, I.out_dim)
+            for k in range(4):
+                if I.src[k] >= 0:
+                    slots = max(slots, I.src[k] + 1)
+                    width = max(width, I.src_off[k] + I.src_dim[k])
+            if I.res >= 0:
+                slots = max(slots, I.res + 1)
+        return slots, (64 if width <= 64 else 128)
+
     def run(self, tensors: Dict[str, torch.Tensor], R: int):
         """``tensors``: every input and (pre-allocated) output by the names used in the program."""
         assert set(tensors) == set(self._io), (sorted(tensors), sorted(self._io))
@@ -140,4 +155,4 @@ class TrajProgram:
         io = [None] * len(self._io)
         for name, idx in self._io.items():
             io[idx] = tensors[name]
-        _abi.traj_program(self._prog_dev, len(self._instrs), self._blob, io, R)
+        _abi.traj_program(self._prog_dev, len(self._instrs), self._blob, io, R, *self._footprint())
