@@ -414,7 +414,7 @@ class CrossmodalKalmanFilter(_FusedKalmanFilters):
             w = w[:, None, None].repeat(1, N, self.state_dim)
         else:
             w = raw
-        w = w[on]
+        w = _select_enabled(w, on)
         assert w.shape == (np.sum(on), N, self.state_dim)
         return w
 
@@ -483,7 +483,7 @@ class CrossmodalKalmanFilter(_FusedKalmanFilters):
             means = torch.stack([x[0] for x in outs])
             trils = torch.stack([x[1] for x in outs])
             covs = trils @ trils.transpose(-1, -2)
-            w = self.crossmodal_weight_model(observations=observations)[on]
+            w = _select_enabled(self.crossmodal_weight_model(observations=observations), on)
             mu = weighted_average(means, w)
             mult = torch.prod(torch.prod(w, dim=-1), dim=0).unsqueeze(-1).unsqueeze(-1)
             self.initialize_beliefs(mean=mu, covariance=mult * torch.sum(covs, dim=0))
@@ -517,6 +517,16 @@ class UnimodalKalmanFilter(_FusedKalmanFilters):
             return mu[0]
         mu_f, _, _, _ = self._fused_step(controls, enc, ctrl, fusion=2, fuse_w=None, feedback=0)
         return mu_f
+
+
+def _select_enabled(w: torch.Tensor, on) -> torch.Tensor:
+    """``w[on]`` for a host-side boolean list ``on`` without the device round trip of boolean-mask
+    indexing (mask upload + ``nonzero`` + a host sync per call -- once per time step in the loop
+    prologue): all enabled is a no-op, otherwise the enabled rows are stacked as views."""
+    on = [bool(x) for x in on]
+    if all(on):
+        return w
+    return torch.stack([w[i] for i, x in enumerate(on) if x])
 
 
 # ===================================================================== fused virtual sensors
@@ -555,7 +565,7 @@ class CrossmodalVirtualSensorModel(base.VirtualSensorModel, _EnabledModels):
             w = w[:, None, None].repeat(1, N, self.state_dim)
         else:
             w = self.crossmodal_weight_model(observations=observations)
-        w = w[on]
+        w = _select_enabled(w, on)
         assert w.shape == (np.sum(on), N, self.state_dim)
         if not use_autograd(self):
             return _fuse_sensors(means, trils, w, mode=1)

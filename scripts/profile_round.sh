@@ -6,7 +6,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 32 --warmup 4 --no-cpu-baseline --no-f32-mode --no-precision-study > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_f32 -- python3 $R/bench.py --steps 32 --warmup 4 --no-cpu-baseline --precision f32 --no-precision-study > $OUT/bench_under_rocprof_f32.json 2> $OUT/stats_f32.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ekf -- python3 $R/bench.py --workload door_ekf --steps 32 --warmup 4 --no-cpu-baseline > $OUT/bench_under_rocprof_ekf.json 2> $OUT/stats_ekf.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_ekf -- python3 $R/bench.py --workload door_ekf --steps 32 --warmup 4 --no-cpu-baseline --no-precision-study > $OUT/bench_under_rocprof_ekf.json 2> $OUT/stats_ekf.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_FETCH_SIZE -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-f32-mode --no-precision-study > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_WRITE_SIZE -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timers --no-f32-mode --no-precision-study > /dev/null 2>&1
 # image encoder alone, 2048 images x 2 encoders per launch sequence: traffic per image-encoder
