@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 22
+#define MMF_ABI_VERSION 23
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -182,17 +182,20 @@ int mmf_pf_measure(const float* packed, int n_res, int precision, const float* s
 /* Forward-mode Jacobian of the dynamics network (replaces torchfilter's default autograd
  * DynamicsModel.jacobian: batch replicated d times + one autograd.grad):
  *  states_in (N, d), traj_bias (N, 64) -> states_out (N, d), jac (N, d, d), jac[n][i][j] = d x'_i / d x_j
+ *  precision: of `packed` (mmf_pack_particle_net); f16x3: the tangent columns are operands like any
+ *  other (signed: their splits mask the sign for the range tracking), range_flag as in mmf_pf_dynamics
  */
-int mmf_dynamics_jacobian(const float* packed, int n_res, const float* states_in,
-                          const float* traj_bias, float* states_out, float* jac, int N, int d,
-                          void* stream);
+int mmf_dynamics_jacobian(const float* packed, int n_res, int precision, const float* states_in,
+                          const float* traj_bias, float* states_out, float* jac, int32_t* range_flag,
+                          int N, int d, void* stream);
 
 /* K independent Jacobian problems of one shape in ONE launch (the sub-filters of a fused EKF):
  * states_in / states_out (K, N, d), jac (K, N, d, d); packed[k], traj_bias[k] per problem.
  */
-int mmf_dynamics_jacobian_multi(const float* const* packed, int n_res, const float* states_in,
-                                const float* const* traj_bias, float* states_out, float* jac,
-                                int K, int N, int d, void* stream);
+int mmf_dynamics_jacobian_multi(const float* const* packed, int n_res, int precision,
+                                const float* states_in, const float* const* traj_bias,
+                                float* states_out, float* jac, int32_t* range_flag, int K, int N,
+                                int d, void* stream);
 
 /* ---------------------------------------------------------------- K6: training through the per-particle networks
  * Replaces autograd through DoorDynamicsModel*.forward / DoorMeasurementModel.forward over N*M
@@ -476,7 +479,9 @@ typedef struct MmfEkfLoopArgs {
   int32_t T, N, d, K;
   int32_t fusion, feedback;  /* as mmf_ekf_step                                              */
   int32_t n_res_dyn;
-  const float* dyn_packed[MMF_LOOP_MAX_MEAS];  /* MMF_PREC_F32 blobs of the dynamics networks   */
+  int32_t precision;         /* of dyn_packed (the Jacobian launches)                          */
+  int32_t* range_flag;       /* f16x3: OR-ed with 1 when an operand leaves the f16 range, or null */
+  const float* dyn_packed[MMF_LOOP_MAX_MEAS];  /* blobs of the dynamics networks (mmf_pack_particle_net) */
   const float* dyn_bias[MMF_LOOP_MAX_MEAS];    /* (T*N, 64) hoisted control terms               */
   const float* q_tril;       /* (K, d, d)                                                      */
   const float* z;            /* (T, K, N, d)      virtual-sensor observations                  */

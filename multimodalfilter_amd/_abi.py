@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 22
+ABI_VERSION = 23
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
@@ -69,7 +69,8 @@ class MmfPfLoopArgs(Structure):
 
 class MmfEkfLoopArgs(Structure):
     _fields_ = [("T", c_int32), ("N", c_int32), ("d", c_int32), ("K", c_int32),
-                ("fusion", c_int32), ("feedback", c_int32), ("n_res_dyn", c_int32),
+                ("fusion", c_int32), ("feedback", c_int32), ("n_res_dyn", c_int32), ("precision", c_int32),
+                ("range_flag", _FP),
                 ("dyn_packed", _FP * LOOP_MAX_MEAS), ("dyn_bias", _FP * LOOP_MAX_MEAS),
                 ("q_tril", _FP), ("z", _FP), ("r_tril", _FP), ("fuse_w", _FP),
                 ("mu", _FP), ("Sigma", _FP), ("mu_pred", _FP), ("A", _FP), ("Sigma_f", _FP),
@@ -92,7 +93,7 @@ SIGNATURES = {
     "mmf_pack_particle_net": (c_int, [POINTER(MmfParticleNetDesc), _FP, c_int, c_void_p]),
     "mmf_pf_dynamics": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_measure": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, c_int, _FP, c_int, _FP, c_int, c_int, c_int, c_void_p]),
-    "mmf_dynamics_jacobian": (c_int, [_FP, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
+    "mmf_dynamics_jacobian": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_ekf_step": (c_int, [_FP] * 10 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_ekf_step_backward": (c_int, [_FP] * 13 + [c_int, c_int, c_int, c_void_p]),
     "mmf_ukf_sigma_points": (c_int, [_FP, _FP, ctypes.c_float, _FP, _FP, c_int, c_int, c_void_p]),
@@ -103,7 +104,7 @@ SIGNATURES = {
     "mmf_traj_program": (c_int, [_FP, c_int, _FP, POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
     "mmf_fuse_virtual_sensors": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_ekf_forward_loop": (c_int, [POINTER(MmfEkfLoopArgs), c_void_p]),
-    "mmf_dynamics_jacobian_multi": (c_int, [POINTER(c_void_p), c_int, _FP, POINTER(c_void_p), _FP, _FP,
+    "mmf_dynamics_jacobian_multi": (c_int, [POINTER(c_void_p), c_int, c_int, _FP, POINTER(c_void_p), _FP, _FP, _FP,
                                             c_int, c_int, c_int, c_void_p]),
     "mmf_particle_net_train_forward": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_particle_net_weight_grads": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
@@ -226,10 +227,10 @@ def pf_measure(packed, n_res, precision, states, traj_bias, modality_logw, logw_
                                      stream_of(states)), "mmf_pf_measure")
 
 
-def dynamics_jacobian(packed, n_res, states_in, traj_bias, states_out, jac, N, d):
+def dynamics_jacobian(packed, n_res, precision, states_in, traj_bias, states_out, jac, range_flag, N, d):
     with _on(states_in):
-        _check(load().mmf_dynamics_jacobian(ptr(packed), n_res, ptr(states_in), ptr(traj_bias),
-                                            ptr(states_out), ptr(jac), N, d,
+        _check(load().mmf_dynamics_jacobian(ptr(packed), n_res, precision, ptr(states_in), ptr(traj_bias),
+                                            ptr(states_out), ptr(jac), ptr(range_flag, dtype=torch.int32), N, d,
                                             stream_of(states_in)), "mmf_dynamics_jacobian")
 
 

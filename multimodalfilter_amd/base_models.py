@@ -350,13 +350,16 @@ class _FusedKalmanFilters(base.Filter, _EnabledModels):
         mu_pred, A = torch.empty_like(mu), torch.empty_like(Sigma)
         Sigma_f = torch.empty((N, d, d), dtype=torch.float32, device=dev)
         est = torch.empty((T, N, d), dtype=torch.float32, device=dev)
-        blobs = [m._net.blob(_abi.PREC_F32) for m in dyns]
+        prec = dyns[0]._net.precision_code()
+        blobs = [m._net.blob(prec) for m in dyns]
         biases = [ctrl_all[i]["bias"] for i in live_idx]
         fw = None if fuse_w is None else f32(fuse_w).contiguous()
         P = lambda t: None if t is None else ctypes.c_void_p(_abi.ptr(t))
         a = _abi.MmfEkfLoopArgs()
         a.T, a.N, a.d, a.K, a.fusion, a.feedback = T, N, d, K, fusion, feedback
-        a.n_res_dyn = dyns[0]._net.n_res
+        a.n_res_dyn, a.precision = dyns[0]._net.n_res, prec
+        a.range_flag = (ctypes.c_void_p(_abi.ptr(engine.range_flag(dev), dtype=torch.int32))
+                        if prec != _abi.PREC_F32 else None)
         for k in range(K):
             a.dyn_packed[k], a.dyn_bias[k] = P(blobs[k]), P(biases[k])
         a.q_tril, a.z, a.r_tril, a.fuse_w = P(q), P(z), P(r), P(fw)

@@ -23,8 +23,8 @@ extern "C" int mmf_ekf_forward_loop(const MmfEkfLoopArgs* a, void* stream) {
     {  // every sub-filter's Jacobian in one launch (they are ~45 us of latency each on their own)
       const float* bias[MMF_LOOP_MAX_MEAS];
       for (size_t k = 0; k < K; ++k) bias[k] = a->dyn_bias[k] + t * N * MMF_UNITS;
-      const int rc = mmf_dynamics_jacobian_multi(a->dyn_packed, a->n_res_dyn, a->mu, bias, a->mu_pred, a->A,
-                                                 a->K, a->N, a->d, stream);
+      const int rc = mmf_dynamics_jacobian_multi(a->dyn_packed, a->n_res_dyn, a->precision, a->mu, bias, a->mu_pred,
+                                                 a->A, a->range_flag, a->K, a->N, a->d, stream);
       if (rc) return rc;
     }
     float* est = a->estimates + t * N * d;

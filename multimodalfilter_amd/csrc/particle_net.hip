@@ -322,19 +322,23 @@ __device__ __forceinline__ void mfma_layer_f16(const float* __restrict__ Wl, con
     }
 }
 
-template <int CT, bool SIGNED = false>
+// JAC: the tile holds groups of {primal, tangents}: tangent columns take no bias, follow the primal's
+// ReLU mask and are signed (their splits mask the sign bits for the range tracking).
+template <int CT, bool SIGNED = false, bool JAC = false>
 __device__ __forceinline__ void res_block_f16(const float* __restrict__ lds, int n_res, int l1,
                                               Act<CT>& x, Act<CT>& hbuf, SplitAct<CT>& sp, int lane,
-                                              float neg_one, short2v& amax) {
+                                              float neg_one, short2v& amax, bool primal = true) {
   const int h = lane >> 5;
-  split_act<CT, SIGNED>(x, sp, neg_one, amax);
-  add_bias<CT, false>(lds + off_bias(n_res) + l1 * kUnits, hbuf, h, 1.f);
+  const float bs = (JAC && !primal) ? 0.f : 1.f;
+  split_act<CT, SIGNED || JAC>(x, sp, neg_one, amax);
+  add_bias<CT, false>(lds + off_bias(n_res) + l1 * kUnits, hbuf, h, bs);
   mfma_layer_f16<CT>(lds + off_layers() + l1 * kLayerFloats, sp, hbuf, lane);
-  relu<CT, false>(hbuf, true);
-  split_act<CT>(hbuf, sp, neg_one, amax);
-  add_bias_packed<CT>(lds + off_bias(n_res) + (l1 + 1) * kUnits, x, h);
+  relu<CT, JAC>(hbuf, primal);
+  split_act<CT, JAC>(hbuf, sp, neg_one, amax);
+  if constexpr (JAC) add_bias<CT, true>(lds + off_bias(n_res) + (l1 + 1) * kUnits, x, h, bs);
+  else add_bias_packed<CT>(lds + off_bias(n_res) + (l1 + 1) * kUnits, x, h);
   mfma_layer_f16<CT>(lds + off_layers() + (l1 + 1) * kLayerFloats, sp, x, lane);
-  relu<CT, false>(x, true);
+  relu<CT, JAC>(x, primal);
 }
 
 // ------------------------------------------------------------------ f16x3, pipelined halves
@@ -488,7 +492,6 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr bool JAC = KIND == kJacobian;
   constexpr bool F16 = PREC == MMF_PREC_F16X3;
-  static_assert(!(JAC && F16), "the Jacobian kernel runs in f32");
   constexpr int NOUT = (KIND == kMeasure) ? 1 : D + 1;
   constexpr int TILE = 32 * CT;
   static_assert(!JAC || D <= 3, "jacobian groups are 4 columns: primal + up to 3 tangents");
@@ -654,7 +657,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
       relu_half<1>(H);
     } else {
     // ---- encoder residual block (layers 0, 1)
-    if constexpr (F16) res_block_f16<CT>(lds, NRES, 0, X, H, SP, lane, neg_one, amax);
+    if constexpr (F16) res_block_f16<CT, false, JAC>(lds, NRES, 0, X, H, SP, lane, neg_one, amax, primal);
     else res_block<CT, JAC>(lds, NRES, 0, X, H, lane, primal);
 
     // ---- join layer (2): per-trajectory hoisted half arrives as the accumulator init
@@ -671,7 +674,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
         }
       }
     if constexpr (F16) {
-      split_act<CT>(X, SP, neg_one, amax);
+      split_act<CT, JAC>(X, SP, neg_one, amax);
       mfma_layer_f16<CT>(lds + off_layers() + 2 * kLayerFloats, SP, H, lane);
     } else {
       mfma_layer<CT>(lds + off_layers() + 2 * kLayerFloats, X, H, lane);
@@ -683,8 +686,8 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
     for (int i = 0; i < NRES; ++i) {
       // without a ReLU after the join layer (dynamics) the trunk's first split sees signed values
       if constexpr (F16) {
-        if (i == 0 && KIND != kMeasure) res_block_f16<CT, true>(lds, NRES, 3, H, X, SP, lane, neg_one, amax);
-        else res_block_f16<CT>(lds, NRES, 3 + 2 * i, H, X, SP, lane, neg_one, amax);
+        if (i == 0 && KIND != kMeasure) res_block_f16<CT, true, JAC>(lds, NRES, 3, H, X, SP, lane, neg_one, amax, primal);
+        else res_block_f16<CT, false, JAC>(lds, NRES, 3 + 2 * i, H, X, SP, lane, neg_one, amax, primal);
       }
       else res_block<CT, JAC>(lds, NRES, 3 + 2 * i, H, X, lane, primal);
     }
@@ -843,8 +846,7 @@ int launch_multi(const NetArgsMulti& m, int count, int d, int n_res, int precisi
 #define MMF_CASE(D, NR)                                                              \
   if (d == D && n_res == NR) {                                                       \
     if (precision == MMF_PREC_F32) return launch_ct<D, NR, KIND, MMF_PREC_F32>(m, count, s); \
-    if constexpr (KIND != kJacobian)                                                 \
-      if (precision == MMF_PREC_F16X3) return launch_ct<D, NR, KIND, MMF_PREC_F16X3>(m, count, s); \
+    if (precision == MMF_PREC_F16X3) return launch_ct<D, NR, KIND, MMF_PREC_F16X3>(m, count, s); \
     return MMF_EINVAL;                                                               \
   }
   if (KIND == kJacobian || KIND == kDynamics) {
@@ -910,9 +912,9 @@ extern "C" int mmf_pf_measure(const float* packed, int n_res, int precision, con
   return launch<kMeasure>(a, d, n_res, precision, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int mmf_dynamics_jacobian(const float* packed, int n_res, const float* states_in,
-                                     const float* traj_bias, float* states_out, float* jac, int N,
-                                     int d, void* stream) {
+extern "C" int mmf_dynamics_jacobian(const float* packed, int n_res, int precision, const float* states_in,
+                                     const float* traj_bias, float* states_out, float* jac,
+                                     int* range_flag, int N, int d, void* stream) {
   if (!packed || !states_in || !traj_bias || !states_out || !jac) return MMF_EINVAL;
   if (N < 0) return MMF_EINVAL;
   if (N > 0x7fffffff / 32) return MMF_ETOOLARGE;
@@ -920,12 +922,14 @@ extern "C" int mmf_dynamics_jacobian(const float* packed, int n_res, const float
   NetArgs a{};
   a.packed = packed; a.states_in = states_in; a.traj_bias = traj_bias;
   a.states_out = states_out; a.jac = jac; a.R = 4 * N; a.M = 4;
-  return launch<kJacobian>(a, d, n_res, MMF_PREC_F32, static_cast<hipStream_t>(stream));
+  a.range_flag = range_flag;
+  return launch<kJacobian>(a, d, n_res, precision, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int mmf_dynamics_jacobian_multi(const float* const* packed, int n_res, const float* states_in,
-                                           const float* const* traj_bias, float* states_out, float* jac,
-                                           int K, int N, int d, void* stream) {
+extern "C" int mmf_dynamics_jacobian_multi(const float* const* packed, int n_res, int precision,
+                                           const float* states_in, const float* const* traj_bias,
+                                           float* states_out, float* jac, int* range_flag, int K, int N,
+                                           int d, void* stream) {
   if (!packed || !states_in || !traj_bias || !states_out || !jac) return MMF_EINVAL;
   if (K < 1 || K > MMF_LOOP_MAX_MEAS || N < 0) return MMF_EINVAL;
   if (N > 0x7fffffff / 32) return MMF_ETOOLARGE;
@@ -939,8 +943,9 @@ extern "C" int mmf_dynamics_jacobian_multi(const float* const* packed, int n_res
     a.states_out = states_out + static_cast<size_t>(k) * N * d;
     a.jac = jac + static_cast<size_t>(k) * N * d * d;
     a.R = 4 * N; a.M = 4;
+    a.range_flag = range_flag;
   }
-  return launch_multi<kJacobian>(m, K, d, n_res, MMF_PREC_F32, static_cast<hipStream_t>(stream));
+  return launch_multi<kJacobian>(m, K, d, n_res, precision, static_cast<hipStream_t>(stream));
 }
 
 #include "particle_net_train.inc"

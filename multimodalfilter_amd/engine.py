@@ -536,8 +536,9 @@ def run_jacobian(net: PackedParticleNet, states: torch.Tensor, traj_bias: torch.
     N, d = states.shape
     out = torch.empty_like(states)
     jac = torch.empty((N, d, d), dtype=torch.float32, device=states.device)
-    blob = net.blob(_abi.PREC_F32)  # the tangent kernel is f32-only
-    _abi.dynamics_jacobian(blob, net.n_res, states.contiguous(), traj_bias, out, jac, N, d)
+    prec = net.precision_code()
+    flag = range_flag(states.device) if prec != _abi.PREC_F32 else None
+    _abi.dynamics_jacobian(net.blob(prec), net.n_res, prec, states.contiguous(), traj_bias, out, jac, flag, N, d)
     return out, jac
 
 

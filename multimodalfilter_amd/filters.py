@@ -503,11 +503,14 @@ class VirtualSensorExtendedKalmanFilter(base.Filter):
         q = dyn.scale_tril().to(torch.float32).reshape(1, d, d).contiguous()
         mu_pred, A = torch.empty_like(mu), torch.empty_like(Sigma)
         est = torch.empty((T, N, d), dtype=torch.float32, device=mu.device)
-        blob = dyn._net.blob(_abi.PREC_F32)
+        prec = dyn._net.precision_code()
+        blob = dyn._net.blob(prec)
         P = lambda t: ctypes.c_void_p(_abi.ptr(t))
         a = _abi.MmfEkfLoopArgs()
         a.T, a.N, a.d, a.K, a.fusion, a.feedback = T, N, d, 1, 0, 0
-        a.n_res_dyn = dyn._net.n_res
+        a.n_res_dyn, a.precision = dyn._net.n_res, prec
+        a.range_flag = (ctypes.c_void_p(_abi.ptr(engine.range_flag(mu.device), dtype=torch.int32))
+                        if prec != _abi.PREC_F32 else None)
         a.dyn_packed[0], a.dyn_bias[0] = P(blob), P(ctrl_all["bias"])
         a.q_tril, a.z, a.r_tril = P(q), P(z), P(r)
         a.mu, a.Sigma, a.mu_pred, a.A, a.estimates = P(mu), P(Sigma), P(mu_pred), P(A), P(est)
