@@ -40,11 +40,13 @@ def test_stacked_noise_checks_shapes():
 def test_loop_argument_structs_match_the_header():
     """Field order / sizes of the host structs handed to the native step loops."""
     P, I = ctypes.sizeof(ctypes.c_void_p), 4
-    assert ctypes.sizeof(_abi.MmfEkfLoopArgs) == 8 * I + (2 * _abi.LOOP_MAX_MEAS + 10) * P
+    assert ctypes.sizeof(_abi.MmfEkfLoopArgs) == 8 * I + (2 * _abi.LOOP_MAX_MEAS + 11) * P
     pf = _abi.MmfPfLoopArgs
     assert pf.T.offset == 0 and pf.dyn_packed.offset == 10 * I
     assert pf.event_stride.offset + I <= ctypes.sizeof(pf)
-    assert [n for n, _ in _abi.MmfEkfLoopArgs._fields_][:7] == ["T", "N", "d", "K", "fusion", "feedback", "n_res_dyn"]
+    assert [n for n, _ in _abi.MmfEkfLoopArgs._fields_][:9] == ["T", "N", "d", "K", "fusion", "feedback", "n_res_dyn",
+                                                                "precision", "range_flag"]
+    assert _abi.MmfEkfLoopArgs.range_flag.offset == 8 * I  # eight int32 fields, then pointers
 
 
 def test_training_entry_points_fail_loudly_without_backend_or_gpu():
