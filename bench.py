@@ -584,7 +584,7 @@ def main():
             distributed.all_gather_rows(
                 evaluation.per_trajectory_mse(pred_w, traj_w["states"][1:], start=min(30, W // 2)))
         torch.cuda.synchronize()
-        timer = None if args.no_kernel_timers else engine.KernelTimer(loop_stride=max(1, (K + 2) // 3))  # 3 sampled steps
+        timer = None if args.no_kernel_timers else engine.KernelTimer(loop_stride=K if K < 64 else (K + 2) // 3)  # 3 sampled steps (1 for short passes)
         engine.set_kernel_timer(timer)
         distributed.barrier()
         torch.cuda.synchronize()
@@ -602,7 +602,7 @@ def main():
     # FIRST, the headline pass last (each pass does its own W warm-up steps and times exactly K): a short
     # run -- the driver's --steps 20 --warmup 5 is 17 ms of GPU work -- then finds the GPU busy and its
     # kernels loaded.  (What cost such runs 15-18 % was the kernel timers: one sampled step in K // 16
-    # means EVERY step at K = 20, and an event record is a barrier packet; now 3 sampled steps per pass.)
+    # means EVERY step at K = 20, and an event record is a barrier packet; now 3 sampled steps per pass, 1 under 64.)
     # the same K steps with exact fp32 products on the f32 MFMA, for comparison (all ranks)
     f32_pass = None
     if wl["kind"] == "pf" and precision != "f32" and not args.no_f32_mode:

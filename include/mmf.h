@@ -355,8 +355,8 @@ typedef struct MmfPfLoopArgs {
                              /* bit 1 log-weights in logw_b                                   */
   void* const* events;       /* HOST array of hipEvent_t or null: recorded around every launch */
                              /* of the sampled steps, [sample][dynamics, measure.., resample][start,end] */
-  int32_t event_stride;      /* steps t with t % event_stride == 0 are sampled (<= 1: every    */
-                             /* step); `events` holds 2*(2+n_meas)*ceil(T/stride) entries      */
+  int32_t event_stride;      /* steps t with t % stride == stride / 2 are sampled (<= 1: every  */
+                             /* step); `events` holds 2*(2+n_meas) entries per sampled step    */
 } MmfPfLoopArgs;             /* host struct holding device pointers                           */
 
 int mmf_pf_forward_loop(const MmfPfLoopArgs* args /* host */, void* stream);

@@ -34,7 +34,7 @@ extern "C" int mmf_pf_forward_loop(const MmfPfLoopArgs* a, void* stream) {
   };
   for (int t = 0; t < a->T; ++t) {
     int rc;
-    sampled = a->events && t % stride == 0;
+    sampled = a->events && t % stride == stride / 2;  // the middle step of every stride-long window
     if ((rc = mark())) return rc;
     rc = mmf_pf_dynamics(a->dyn_packed, a->n_res_dyn, a->precision, cur, a->dyn_bias + t * row * MMF_UNITS,
                              a->noise + t * nm * a->d, a->scale_tril, other, a->range_flag, a->N, a->M, a->d,

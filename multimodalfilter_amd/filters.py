@@ -318,7 +318,7 @@ class ParticleFilter(base.Filter):
         stride = 1
         if timer is not None:
             stride = max(1, int(timer.loop_stride))
-            events = timer.loop_events(2 * len(names) * ((T + stride - 1) // stride))
+            events = timer.loop_events(2 * len(names) * len(range(stride // 2, T, stride)))  # pf_loop.hip samples t % stride == stride // 2
         loc = _abi.pf_forward_loop(a, like, events, stride)
         if timer is not None:
             R = N * M
