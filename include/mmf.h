@@ -57,14 +57,15 @@ int mmf_version(void);
  * oracle/resample.py.
  *
  *  loglik      (N, M)          measurement log-likelihoods
- *  logw_in     (N, M)          current log-weights
+ *  logw_in     (N, M)          current log-weights; modes 1/2: null = uniform -log M (nothing is read)
  *  states_in   (N, M, d)
  *  u           mode 1: (N) uniforms in [0,1); mode 2: (N, M_out); mode 0: ignored (may be null)
  *  estimate    (N, d)          weighted-mean state estimate (always written)
  *  states_out  (N, M_out, d)   mode 1/2: resampled particles; must NOT alias states_in.
  *                              mode 0: may be null or alias states_in (no copy when it does)
  *  logw_out    (N, M_out)      mode 0: normalised log-weights (may alias logw_in);
- *                              mode 1/2: -log(M_out) (may alias logw_in when M_out == M)
+ *                              mode 1/2: -log(M_out) (may alias logw_in when M_out == M); null = not
+ *                              written (the survivors' weights are uniform by definition)
  *  indices_out (N, M_out) int32 ancestor indices, or null
  *  mode        0 none, 1 systematic, 2 multinomial
  * Limits: d <= 4; M, M_out <= 65536; mode 0 stages 4 B/particle in LDS (M <= 40000),

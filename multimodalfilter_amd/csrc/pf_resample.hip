@@ -55,7 +55,9 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
   const int chunk = blockDim.x * 4;
 
   const float* ll = loglik + static_cast<size_t>(n) * M;
-  const float* lw = logw_in + static_cast<size_t>(n) * M;
+  // logw_in == nullptr: uniform weights -log M (what every resampling step leaves behind): nothing to read
+  const float* lw = logw_in ? logw_in + static_cast<size_t>(n) * M : nullptr;
+  const float lw_uniform = -logf(static_cast<float>(M));
   const float* xs = states_in + static_cast<size_t>(n) * M * D;
   const bool vec = (M & 3) == 0;  // rows 16-B aligned -> float4 path
 
@@ -92,11 +94,11 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
     float v[4];
     if (vec && i0 + 3 < M) {
       const float4 a = *reinterpret_cast<const float4*>(ll + i0);
-      const float4 b = *reinterpret_cast<const float4*>(lw + i0);
+      const float4 b = lw ? *reinterpret_cast<const float4*>(lw + i0) : make_float4(lw_uniform, lw_uniform, lw_uniform, lw_uniform);
       v[0] = b.x + a.x; v[1] = b.y + a.y; v[2] = b.z + a.z; v[3] = b.w + a.w;
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = (i0 + j < M) ? lw[i0 + j] + ll[i0 + j] : -INFINITY;
+      for (int j = 0; j < 4; ++j) v[j] = (i0 + j < M) ? (lw ? lw[i0 + j] : lw_uniform) + ll[i0 + j] : -INFINITY;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -257,7 +259,8 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
   const int shift = __ffs(M_out) - 1;
   const float log_uniform = -logf(static_cast<float>(M_out));
   float* so = states_out + static_cast<size_t>(n) * M_out * D;
-  float* lo = logw_out + static_cast<size_t>(n) * M_out;
+  // logw_out == nullptr (plain resampling only): the survivors' weights are -log M_out by definition
+  float* lo = logw_out ? logw_out + static_cast<size_t>(n) * M_out : nullptr;
   int32_t* io = indices_out ? indices_out + static_cast<size_t>(n) * M_out : nullptr;
   const float* un = (mode == 2) ? u + static_cast<size_t>(n) * M_out : nullptr;
   const bool vec_out = (M_out & 3) == 0;
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
 #pragma unroll
         for (int c = 0; c < D; ++c) g[j * D + c] = STAGE ? xs_lds[lo_i * D + c] : xs[static_cast<size_t>(lo_i) * D + c];
         if (SOFT) {  // importance weight of the survivor: w / (alpha w + (1 - alpha) / M), up to the common 1 / S
-          const float e = mmf::detexp((lw[lo_i] + ll[lo_i]) - mx);
+          const float e = mmf::detexp(((lw ? lw[lo_i] : lw_uniform) + ll[lo_i]) - mx);
           const float r = e / (alpha * e + mix_uniform);
           rsum += r;
           lr[j] = logf(r);
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
       float4* p = reinterpret_cast<float4*>(so + static_cast<size_t>(k0) * D);
 #pragma unroll
       for (int k = 0; k < D; ++k) p[k] = make_float4(g[4 * k], g[4 * k + 1], g[4 * k + 2], g[4 * k + 3]);
-      *reinterpret_cast<float4*>(lo + k0) = make_float4(lr[0], lr[1], lr[2], lr[3]);
+      if (lo) *reinterpret_cast<float4*>(lo + k0) = make_float4(lr[0], lr[1], lr[2], lr[3]);
       if (io) *reinterpret_cast<int4*>(io + k0) = make_int4(idx[0], idx[1], idx[2], idx[3]);
     } else {
 #pragma unroll
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
         if (k < M_out) {
 #pragma unroll
           for (int c = 0; c < D; ++c) so[static_cast<size_t>(k) * D + c] = g[j * D + c];
-          lo[k] = lr[j];
+          if (lo) lo[k] = lr[j];
           if (io) io[k] = idx[j];
         }
       }
@@ -362,8 +365,10 @@ namespace {
 int launch_reweight_resample(const float* loglik, const float* logw_in, const float* states_in, const float* u,
                              float* estimate, float* states_out, float* logw_out, int32_t* indices_out, int N,
                              int M, int M_out, int d, int mode, float alpha, void* stream) {
-  if (!loglik || !logw_in || !states_in || !estimate || !logw_out) return MMF_EINVAL;
+  if (!loglik || !states_in || !estimate) return MMF_EINVAL;
   if (N < 0 || M < 1 || M_out < 1 || d < 1 || d > MMF_MAX_STATE_DIM || mode < 0 || mode > 2) return MMF_EINVAL;
+  // the uniform-weight shortcuts (null logw_in / logw_out) belong to plain resampling
+  if ((!logw_in || !logw_out) && (mode == 0 || alpha < 1.f)) return MMF_EINVAL;
   if (mode != 0 && (!u || !states_out || states_out == states_in)) return MMF_EINVAL;
   if (mode == 0 && M_out != M) return MMF_EINVAL;
   if (!(alpha > 0.f && alpha <= 1.f)) return MMF_EINVAL;
