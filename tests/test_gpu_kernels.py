@@ -144,6 +144,43 @@ def test_k1_edge_cases_changing_count_neg_inf_and_degenerate():
     np.testing.assert_array_equal(idx, rs.resample_indices(ll, u, "systematic"))
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_k1_uniform_weight_shortcuts(mode):
+    """Null ``logw_in`` = uniform ``-log M`` and null ``logw_out`` = nothing written (what the native
+    step loop passes from its second step on): same ancestors, particles and estimate, bit for bit, as
+    the call with the materialised uniform weights; refused where the weights are not uniform."""
+    abi = _abi()
+    dev = _cuda()
+    N, M, d = 5, 4096, 3
+    g = torch.Generator().manual_seed(3)
+    ll = (torch.randn((N, M), generator=g) * 2).to(dev)
+    x = torch.randn((N, M, d), generator=g).to(dev)
+    u = torch.rand((N,) if mode == 1 else (N, M), generator=g).to(dev)
+    lw = torch.full((N, M), 0.0, device=dev)
+    # the uniform weights exactly as a resampling step leaves them
+    abi.pf_reweight_resample(torch.zeros_like(ll), lw.clone(), x, torch.rand((N,), generator=g).to(dev),
+                             torch.empty((N, d), device=dev), torch.empty_like(x), lw, None, 1)
+    assert float((lw + math.log(M)).abs().max()) < 1e-6
+    est0, xo0 = torch.empty((N, d), device=dev), torch.empty_like(x)
+    lw0, idx0 = torch.empty_like(lw), torch.empty((N, M), dtype=torch.int32, device=dev)
+    abi.pf_reweight_resample(ll, lw, x, u, est0, xo0, lw0, idx0, mode)
+    est1, xo1, idx1 = torch.empty_like(est0), torch.empty_like(x), torch.empty_like(idx0)
+    # the wrapper takes the output count from logw_out: hand it a (N, M) view that the library is told not to fill
+    keep = torch.full((N, M), 7.0, device=dev)
+    with abi._on(x):
+        abi._check(abi.load().mmf_pf_reweight_resample(abi.ptr(ll), None, abi.ptr(x), abi.ptr(u), abi.ptr(est1), abi.ptr(xo1),
+                                                     None, abi.ptr(idx1, dtype=torch.int32), N, M, M, d, mode,
+                                                     abi.stream_of(x)), "mmf_pf_reweight_resample")
+    torch.cuda.synchronize()
+    assert torch.equal(idx0, idx1) and torch.equal(xo0, xo1) and torch.equal(est0, est1)
+    assert float(keep.min()) == 7.0
+    # mode 0 (weights are the output) and soft resampling (weights are not uniform) need both tensors
+    assert abi.load().mmf_pf_reweight_resample(abi.ptr(ll), None, abi.ptr(x), None, abi.ptr(est1), None, abi.ptr(lw0), None,
+                                              N, M, M, d, 0, abi.stream_of(x)) != 0
+    assert abi.load().mmf_pf_reweight_resample_soft(abi.ptr(ll), abi.ptr(lw), abi.ptr(x), abi.ptr(u), abi.ptr(est1), abi.ptr(xo1),
+                                                   None, None, N, M, M, d, mode, 0.5, abi.stream_of(x)) != 0
+
+
 def test_k1_argument_errors():
     abi = _abi()
     dev = _cuda()
