@@ -155,7 +155,25 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
     if (need_cdf && !SOFT) {
       const unsigned long long incl = mmf::wave_inclusive_scan(tsum, lane);
       if (lane == MMF_WAVE - 1) sc.wave_tot[wave] = incl;
+      // the float sums of the estimate ride on the last chunk's two barriers instead of two of their own
+      const bool last_chunk = base + chunk >= M;
+      if (last_chunk) {
+        const float Sw = mmf::wave_sum(S);
+        float aw[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) aw[c] = mmf::wave_sum(acc[c]);
+        if (lane == 0) {
+          sc.red[wave][0] = Sw;
+#pragma unroll
+          for (int c = 0; c < D; ++c) sc.red[wave][1 + c] = aw[c];
+        }
+      }
       __syncthreads();
+      if (last_chunk && tid <= D) {
+        float t = 0.f;
+        for (int w = 0; w < nwaves; ++w) t += sc.red[w][tid];
+        sc.bcast[tid] = t;
+      }
       unsigned long long before = carry, total = 0;
       for (int w = 0; w < nwaves; ++w) {
         const unsigned long long t = sc.wave_tot[w];
@@ -214,21 +232,23 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
       __syncthreads();
     }
   }
-  S = mmf::wave_sum(S);
+  if (!need_cdf || SOFT) {  // (plain resampling did this on its last chunk's barriers)
+    S = mmf::wave_sum(S);
 #pragma unroll
-  for (int c = 0; c < D; ++c) acc[c] = mmf::wave_sum(acc[c]);
-  if (lane == 0) {
-    sc.red[wave][0] = S;
+    for (int c = 0; c < D; ++c) acc[c] = mmf::wave_sum(acc[c]);
+    if (lane == 0) {
+      sc.red[wave][0] = S;
 #pragma unroll
-    for (int c = 0; c < D; ++c) sc.red[wave][1 + c] = acc[c];
+      for (int c = 0; c < D; ++c) sc.red[wave][1 + c] = acc[c];
+    }
+    __syncthreads();
+    if (tid <= D) {
+      float t = 0.f;
+      for (int w = 0; w < nwaves; ++w) t += sc.red[w][tid];
+      sc.bcast[tid] = t;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (tid <= D) {
-    float t = 0.f;
-    for (int w = 0; w < nwaves; ++w) t += sc.red[w][tid];
-    sc.bcast[tid] = t;
-  }
-  __syncthreads();
   S = sc.bcast[0];
   if (tid < D) estimate[static_cast<size_t>(n) * D + tid] = sc.bcast[1 + tid] / S;
 
