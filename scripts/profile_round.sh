@@ -24,6 +24,8 @@ python bench.py --workload push_pf --batch 1024 --steps 64 --no-f32-mode --no-cp
 # SURVEY 8d's headline trio is door PF at M=4096 with N in {32, 256, 1024}: the default bench is N=256
 python bench.py --workload door_pf --batch 32 --steps 64 --no-f32-mode --no-cpu-baseline --no-precision-study > $OUT/bench_door_pf_n32_m4096.json 2>> $OUT/bench.err
 python bench.py --workload door_pf --batch 1024 --steps 32 --no-f32-mode --no-cpu-baseline --no-precision-study > $OUT/bench_door_pf_n1024_m4096.json 2>> $OUT/bench.err
+# C4's global batch (8192 EKF trajectories) on the one GPU: the strong-scaling switch at N = 1
+python bench.py --workload door_ekf --global-batch 8192 --steps 32 --warmup 4 --no-cpu-baseline --no-precision-study > $OUT/bench_c4_door_ekf_n8192_one_gpu.json 2>> $OUT/bench.err
 python bench.py --workload door_pf --batch 32 --particles 300 --steps 200 --no-f32-mode --no-precision-study > $OUT/bench_door_pf_n32_m300.json 2>> $OUT/bench.err
 # the N > 1 launcher on one GPU (two gloo ranks sharing it): plumbing evidence, not a scaling number
 MMF_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 32 --warmup 8 --no-f32-mode --no-precision-study 2>> $OUT/bench.err | grep "^{" > $OUT/bench_gpus2_gloo_one_gpu.json
