@@ -18,7 +18,7 @@ Models that only implement ``forward`` still work: the filters fall back to call
 (on the GPU) and use the HIP kernels for the recursion itself.
 """
 import abc
-from typing import Dict, Tuple
+from typing import Tuple
 
 import torch
 import torch.nn as nn

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import _abi, base, engine, filters
-from .engine import call_with_image_feat, encode_observation_images, require_device, use_autograd
+from .engine import call_with_image_feat, encode_observation_images, use_autograd
 from .utils import tree_index, tree_leading_shape, tree_map
 
 

@@ -5,7 +5,6 @@ over LDS vector slots; ``run`` is then ONE HIP launch, whatever the number of la
 Weights are gathered (transposed, padded) from the owning ``nn.Module`` parameters into one
 device blob that is rebuilt lazily when a parameter changes.
 """
-import ctypes
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
