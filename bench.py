@@ -154,9 +154,12 @@ def oracle_pf_run(cls, state_dict, traj, eps0, eps, us, M, *, mode="systematic",
     ests, beliefs, ess, dt = [], [], [], 0.0
     resample = oracle._resample
 
+    resampled_from = []
+
     def resample_and_record_ess():  # effective sample size of the weights about to be resampled
         w = torch.softmax(oracle.particle_log_weights, dim=1)
         ess.append((1.0 / (w * w).sum(1)) / w.shape[1])  # per trajectory, as a fraction of M
+        resampled_from.append(oracle.particle_log_weights)
         resample()
 
     if keep_beliefs:
@@ -170,7 +173,8 @@ def oracle_pf_run(cls, state_dict, traj, eps0, eps, us, M, *, mode="systematic",
             if t > warm:
                 dt += time.perf_counter() - t0
             if keep_beliefs:
-                beliefs.append(before + (oracle.last_resample_indices, float(ess[-1].mean()), ess[-1]))
+                # [5]: the (normalised) log-weights the oracle's resampler drew from -- for the certificate
+                beliefs.append(before + (oracle.last_resample_indices, float(ess[-1].mean()), ess[-1], resampled_from[-1]))
     return torch.stack(ests), dt, beliefs
 
 
@@ -178,8 +182,14 @@ def teacher_forced_parity(engine_filter, traj, eps, us, beliefs, want, M, *, mod
     """Engine against oracle with the recursion's chaos taken out: before EVERY step the engine's
     belief is overwritten with the belief the oracle held at that point, then one engine step
     runs on the same noise.  What remains is kernel arithmetic: the posterior mean of that step
-    and the ancestor indices the resampler draws from log-weights that differ in the last ulp."""
+    and the ancestor indices the resampler draws from log-weights that differ in the last ulp.
+
+    Every differing ancestor is CERTIFIED (``oracle.resample.certify_mismatches``): (i) the engine's
+    ancestors equal the integer resampler applied to the engine's OWN log-weights (K1 is exact on
+    what it was given), and (ii) each mismatch against the oracle lies within the L1 distance of the
+    two fixed-point weight vectors of the CDF boundary it crossed.  ``unexplained`` counts the rest."""
     import multimodalfilter_amd as mmf
+    from oracle import resample as ors
 
     dev = next(engine_filter.parameters()).device
     f = engine_filter
@@ -192,19 +202,31 @@ def teacher_forced_parity(engine_filter, traj, eps, us, beliefs, want, M, *, mod
     f.initialize_beliefs(mean=traj["states"][0].to(dev), covariance=cov)
     scale = max(1.0, float(want.abs().max()))
     errs, flips = [], []
-    for t, (S, W, idx, _, _) in enumerate(beliefs):
+    cert = {"unexplained": 0, "k1_inexact_on_own_weights": 0, "max_slack_used": 0.0, "max_hop": 0, "max_D_over_Q": 0.0}
+    for t, (S, W, idx, _, _, lw_o) in enumerate(beliefs):
         f.particle_states = S.to(dev).contiguous()
         f.particle_log_weights = W.to(dev).contiguous()
         f._spare_states = None
         f.noise = mmf.ReplayNoise([eps[t]], [us[t]])
         est = f(observations={k: v[t + 1].to(dev) for k, v in obs.items()}, controls=traj["controls"][t + 1].to(dev))
         errs.append(float((est.cpu() - want[t]).abs().max()) / scale)
-        flips.append(int((f.last_resample_indices.cpu().long() != idx).sum()))
+        got_idx = f.last_resample_indices.cpu().numpy()
+        flips.append(int((got_idx.astype("int64") != idx.numpy()).sum()))
+        if mode == "systematic":
+            lw_e = (f.last_log_weights_in + f.last_log_likelihoods).cpu().numpy()  # one fp32 add, as K1 does
+            u_t = us[t].cpu().numpy()
+            cert["k1_inexact_on_own_weights"] += int((ors.resample_indices(lw_e, u_t, mode) != got_idx).sum())
+            c = ors.certify_mismatches(lw_o.numpy(), lw_e, u_t, idx.numpy(), got_idx)
+            assert c["mismatches"] == flips[-1]
+            cert["unexplained"] += c["unexplained"]
+            for k in ("max_slack_used", "max_hop", "max_D_over_Q"):
+                cert[k] = max(cert[k], c[k])
     f.record_indices = rec
     return {"max_rel_err_posterior_mean_per_step": errs,
             "max_rel_err_posterior_mean": max(errs),
             "resample_index_mismatches_per_step": flips,
             "resample_index_mismatch_fraction": sum(flips) / float(len(beliefs) * N * M),
+            "mismatch_certificate": cert,
             "oracle_ess_over_m_per_step": [round(b[3], 4) for b in beliefs]}
 
 

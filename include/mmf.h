@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 23
+#define MMF_ABI_VERSION 24
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -358,6 +358,9 @@ typedef struct MmfPfLoopArgs {
                              /* of the sampled steps, [sample][dynamics, measure.., resample][start,end] */
   int32_t event_stride;      /* steps t with t % stride == stride / 2 are sampled (<= 1: every  */
                              /* step); `events` holds 2*(2+n_meas) entries per sampled step    */
+  float* loglik_steps;       /* (T, N, M) or null: step t's fused log-likelihoods are kept here  */
+                             /* instead of the shared `loglik` scratch (parity certificates)     */
+  int32_t* indices_steps;    /* (T, N, M) int32 or null: ancestors drawn at every resampling step */
 } MmfPfLoopArgs;             /* host struct holding device pointers                           */
 
 int mmf_pf_forward_loop(const MmfPfLoopArgs* args /* host */, void* stream);

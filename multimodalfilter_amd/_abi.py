@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 23
+ABI_VERSION = 24
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
@@ -64,7 +64,7 @@ class MmfPfLoopArgs(Structure):
                 ("states_a", _FP), ("states_b", _FP), ("logw_a", _FP), ("logw_b", _FP),
                 ("loglik", _FP), ("estimates", _FP), ("range_flag", _FP),
                 ("final_location", POINTER(c_int32)), ("events", POINTER(c_void_p)),
-                ("event_stride", c_int32)]
+                ("event_stride", c_int32), ("loglik_steps", _FP), ("indices_steps", _FP)]
 
 
 class MmfEkfLoopArgs(Structure):

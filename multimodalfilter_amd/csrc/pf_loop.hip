@@ -41,11 +41,14 @@ extern "C" int mmf_pf_forward_loop(const MmfPfLoopArgs* a, void* stream) {
                              stream);
     if (rc) return rc;
     if ((rc = mark())) return rc;
+    // parity certificates keep every step's log-likelihoods and ancestors (null on the timed path)
+    float* ll = a->loglik_steps ? a->loglik_steps + t * nm : a->loglik;
+    int32_t* anc = a->indices_steps ? a->indices_steps + t * nm : nullptr;
     for (int k = 0; k < a->n_meas; ++k) {
       const float* lw = a->meas_logw[k] ? a->meas_logw[k] + t * row * a->logw_stride : nullptr;
       if ((rc = mark())) return rc;
       rc = mmf_pf_measure(a->meas_packed[k], a->n_res_meas, a->precision, other,
-                          a->meas_bias[k] + t * row * MMF_UNITS, lw, a->logw_stride, a->loglik, k > 0,
+                          a->meas_bias[k] + t * row * MMF_UNITS, lw, a->logw_stride, ll, k > 0,
                           a->range_flag, a->N, a->M, a->d, stream);
       if (rc) return rc;
       if ((rc = mark())) return rc;
@@ -53,7 +56,7 @@ extern "C" int mmf_pf_forward_loop(const MmfPfLoopArgs* a, void* stream) {
     float* est = a->estimates + t * row * a->d;
     if ((rc = mark())) return rc;
     if (a->resample_mode == 0) {
-      rc = mmf_pf_reweight_resample(a->loglik, lw_cur, other, nullptr, est, nullptr, lw_other, nullptr, a->N,
+      rc = mmf_pf_reweight_resample(ll, lw_cur, other, nullptr, est, nullptr, lw_other, nullptr, a->N,
                                     a->M, a->M, a->d, 0, stream);
       if (rc) return rc;
       float* s = cur; cur = other; other = s;  // propagated particles are the new belief
@@ -62,8 +65,8 @@ extern "C" int mmf_pf_forward_loop(const MmfPfLoopArgs* a, void* stream) {
       // every step of this loop resamples, so from the second step on the incoming weights are the
       // uniform -log M the previous step would have written, and only the last step's are ever read
       // again: 8 of the 40 B per particle-step stay out of HBM
-      rc = mmf_pf_reweight_resample(a->loglik, t == 0 ? lw_cur : nullptr, other, u, est, cur,
-                                    t == a->T - 1 ? lw_other : nullptr, nullptr, a->N, a->M, a->M, a->d,
+      rc = mmf_pf_reweight_resample(ll, t == 0 ? lw_cur : nullptr, other, u, est, cur,
+                                    t == a->T - 1 ? lw_other : nullptr, anc, a->N, a->M, a->M, a->d,
                                     a->resample_mode, stream);
       if (rc) return rc;  // resampled particles land back in `cur`
     }

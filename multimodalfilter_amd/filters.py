@@ -60,8 +60,13 @@ class ParticleFilter(base.Filter):
         self.resample_mode = resample_mode
         self.estimation_method = estimation_method
         self.noise = NoiseSource(0)
+        # parity certificates: with record_indices set, every step (and the native loop, per step)
+        # keeps its ancestors, the log-likelihoods K2 produced and the log-weights K1 started from
         self.record_indices = False
         self.last_resample_indices = None
+        self.last_log_likelihoods = None
+        self.last_log_weights_in = None
+        self.use_native_loop = True   # False: forward_loop keeps the step-by-step Python loop
         self.particle_states: torch.Tensor = None
         self.particle_log_weights: torch.Tensor = None
         self._spare_states = None
@@ -172,6 +177,8 @@ class ParticleFilter(base.Filter):
             states = self._propagate(controls, ctrl_ctx, N, M, d)
             loglik = self._measure(states, observations, obs_ctx)
             assert loglik.shape == (N, M)
+            if self.record_indices:
+                self.last_log_likelihoods, self.last_log_weights_in = loglik, self.particle_log_weights
 
             estimate = torch.empty((N, d), dtype=torch.float32, device=states.device)
             if do_resample:
@@ -275,8 +282,10 @@ class ParticleFilter(base.Filter):
         dyn, meas = self.dynamics_model, self.measurement_model
         if obs_all is None or ctrl_all is None or not hasattr(dyn, "_net") or not hasattr(meas, "fused_measurements"):
             return None
+        if not self.use_native_loop:
+            return None
         plan = meas.fused_measurements(obs_all)
-        if plan is None or self.estimation_method != "weighted_average" or self.record_indices or T == 0:
+        if plan is None or self.estimation_method != "weighted_average" or T == 0:
             return None
         nets, stride = plan
         Nb, M, d = self.particle_states.shape
@@ -311,6 +320,13 @@ class ParticleFilter(base.Filter):
         a.noise, a.scale_tril, a.uniforms = P(eps), P(tril), P(u)
         a.states_a, a.states_b, a.logw_a, a.logw_b = P(states_a), P(states_b), P(logw_a), P(logw_b)
         a.loglik, a.estimates = P(loglik), P(est)
+        if self.record_indices:
+            self.last_log_weights_in = logw_a.clone()
+            self.last_log_likelihoods = torch.empty((T, N, M), dtype=torch.float32, device=dev)
+            a.loglik_steps = P(self.last_log_likelihoods)
+            if mode != 0:
+                self.last_resample_indices = torch.empty((T, N, M), dtype=torch.int32, device=dev)
+                a.indices_steps = P(self.last_resample_indices)
         a.range_flag = ctypes.c_void_p(engine.range_flag(dev).data_ptr())
         timer = engine.kernel_timer()
         events = None

@@ -163,3 +163,56 @@ def reweight_resample(loglik, logw, states, u, mode: str, num_out: int = None, s
     else:
         logw_out = np.full((N, num_out), -np.log(_F(num_out)), dtype=_F)
     return estimate, states_out, logw_out, idx
+
+
+def certify_mismatches(logw_a, logw_b, u, idx_a, idx_b, num_out: int = None):
+    """Certificate for systematic-resampling ancestors drawn from two sets of log-weights that
+    agree only to rounding (``a``: the checker's, ``b``: the implementation under test; both
+    ``(N, M)`` fp32, same uniforms ``u``; ``idx_a`` / ``idx_b`` the ancestors each side drew).
+
+    With ``delta_i = q_i(b) - q_i(a)`` and ``D = sum_i |delta_i|`` (per trajectory), every inclusive
+    CDF entry moves by at most ``D`` and every position ``p_k = (k Q + R) // M`` by at most
+    ``D + 2``, in opposite-signed shares: ``(cdf_i - p_k)`` changes by
+    ``(1 - k/M) sum_{j<=i} delta_j - (k/M) sum_{j>i} delta_j`` up to the two floors, so by at most
+    ``D + 2`` in magnitude.  Hence side ``b`` may legitimately draw ancestor ``e != o`` at output
+    ``k`` only if side ``a``'s position lies within ``D + 2`` of the CDF boundary it would have to
+    cross: ``cdf_a[e-1] - p_k <= D + 2`` when ``e > o``, ``p_k - cdf_a[e] + 1 <= D + 2`` when
+    ``e < o``.  A mismatch outside that band is NOT explained by the weight differences.
+
+    Returns a dict: ``mismatches``, ``unexplained`` (must be 0), ``max_slack_used`` (largest
+    distance / (D + 2) over the mismatches, <= 1 when all are explained), ``max_hop`` (largest
+    number of positive-weight particles of side ``a`` between the two ancestors, 1 = neighbours),
+    ``max_D_over_Q`` (L1 weight difference relative to the total: how tight the band is).
+    """
+    logw_a = np.asarray(logw_a, dtype=_F)
+    logw_b = np.asarray(logw_b, dtype=_F)
+    idx_a = np.asarray(idx_a).astype(np.int64)
+    idx_b = np.asarray(idx_b).astype(np.int64)
+    N, M = logw_a.shape
+    num_out = M if num_out is None else int(num_out)
+    qa = quantise(logw_a)[0].astype(np.int64)
+    qb = quantise(logw_b)[0].astype(np.int64)
+    cdf = np.cumsum(qa, axis=1)
+    Q = cdf[:, -1]
+    D = np.abs(qb - qa).sum(axis=1)
+    U = _fix_uniform(u).astype(np.int64)
+    R = (U * Q) >> FIX_BITS
+    out = {"mismatches": 0, "unexplained": 0, "max_slack_used": 0.0, "max_hop": 0,
+           "max_D_over_Q": float((D / np.maximum(Q, 1)).max())}
+    pos_rank = np.cumsum(qa > 0, axis=1)  # number of positive-weight particles up to and including i
+    for n in range(N):
+        ks = np.nonzero(idx_a[n] != idx_b[n])[0]
+        if ks.size == 0:
+            continue
+        p = (ks.astype(np.int64) * Q[n] + R[n]) // num_out
+        o, e = idx_a[n, ks], idx_b[n, ks]
+        up = e > o
+        dist = np.where(up, cdf[n, np.maximum(e - 1, 0)] - p, p - cdf[n, e] + 1)
+        band = int(D[n]) + 2
+        # positive-weight particles of side a in (lo, hi]: 1 = the two ancestors are neighbours
+        lo, hi = np.minimum(o, e), np.maximum(o, e)
+        out["mismatches"] += int(ks.size)
+        out["unexplained"] += int((dist > band).sum())
+        out["max_slack_used"] = max(out["max_slack_used"], float((dist / band).max()))
+        out["max_hop"] = max(out["max_hop"], int((pos_rank[n, hi] - pos_rank[n, lo]).max()))
+    return out

@@ -196,7 +196,9 @@ def test_particle_filter_tracks_oracle(tname, kind, cls, mode):
                          for t in range(T)])
     engine.noise = mmf.ReplayNoise([eps0] + eps, us)
     engine.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
+    engine.use_native_loop = False
     loop = engine.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
+    engine.use_native_loop = True
     assert torch.equal(loop, steps)
     torch.testing.assert_close(loop.cpu(), torch.stack(want), rtol=1e-2, atol=1e-2)
 
