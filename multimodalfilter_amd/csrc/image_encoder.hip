@@ -777,11 +777,11 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcArgs a) {
   h = fmaxf(h, 0.f);
   float t = blob[L.r1b + lane];
 #pragma unroll 8
-  for (int k = 0; k < kFeat; ++k) t += blob[L.r1t + k * kFeat + lane] * __shfl(h, k);
+  for (int k = 0; k < kFeat; ++k) t = __builtin_fmaf(blob[L.r1t + k * kFeat + lane], __shfl(h, k), t);  // explicit chains: strict mode
   t = fmaxf(t, 0.f);
   float y = blob[L.r2b + lane] + h;
 #pragma unroll 8
-  for (int k = 0; k < kFeat; ++k) y += blob[L.r2t + k * kFeat + lane] * __shfl(t, k);
+  for (int k = 0; k < kFeat; ++k) y = __builtin_fmaf(blob[L.r2t + k * kFeat + lane], __shfl(t, k), y);
   a.feat[(static_cast<size_t>(net) * a.N + img) * kFeat + lane] = fmaxf(y, 0.f);
 }
 

@@ -26,6 +26,7 @@
 #include <utility>
 
 #include "mmf_common.h"
+#include "../../include/mmf_detmath.h"
 
 namespace {
 
@@ -715,7 +716,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
 #pragma unroll
           for (int c = 0; c < CT; ++c)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) part[c] += w[e] * H.v[t][c][4 * g + e];
+            for (int e = 0; e < 4; ++e) part[c] = __builtin_fmaf(w[e], H.v[t][c][4 * g + e], part[c]);  // explicit: the strict mode's chain
         }
 #pragma unroll
       for (int c = 0; c < CT; ++c) out[o][c] = part[c] + __shfl_xor(part[c], 32);
@@ -746,15 +747,22 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
         if (a.mod_logw) ll += a.mod_logw[static_cast<size_t>(traj) * a.logw_stride];
         if (a.combine) {
           const float prev = a.loglik[my_row];
-          const float m = fmaxf(prev, ll);
-          ll = (m == -INFINITY) ? m : m + logf(expf(prev - m) + expf(ll - m));
+          if constexpr (PREC == MMF_PREC_F32) {
+            // exact-fp32 mode = the bit-reproducible mode: shared deterministic exp / log (mmf_detmath.h)
+            ll = mmf_det_logaddexp(prev, ll);
+          } else {
+            const float m = fmaxf(prev, ll);
+            ll = (m == -INFINITY) ? m : m + logf(expf(prev - m) + expf(ll - m));
+          }
         }
         a.loglik[my_row] = ll;
       }
     } else if (KIND == kDynamics) {
       if (active) {
         const float gate = mine[D] + bh[D];
-        const float sg = 1.0f / (1.0f + expf(-gate));
+        float sg;
+        if constexpr (PREC == MMF_PREC_F32) sg = mmf_det_sigmoid(gate);
+        else sg = 1.0f / (1.0f + expf(-gate));
         float xo[D], eps[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) {
@@ -763,10 +771,10 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
         }
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-          float v = xo[i] + (mine[i] + bh[i]) * sg;
+          float v = __builtin_fmaf(mine[i] + bh[i], sg, xo[i]);
           if (a.noise) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) v += a.scale_tril[i * D + k] * eps[k];
+            for (int k = 0; k < D; ++k) v = __builtin_fmaf(a.scale_tril[i * D + k], eps[k], v);
           }
           a.states_out[static_cast<size_t>(my_row) * D + i] = v;
         }

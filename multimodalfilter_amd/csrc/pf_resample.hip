@@ -11,6 +11,8 @@
 // (+4 logw written in mode 0) = 32 B (d=3) / 24 B (d=2); everything else stays in LDS:
 //   slot[i] (8 B/particle): first the fp32 unnormalised log-weight x_i, then (modes 1/2)
 //   overwritten in place by the u64 inclusive CDF.
+#include <cmath>
+
 #include "mmf_common.h"
 
 namespace {
@@ -37,7 +39,8 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
     const float* __restrict__ loglik, const float* __restrict__ logw_in,
     const float* __restrict__ states_in, const float* __restrict__ u,
     float* __restrict__ estimate, float* states_out, float* logw_out,
-    int32_t* __restrict__ indices_out, int M, int M_out, int mode, float alpha) {
+    int32_t* __restrict__ indices_out, int M, int M_out, int mode, float alpha, float lw_uniform,
+    float log_uniform) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const bool need_cdf = mode != 0;
   const int slot_bytes = need_cdf ? 8 : 4;
@@ -57,7 +60,8 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
   const float* ll = loglik + static_cast<size_t>(n) * M;
   // logw_in == nullptr: uniform weights -log M (what every resampling step leaves behind): nothing to read
   const float* lw = logw_in ? logw_in + static_cast<size_t>(n) * M : nullptr;
-  const float lw_uniform = -logf(static_cast<float>(M));
+  // lw_uniform = float(-log(double(M))), rounded once on the host: the value mmf_pf_init_particles and
+  // every resampling step write, and the one the oracle holds (device logf may differ by an ulp)
   const float* xs = states_in + static_cast<size_t>(n) * M * D;
   const bool vec = (M & 3) == 0;  // rows 16-B aligned -> float4 path
 
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
       tsum += q[j];
       S += e[j];
 #pragma unroll
-      for (int c = 0; c < D; ++c) acc[c] += e[j] * st[j * D + c];
+      for (int c = 0; c < D; ++c) acc[c] = __builtin_fmaf(e[j], st[j * D + c], acc[c]);  // explicit: oracle/strict restates this chain
     }
     qsum += tsum;
     if (need_cdf && !SOFT) {
@@ -277,7 +281,6 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
   }
   const bool pow2 = (M_out & (M_out - 1)) == 0;
   const int shift = __ffs(M_out) - 1;
-  const float log_uniform = -logf(static_cast<float>(M_out));
   float* so = states_out + static_cast<size_t>(n) * M_out * D;
   // logw_out == nullptr (plain resampling only): the survivors' weights are -log M_out by definition
   float* lo = logw_out ? logw_out + static_cast<size_t>(n) * M_out : nullptr;
@@ -406,6 +409,8 @@ int launch_reweight_resample(const float* loglik, const float* logw_in, const fl
   int block = ((M + 3) / 4 + MMF_WAVE - 1) / MMF_WAVE * MMF_WAVE;
   if (block > kBlock) block = kBlock;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const float lw_uniform = static_cast<float>(-std::log(static_cast<double>(M)));
+  const float log_uniform = static_cast<float>(-std::log(static_cast<double>(M_out)));
 #define MMF_K1_LAUNCH(D, ST, SO)                                                               \
   {                                                                                            \
     if (lds > 64 * 1024) {                                                                     \
@@ -415,7 +420,7 @@ int launch_reweight_resample(const float* loglik, const float* logw_in, const fl
       if (e != hipSuccess) return static_cast<int>(e);                                         \
     }                                                                                          \
     pf_reweight_resample_kernel<D, ST, SO><<<N, block, lds, s>>>(loglik, logw_in, states_in, u, \
-        estimate, states_out, logw_out, indices_out, M, M_out, mode, alpha);                   \
+        estimate, states_out, logw_out, indices_out, M, M_out, mode, alpha, lw_uniform, log_uniform); \
   }
 #define MMF_K1(D)                                                                              \
   case D: {                                                                                    \

@@ -326,7 +326,7 @@ class ParticleFilter(base.Filter):
             a.loglik_steps = P(self.last_log_likelihoods)
             if mode != 0:
                 self.last_resample_indices = torch.empty((T, N, M), dtype=torch.int32, device=dev)
-                a.indices_steps = P(self.last_resample_indices)
+                a.indices_steps = ctypes.c_void_p(_abi.ptr(self.last_resample_indices, dtype=torch.int32))
         a.range_flag = ctypes.c_void_p(engine.range_flag(dev).data_ptr())
         timer = engine.kernel_timer()
         events = None
