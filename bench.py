@@ -21,6 +21,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -230,7 +232,58 @@ def teacher_forced_parity(engine_filter, traj, eps, us, beliefs, want, M, *, mod
             "oracle_ess_over_m_per_step": [round(b[3], 4) for b in beliefs]}
 
 
-def cpu_baseline_pf(wl, engine_filter, state_dim, cores, sample_batch=32, sample_steps=12, warm=1):
+def strict_parity(cls, engine_filter, traj, eps0, eps, us, M):
+    """Row N1: the engine in its exact-fp32 (bit-reproducible) mode against ``oracle/strict`` -- the CPU
+    restatement of the same fmaf chains, itself within 2e-6 of the torch oracle -- both FREE-RUNNING over
+    the whole sample from the same initial particles: differing ancestors, differing estimate bits, and
+    the relative difference of the evaluation RMSE (``eval_helpers.py:149-160``).  All three must be 0."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine
+    from oracle import models as om
+    from oracle import strict
+
+    dev = next(engine_filter.parameters()).device
+    f = engine_filter
+    T = len(eps)
+    N, d = traj["states"].shape[1:]
+    o = om.build(cls)
+    o.load_state_dict({k: v.detach().cpu() for k, v in f.state_dict().items()})
+    o.eval()
+    obs = {k: traj[k][1:] for k in ("image", "gripper_pos", "gripper_sensors")}
+    ctrl = traj["controls"][1:]
+    old, rec = engine.DEFAULT_PRECISION, f.record_indices
+    engine.set_default_precision("f32")
+    try:
+        f.num_particles, f.resample_mode, f.record_indices = M, "systematic", True
+        f.noise = mmf.StackedNoise(eps0.to(dev), torch.stack(list(eps)).to(dev), torch.stack(list(us)).to(dev))
+        cov = (torch.eye(d, device=dev) * 0.1)[None].expand(N, d, d)
+        f.initialize_beliefs(mean=traj["states"][0].to(dev), covariance=cov)
+        s = strict.StrictParticleFilter(o)
+        s.set_belief(f.particle_states.cpu().numpy(), f.particle_log_weights.cpu().numpy())
+        got = f.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev)).cpu().numpy()
+        idx = f.last_resample_indices.cpu().numpy()
+    finally:
+        engine.set_default_precision(old)
+        f.record_indices = rec
+    t0 = time.perf_counter()
+    want, flips = [], []
+    for t in range(T):
+        want.append(s.step(observations={k: v[t] for k, v in obs.items()}, controls=ctrl[t], eps=eps[t], u=us[t]))
+        flips.append(int((idx[t] != s.last_resample_indices).sum()))
+    want = np.stack(want)
+    truth = traj["states"][1:].numpy()
+    rm_e = np.sqrt(((got - truth) ** 2).mean((0, 1)))
+    rm_o = np.sqrt(((want - truth) ** 2).mean((0, 1)))
+    return {"mode": "f32 (strict)", "steps": T, "batch": N, "particles": M,
+            "differing_ancestors_per_step": flips, "differing_ancestors": int(sum(flips)),
+            "differing_estimate_values": int((got != want).sum()),
+            "final_particle_set_identical": bool(np.array_equal(f.particle_states.cpu().numpy(), s.states)),
+            "rmse_rel_diff": float((np.abs(rm_e - rm_o) / rm_o).max()),
+            "checker": "oracle/strict (C, fmaf chains in the kernels' k-order; <= 2e-6 from the torch oracle)",
+            "checker_seconds": round(time.perf_counter() - t0, 1)}
+
+
+def cpu_baseline_pf(wl, engine_filter, state_dim, cores, sample_batch=32, sample_steps=24, warm=1):
     """The oracle (pure torch, fp32, CPU) on a bounded sample of the same workload, with the
     engine run on the identical sample (same weights, observations, noise) for parity:
     teacher-forced (kernel arithmetic, the 1e-4 bar) and free-running (both filters left alone
@@ -253,6 +306,7 @@ def cpu_baseline_pf(wl, engine_filter, state_dim, cores, sample_batch=32, sample
     rm_e = ((got - traj["states"][1:]) ** 2).mean((0, 1)).sqrt()
     rm_o = ((want - traj["states"][1:]) ** 2).mean((0, 1)).sqrt()
     parity = {
+        "strict_f32_free_running": strict_parity(wl["cls"], engine_filter, traj, eps0, eps, us, M),
         "teacher_forced": teacher_forced_parity(engine_filter, traj, eps, us, beliefs, want, M),
         "free_running": {
             # both filters run the whole horizon on their own beliefs: a 1e-7 difference in a
@@ -482,6 +536,7 @@ def launch_ranks(n_ranks: int, argv) -> int:
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e))
     rc = 0
     pending = list(procs)
+    kill_at = None  # a rank stuck in a collective or a kernel may ignore SIGTERM: SIGKILL after a grace period
     while pending:
         for p in list(pending):
             code = p.poll()
@@ -492,6 +547,11 @@ def launch_ranks(n_ranks: int, argv) -> int:
                 rc = code
                 for q in pending:  # exact PIDs of our own children only
                     q.terminate()
+                kill_at = time.monotonic() + 10.0
+        if kill_at is not None and time.monotonic() > kill_at:
+            for q in pending:
+                q.kill()
+            kill_at = time.monotonic() + 10.0
         time.sleep(0.05)
     return rc
 
@@ -620,20 +680,23 @@ def main():
         engine.set_kernel_timer(None)
         return distributed.max_over_ranks(dt, device), timer, mse_all, pred
 
-    # Order of the GPU work: the comparison pass in exact-f32 mode and the error study against fp64 come
-    # FIRST, the headline pass last (each pass does its own W warm-up steps and times exactly K): a short
-    # run -- the driver's --steps 20 --warmup 5 is 17 ms of GPU work -- then finds the GPU busy and its
-    # kernels loaded.  (What cost such runs 15-18 % was the kernel timers: one sampled step in K // 16
-    # means EVERY step at K = 20, and an event record is a barrier packet; now 3 sampled steps per pass, 1 under 64.)
-    # the same K steps with exact fp32 products on the f32 MFMA, for comparison (all ranks)
+    # Order of the GPU work: the HEADLINE pass first (its own W warm-up steps, then exactly K timed), then
+    # the comparison pass in exact-f32 mode and the error study against fp64, then -- once, on one GPU -- the
+    # headline pass AGAIN after a 1 s idle, reported beside the first as `pass_order` (round 2 ran the
+    # headline right behind the f32 pass and the fp64 study, on a chip already at its power limit: the same
+    # kernels were 5-8 % slower there than in a pass of their own).  With more than one rank the extras are
+    # skipped: they are rank-0 or all-rank work that is not the metric.
+    elapsed, timer, mse_all, pred_main = timed_pass()
+
+    lean = world > 1
     f32_pass = None
-    if wl["kind"] == "pf" and precision != "f32" and not args.no_f32_mode:
+    if wl["kind"] == "pf" and precision != "f32" and not args.no_f32_mode and not lean:
         engine.set_default_precision("f32")
         f32_pass = timed_pass()
         engine.set_default_precision(precision)
     # arithmetic error of each mode against fp64, at the benchmark's size (rank 0, no collective)
     study = None
-    if rank == 0 and not args.no_precision_study:
+    if rank == 0 and not args.no_precision_study and not lean:
         if wl["kind"] == "pf":
             study = precision_errors(wl, f, traj, B, M, raw_dynamics=build_filter(wl, device).dynamics_model)
         else:
@@ -641,9 +704,12 @@ def main():
             # on an un-stabilised twin: the bench scales the dynamics heads by 2e-3, which hides the
             # networks' error behind the rounding of x + tiny
             study["jacobians"] = jacobian_precision_errors(wl, build_filter(wl, device), traj)
+    second = None
+    if not lean and (f32_pass is not None or study is not None):
+        torch.cuda.synchronize()
+        time.sleep(1.0)
+        second = timed_pass()[0]
     distributed.barrier()
-
-    elapsed, timer, mse_all, pred_main = timed_pass()
 
     total_batch = args.global_batch if args.global_batch else B * world
     units_per_step = total_batch * M if wl["kind"] == "pf" else total_batch
@@ -670,6 +736,10 @@ def main():
                    "world_size_seen": world,
                    "parallelism": f"trajectory-sharded x{world}"},
         "posterior_rmse_vs_truth": [float(x) for x in rmse],
+        "pass_order": None if second is None else {
+            "headline_first_ms_per_step": 1e3 * elapsed / K,
+            "headline_again_after_f32_pass_fp64_study_and_1s_idle_ms_per_step": 1e3 * second / K,
+            "note": "value / ms_per_step are the FIRST pass (W warm-up steps, then K timed)"},
         "traffic_source": "profiles/r02/pmc_hbm_traffic.json, pmc_k4_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                           "separate passes; bytes per launch = 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction)",
     }
@@ -680,7 +750,7 @@ def main():
         default_shape = (args.workload == "door_pf" and B == 256 and M == 4096)
         r = {"kernel": k2_kernel_name(d, prec) + " (measurement network)", "bound": "mfma", "achieved": ach,
              "peak": MFMA_PEAK[prec], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK[prec],
-             "traffic": pmc_traffic(k2_kernel_name(d, "f16x3")) if default_shape else None}
+             "traffic": pmc_traffic(k2_kernel_name(d, prec)) if default_shape else None}
         if prec == "f16x3":
             r["note"] = ("achieved counts ALGORITHMIC fp32 FLOPs; the kernel executes 3 f16 MFMA "
                          "products per algorithmic product (executed-MFMA fraction = 3 x frac)")

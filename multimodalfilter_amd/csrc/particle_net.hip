@@ -260,8 +260,8 @@ __device__ __forceinline__ void split_pair(float x0, float x1, float neg_one, un
   lo = __builtin_bit_cast(unsigned, l);
 }
 
-// Range tracking on the packed hi halves: RTZ saturates at the largest finite f16 (0x7BFF) for
-// every |x| >= 65504, and for non-negative halves the i16 order is the f16 order, so ONE
+// Range tracking on the packed hi halves: round-to-nearest maps every |x| >= 65504 to 0x7BFF or to
+// +inf (0x7C00), both >= the threshold below, and for non-negative halves the i16 order is the f16 order, so ONE
 // v_pk_max_i16 per pair keeps the running maximum (fmaxf on the fp32 values costs 3 ops per
 // pair once canonicalisation is counted).  Negative halves compare below zero and are ignored,
 // which is right after a ReLU; the one split that sees signed values (dynamics trunk entry, no
@@ -695,7 +695,8 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
 
     }
     if constexpr (F16) {
-      // an operand beyond the f16 range saturates the split (finite but wrong): report it
+      // an operand beyond the f16 range breaks the split (round-to-nearest: |x| >= 65520 gives hi = inf,
+      // lo = x - inf = -inf, so the MFMAs produce NaN until the caller's check_range raises): report it
       if (a.range_flag != nullptr && (amax[0] >= kF16Saturated || amax[1] >= kF16Saturated))
         atomicOr(a.range_flag, 1);
     }

@@ -49,6 +49,14 @@ __global__ __launch_bounds__(256) void ukf_sigma_points_kernel(const float* __re
       }
   }
   if (bad && not_pd) atomicOr(not_pd, 1);
+  if (bad) {
+    // not positive definite: reported through *not_pd (the caller raises, once per step or once per
+    // loop); the points collapse onto the mean so the networks downstream see finite, in-range rows
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = 0; j < D; ++j) L[i][j] = 0.f;
+  }
   float m[D];
 #pragma unroll
   for (int i = 0; i < D; ++i) m[i] = mu[static_cast<size_t>(n) * D + i];

@@ -486,7 +486,11 @@ class VirtualSensorExtendedKalmanFilter(base.Filter):
         else:
             mu_pred, L = dyn(initial_states=mu, controls=controls)
             A = dyn.jacobian(initial_states=mu, controls=controls)
-        if engine.use_hip_backward():
+        # K6's Kalman step takes ONE (d, d) process-noise factor and returns no gradient for it: right for
+        # the reference's models (constant Q, requires_grad=False), wrong for a user model whose
+        # scale_tril depends on the state / control or is trainable -- those keep the torch algebra below
+        q_const = (not L.requires_grad) and (L.shape[0] == 1 or bool((L == L[:1]).all()))
+        if engine.use_hip_backward() and q_const:
             # K6: the Kalman algebra forward (K3) and backward (closed-form adjoints) in HIP; the
             # networks around it (sensor, dynamics, Jacobian) keep their autograd form
             self._belief_mean, self._belief_covariance = engine.EkfStepFunction.apply(A, mu_pred, L[0], z, r_tril, Sigma)
@@ -549,10 +553,13 @@ class VirtualSensorExtendedKalmanFilter(base.Filter):
                 return native
             sensors = [self.virtual_sensor_model(observations=tree_index(observations, t)) for t in range(T)]
         out = []
+        not_pd = torch.zeros(1, dtype=torch.int32, device=self._belief_mean.device)  # one flag, one read per loop
         for t in range(T):
             sl = slice(t * N, (t + 1) * N)
             out.append(self._step(tree_index(observations, t), tree_index(controls, t), sensors[t],
-                                  None if ctrl_all is None else {k: v[sl] for k, v in ctrl_all.items()}))
+                                  None if ctrl_all is None else {k: v[sl] for k, v in ctrl_all.items()}, not_pd))
+        if T > 0 and int(not_pd.item()):
+            raise ValueError("unscented predict: belief covariance is not positive definite")
         return torch.stack(out, dim=0)
 
 
@@ -607,7 +614,9 @@ class VirtualSensorUnscentedKalmanFilter(VirtualSensorExtendedKalmanFilter):
         super().__init__(dynamics_model=dynamics_model, virtual_sensor_model=virtual_sensor_model)
         self.sigma_point_strategy = sigma_point_strategy if sigma_point_strategy is not None else JulierSigmaPointStrategy()
 
-    def _unscented_predict(self, controls, ctrl_ctx=None):
+    def _unscented_predict(self, controls, ctrl_ctx=None, not_pd=None):
+        """``not_pd``: a loop-wide device flag (checked by the caller after the loop) -- ``None`` checks
+        this step's own flag right away (one blocking 4-byte read)."""
         dyn = self.dynamics_model
         mu, Sigma = self._belief_mean.contiguous(), self._belief_covariance.contiguous()
         N, d = mu.shape
@@ -615,11 +624,13 @@ class VirtualSensorUnscentedKalmanFilter(VirtualSensorExtendedKalmanFilter):
         lambd = self.sigma_point_strategy.compute_lambda(d)
         wc0, wm0, wi = self.sigma_point_strategy.compute_sigma_weights(d)
         points = torch.empty((N, P, d), dtype=torch.float32, device=mu.device)
-        not_pd = torch.zeros(1, dtype=torch.int32, device=mu.device)
+        own = not_pd is None
+        if own:
+            not_pd = torch.zeros(1, dtype=torch.int32, device=mu.device)
         _abi.ukf_sigma_points(mu, Sigma, math.sqrt(d + lambd), points, not_pd)
-        # checked BEFORE the points go anywhere: the rows of a non-PD belief are not sigma points, and
-        # the networks would be evaluated on them (raising the f16x3 range flag for whoever comes next)
-        if int(not_pd.item()):
+        # a non-PD belief collapses its points onto the mean inside the kernel (finite rows for the
+        # networks); a single step raises here, a forward_loop once after its last step
+        if own and int(not_pd.item()):
             raise ValueError("unscented predict: belief covariance is not positive definite")
         if hasattr(dyn, "propagate_encoded"):
             if ctrl_ctx is None:
@@ -637,11 +648,11 @@ class VirtualSensorUnscentedKalmanFilter(VirtualSensorExtendedKalmanFilter):
         _abi.ukf_moments(moved, wm0, wc0, wi, L, mu_pred, Sigma_pred)
         return mu_pred, Sigma_pred
 
-    def _step(self, observations, controls, sensor_out=None, ctrl_ctx=None):
+    def _step(self, observations, controls, sensor_out=None, ctrl_ctx=None, not_pd=None):
         assert self._initialized, "Kalman filter not initialized!"
         with torch.no_grad():
             z, r_tril = sensor_out if sensor_out is not None else self.virtual_sensor_model(observations=observations)
-            mu_pred, Sigma_pred = self._unscented_predict(controls, ctrl_ctx)
+            mu_pred, Sigma_pred = self._unscented_predict(controls, ctrl_ctx, not_pd)
             N, d = mu_pred.shape
             eye = torch.eye(d, dtype=torch.float32, device=mu_pred.device)[None].expand(N, d, d).contiguous()
             mu = torch.empty((1, N, d), dtype=torch.float32, device=mu_pred.device)
@@ -674,8 +685,11 @@ class VirtualSensorUnscentedKalmanFilter(VirtualSensorExtendedKalmanFilter):
             else:
                 sensors = [self.virtual_sensor_model(observations=tree_index(observations, t)) for t in range(T)]
         out = []
+        not_pd = torch.zeros(1, dtype=torch.int32, device=self._belief_mean.device)  # one flag, one read per loop
         for t in range(T):
             sl = slice(t * N, (t + 1) * N)
             out.append(self._step(tree_index(observations, t), tree_index(controls, t), sensors[t],
-                                  None if ctrl_all is None else {k: v[sl] for k, v in ctrl_all.items()}))
+                                  None if ctrl_all is None else {k: v[sl] for k, v in ctrl_all.items()}, not_pd))
+        if T > 0 and int(not_pd.item()):
+            raise ValueError("unscented predict: belief covariance is not positive definite")
         return torch.stack(out, dim=0)

@@ -472,7 +472,12 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             if self.noise_R_tril is not None:
                 # a fixed measurement noise replaces the r head's output (kf.py:36-37,111-126): the
                 # reference feeds it through the same diag_embed / square / + add_R_noise / sqrt
-                lt = torch.diag_embed(self.noise_R_tril.to(device=dev, dtype=torch.float32))
+                fixed = self.noise_R_tril.to(device=dev, dtype=torch.float32)
+                if fixed.shape[0] != N and fixed.shape[0] > 0 and N % fixed.shape[0] == 0:
+                    # a forward_loop evaluates the sensor on the T*N flattened rows (row t*N + n): the
+                    # per-trajectory fixed noise repeats T times (the reference steps row by row)
+                    fixed = fixed.repeat(N // fixed.shape[0], 1)
+                lt = torch.diag_embed(fixed)
                 assert lt.shape == (N, d, d)
                 cov = lt ** 2
                 if self.add_R_noise[0] > 0:
