@@ -553,13 +553,10 @@ class VirtualSensorExtendedKalmanFilter(base.Filter):
                 return native
             sensors = [self.virtual_sensor_model(observations=tree_index(observations, t)) for t in range(T)]
         out = []
-        not_pd = torch.zeros(1, dtype=torch.int32, device=self._belief_mean.device)  # one flag, one read per loop
         for t in range(T):
             sl = slice(t * N, (t + 1) * N)
             out.append(self._step(tree_index(observations, t), tree_index(controls, t), sensors[t],
-                                  None if ctrl_all is None else {k: v[sl] for k, v in ctrl_all.items()}, not_pd))
-        if T > 0 and int(not_pd.item()):
-            raise ValueError("unscented predict: belief covariance is not positive definite")
+                                  None if ctrl_all is None else {k: v[sl] for k, v in ctrl_all.items()}))
         return torch.stack(out, dim=0)
 
 
