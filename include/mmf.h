@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 24
+#define MMF_ABI_VERSION 25
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -364,6 +364,20 @@ typedef struct MmfPfLoopArgs {
 } MmfPfLoopArgs;             /* host struct holding device pointers                           */
 
 int mmf_pf_forward_loop(const MmfPfLoopArgs* args /* host */, void* stream);
+
+/* Open-loop rollout of the dynamics model: replaces torchfilter's DynamicsModel.forward_loop (external
+ * dependency; call sites crossmodal/eval_helpers.py:135-137, scripts/door_task/eval_dynamics.py:36-38):
+ *     x_t = f(x_{t-1}, u_t),  t = 1 .. T      (no process noise: the mean prediction)
+ * as T launches of the K2 dynamics kernel enqueued by one C call, each reading the previous step's row
+ * of the output.
+ *  packed     packed dynamics network (mmf_pack_particle_net)
+ *  x0         (N, d) initial states
+ *  traj_bias  (T, N, 64) hoisted control term of every step (one K7 launch over the T*N controls)
+ *  out        (T, N, d) predicted states
+ */
+int mmf_dynamics_forward_loop(const float* packed, int n_res, int precision, const float* x0,
+                              const float* traj_bias, float* out, int32_t* range_flag, int T, int N, int d,
+                              void* stream);
 
 /* ---------------------------------------------------------------- K7: per-trajectory MLP programs
  * The N-row networks around the filters (vector encoders layers.py:11-40,66-95; PF weight

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 24
+ABI_VERSION = 25
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
@@ -101,6 +101,7 @@ SIGNATURES = {
     "mmf_pf_reweight_backward": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_init_particles": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_forward_loop": (c_int, [POINTER(MmfPfLoopArgs), c_void_p]),
+    "mmf_dynamics_forward_loop": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_traj_program": (c_int, [_FP, c_int, _FP, POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
     "mmf_fuse_virtual_sensors": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_ekf_forward_loop": (c_int, [POINTER(MmfEkfLoopArgs), c_void_p]),
@@ -216,6 +217,13 @@ def pf_dynamics(packed, n_res, precision, states_in, traj_bias, noise, scale_tri
                                       ptr(scale_tril), ptr(states_out),
                                       ptr(range_flag, dtype=torch.int32), N, M, d,
                                       stream_of(states_in)), "mmf_pf_dynamics")
+
+
+def dynamics_forward_loop(packed, n_res, precision, x0, traj_bias, out, range_flag, T, N, d):
+    with _on(x0):
+        _check(load().mmf_dynamics_forward_loop(ptr(packed), n_res, precision, ptr(x0), ptr(traj_bias), ptr(out),
+                                                ptr(range_flag, dtype=torch.int32), T, N, d, stream_of(x0)),
+               "mmf_dynamics_forward_loop")
 
 
 def pf_measure(packed, n_res, precision, states, traj_bias, modality_logw, logw_stride, loglik, combine,

@@ -78,3 +78,21 @@ extern "C" int mmf_pf_forward_loop(const MmfPfLoopArgs* a, void* stream) {
     *a->final_location = (cur == a->states_b ? 1 : 0) | (lw_cur == a->logw_b ? 2 : 0);
   return 0;
 }
+
+// Open-loop rollout x_t = f(x_{t-1}, u_t): replaces torchfilter's DynamicsModel.forward_loop (call
+// sites /root/reference/crossmodal/eval_helpers.py:135-137, scripts/door_task/eval_dynamics.py:36-38).
+extern "C" int mmf_dynamics_forward_loop(const float* packed, int n_res, int precision, const float* x0,
+                                         const float* traj_bias, float* out, int32_t* range_flag, int T, int N,
+                                         int d, void* stream) {
+  if (!packed || !x0 || !traj_bias || !out || T < 0 || N < 1) return MMF_EINVAL;
+  const size_t row = static_cast<size_t>(N);
+  const float* cur = x0;
+  for (int t = 0; t < T; ++t) {
+    float* nxt = out + t * row * d;
+    const int rc = mmf_pf_dynamics(packed, n_res, precision, cur, traj_bias + t * row * MMF_UNITS, nullptr, nullptr,
+                                   nxt, range_flag, N, 1, d, stream);
+    if (rc) return rc;
+    cur = nxt;
+  }
+  return 0;
+}

@@ -214,6 +214,24 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
                                           None, None)
             return new, self.scale_tril()[None, :, :].expand(N, state_dim, state_dim)
 
+        def forward_loop(self, *, initial_states, controls):
+            """Open-loop rollout (``eval_helpers.py:135-137``): the control encoder for all ``T*N`` rows in one
+            K7 launch, then ``mmf_dynamics_forward_loop`` -- one C call enqueuing the ``T`` K2 launches."""
+            if engine.use_autograd(self) or not torch.is_tensor(controls):
+                return base.DynamicsModel.forward_loop(self, initial_states=initial_states, controls=controls)
+            T, N = controls.shape[:2]
+            d = self.state_dim
+            assert initial_states.shape == (N, d)
+            with torch.no_grad():
+                bias = self.encode_controls(controls.reshape(T * N, -1))["bias"]
+                out = torch.empty((T, N, d), dtype=torch.float32, device=controls.device)
+                engine.clear_range(out.device)
+                _abi.dynamics_forward_loop(self._net.blob(), self._net.n_res, self._net.precision_code(),
+                                           initial_states.to(torch.float32).contiguous(), bias, out,
+                                           engine.range_flag(out.device), T, N, d)
+                engine.check_range(out.device)
+            return out, self.scale_tril()[None, None].expand(T, N, d, d)
+
         def jacobian(self, *, initial_states, controls):
             if engine.use_autograd(self):
                 return base.DynamicsModel.jacobian(self, initial_states=initial_states, controls=controls)

@@ -227,6 +227,7 @@ def test_particle_filter_tracks_oracle(tname, kind, cls, mode):
     ("door", "DoorCrossmodalKalmanFilter", {}),
     ("push", "PushCrossmodalKalmanFilter", {"feedback": "belief", "fix_weight_layout": True}),
     ("push", "PushUnimodalKalmanFilter", {}),
+    ("door", "DoorUnimodalKalmanFilter", {}),     # BASELINE config 1 itself: door unimodal EKF, batch 32
 ])
 def test_kalman_filters_track_oracle(tname, cls, okw):
     """EKF recursions, N=32 (config 1's batch), T=6: means and covariances within 1e-4."""
@@ -356,6 +357,46 @@ def test_native_ekf_loop_equals_stepwise(cls, kw, masked):
         assert torch.equal(f.weighted_covariances, wc)
 
 
+@pytest.mark.parametrize("tname", ["door", "push"])
+def test_dynamics_forward_loop_native_rollout(tname):
+    """``DynamicsModel.forward_loop`` (``/root/reference/crossmodal/eval_helpers.py:135-137``): the native
+    rollout (one K7 launch over the T*N controls + ``mmf_dynamics_forward_loop``) equals T separate
+    ``forward`` calls bit for bit and the oracle's rollout to 1e-4."""
+    _need_gpu()
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import _abi
+
+    dev = torch.device("cuda:0")
+    task = om.TASKS[tname]
+    d, N, T = task.state_dim, 37, 9
+    g = torch.Generator().manual_seed(3)
+    ctrl = torch.randn((T, N, 7), generator=g)
+    x0 = torch.randn((N, d), generator=g)
+    o = om.DynamicsModel(task)
+    o.load_state_dict(om.seeded_state_dict(o, seed=2, gain=1.0))
+    o.eval()
+    with torch.no_grad():
+        want, want_tril = o.forward_loop(initial_states=x0, controls=ctrl)
+    e = mmf.model_types(tname)[f"{tname.capitalize()}KalmanFilter"]().dynamics_model
+    e.load_state_dict(o.state_dict())
+    e.to(dev).eval()
+    calls = []
+    real = _abi.dynamics_forward_loop
+    _abi.dynamics_forward_loop = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        got, tril = e.forward_loop(initial_states=x0.to(dev), controls=ctrl.to(dev))
+    finally:
+        _abi.dynamics_forward_loop = real
+    assert calls, "the built-in dynamics models roll out natively"
+    x, steps = x0.to(dev), []
+    for t in range(T):
+        x, _ = e(initial_states=x, controls=ctrl[t].to(dev))
+        steps.append(x)
+    assert torch.equal(got, torch.stack(steps))
+    assert float((got.cpu() - want).abs().max()) / max(1.0, float(want.abs().max())) < REL_TOL
+    assert tril.shape == want_tril.shape and float((tril.cpu() - want_tril).abs().max()) < 1e-7
+
+
 @pytest.mark.parametrize("kind", ["ekf", "ukf", "crossmodal"])
 def test_fixed_measurement_noise_in_forward_loops(kind):
     """``noise_R_tril`` (``/root/reference/crossmodal/door_models/kf.py:36-37,111-126``: a fixed ``(N, d)``
@@ -400,11 +441,12 @@ def test_fixed_measurement_noise_in_forward_loops(kind):
         assert float((loop.cpu() - want).abs().max()) / max(1.0, float(want.abs().max())) < REL_TOL
 
 
-@pytest.mark.parametrize("tname,cls,N", [("door", "DoorCrossmodalParticleFilter", 256),
-                                         ("push", "PushCrossmodalParticleFilter", 1024)])
-def test_full_size_particle_filter_properties(tname, cls, N):
-    """BASELINE.json's headline shape (door crossmodal PF, 256 x 4096 particles) and config 3 (push
-    crossmodal PF, 1024 x 4096, resample-bound), 3 steps: the
+@pytest.mark.parametrize("tname,cls,N,M", [("door", "DoorCrossmodalParticleFilter", 256, 4096),
+                                           ("door", "DoorCrossmodalParticleFilter", 256, 1024),
+                                           ("push", "PushCrossmodalParticleFilter", 1024, 4096)])
+def test_full_size_particle_filter_properties(tname, cls, N, M):
+    """BASELINE.json's headline shape (door crossmodal PF, 256 x 4096 particles), config 2 at its own
+    size (256 x 1024) and config 3 (push crossmodal PF, 1024 x 4096, resample-bound), 3 steps: the
     native step loop equals step-by-step evaluation bit for bit; after resampling the log-weights
     are exactly -log M, every estimate lies inside its particles' bounding box before resampling,
     and every resampled particle is one of the propagated ones (ancestor indices in range and
@@ -416,7 +458,7 @@ def test_full_size_particle_filter_properties(tname, cls, N):
     from multimodalfilter_amd import synthetic
 
     dev = torch.device("cuda:0")
-    M, d, T = 4096, om.TASKS[tname].state_dim, 3
+    d, T = om.TASKS[tname].state_dim, 3
     traj = {k: v.to(dev) for k, v in synthetic.make_trajectories(state_dim=d, T=T, N=N, seed=5).items()}
     eps0, eps, us = synthetic.draw_filter_noise(T=T, N=N, M=M, state_dim=d, seed=6)
     eps0, eps, us = eps0.to(dev), torch.stack(eps).to(dev), torch.stack(us).to(dev)
