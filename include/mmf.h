@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 25
+#define MMF_ABI_VERSION 26
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -361,9 +361,15 @@ typedef struct MmfPfLoopArgs {
   float* loglik_steps;       /* (T, N, M) or null: step t's fused log-likelihoods are kept here  */
                              /* instead of the shared `loglik` scratch (parity certificates)     */
   int32_t* indices_steps;    /* (T, N, M) int32 or null: ancestors drawn at every resampling step */
+  int32_t use_graph;         /* != 0 (and events == null): capture the loop's launches on `stream` into a   */
+                             /* hipGraph and launch that instead (A/B switch; the executable graph is kept  */
+                             /* by the library until its launch has completed -- mmf_loop_graphs_release)   */
 } MmfPfLoopArgs;             /* host struct holding device pointers                           */
 
 int mmf_pf_forward_loop(const MmfPfLoopArgs* args /* host */, void* stream);
+
+/* Waits for and frees every executable graph a use_graph loop left behind (process shutdown, tests). */
+void mmf_loop_graphs_release(void);
 
 /* Open-loop rollout of the dynamics model: replaces torchfilter's DynamicsModel.forward_loop (external
  * dependency; call sites crossmodal/eval_helpers.py:135-137, scripts/door_task/eval_dynamics.py:36-38):

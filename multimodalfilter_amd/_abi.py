@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 25
+ABI_VERSION = 26
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
@@ -64,7 +64,8 @@ class MmfPfLoopArgs(Structure):
                 ("states_a", _FP), ("states_b", _FP), ("logw_a", _FP), ("logw_b", _FP),
                 ("loglik", _FP), ("estimates", _FP), ("range_flag", _FP),
                 ("final_location", POINTER(c_int32)), ("events", POINTER(c_void_p)),
-                ("event_stride", c_int32), ("loglik_steps", _FP), ("indices_steps", _FP)]
+                ("event_stride", c_int32), ("loglik_steps", _FP), ("indices_steps", _FP),
+                ("use_graph", c_int32)]
 
 
 class MmfEkfLoopArgs(Structure):
@@ -101,6 +102,7 @@ SIGNATURES = {
     "mmf_pf_reweight_backward": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_init_particles": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_forward_loop": (c_int, [POINTER(MmfPfLoopArgs), c_void_p]),
+    "mmf_loop_graphs_release": (None, []),
     "mmf_dynamics_forward_loop": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_traj_program": (c_int, [_FP, c_int, _FP, POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
     "mmf_fuse_virtual_sensors": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),

@@ -5,9 +5,12 @@
 // fused models: no interpreter work, tensor allocation or pointer marshalling between steps,
 // so small problems (the reference's own evaluation: a few dozen trajectories x 300
 // particles) are bound by kernel time instead of ~0.15 ms/step of host overhead.
+#include <mutex>
+#include <vector>
+
 #include "mmf_common.h"
 
-extern "C" int mmf_pf_forward_loop(const MmfPfLoopArgs* a, void* stream) {
+static int pf_enqueue_steps(const MmfPfLoopArgs* a, void* stream, bool with_events) {
   if (!a) return MMF_EINVAL;
   if (a->T < 0 || a->N < 1 || a->M < 1 || a->n_meas < 1 || a->n_meas > MMF_LOOP_MAX_MEAS) return MMF_EINVAL;
   if (a->resample_mode < 0 || a->resample_mode > 2) return MMF_EINVAL;
@@ -26,7 +29,7 @@ extern "C" int mmf_pf_forward_loop(const MmfPfLoopArgs* a, void* stream) {
   const int stride = a->event_stride > 1 ? a->event_stride : 1;
   bool sampled = false;  // an event record costs a barrier packet: long loops sample every stride-th step
   auto mark = [&]() {
-    if (sampled) {
+    if (sampled && with_events) {
       hipError_t e = hipEventRecord(static_cast<hipEvent_t>(a->events[ev++]), hs);
       if (e != hipSuccess) return static_cast<int>(e);
     }
@@ -78,6 +81,62 @@ extern "C" int mmf_pf_forward_loop(const MmfPfLoopArgs* a, void* stream) {
     *a->final_location = (cur == a->states_b ? 1 : 0) | (lw_cur == a->logw_b ? 2 : 0);
   return 0;
 }
+
+
+// ---- optional hipGraph replay of a whole loop (MmfPfLoopArgs.use_graph): the T x (2 + n_meas) launches are
+// captured on the caller's stream, instantiated and launched as ONE graph.  An executable graph has to
+// outlive its launch, so finished ones are reaped at the next call (an event marks completion).
+namespace {
+struct PendingGraph { hipGraphExec_t exec; hipGraph_t graph; hipEvent_t done; };
+std::vector<PendingGraph>& pending_graphs() { static std::vector<PendingGraph> v; return v; }
+std::mutex& pending_mutex() { static std::mutex m; return m; }
+
+void reap_graphs(bool wait) {
+  std::lock_guard<std::mutex> lock(pending_mutex());
+  auto& v = pending_graphs();
+  for (size_t i = 0; i < v.size();) {
+    if (wait) (void)hipEventSynchronize(v[i].done);
+    if (hipEventQuery(v[i].done) == hipSuccess) {
+      (void)hipGraphExecDestroy(v[i].exec);
+      (void)hipGraphDestroy(v[i].graph);
+      (void)hipEventDestroy(v[i].done);
+      v[i] = v.back();
+      v.pop_back();
+    } else {
+      ++i;
+    }
+  }
+}
+
+template <class F>
+int run_as_graph(hipStream_t hs, F&& enqueue) {
+  reap_graphs(false);
+  hipError_t e = hipStreamBeginCapture(hs, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) return static_cast<int>(e);
+  const int rc = enqueue();
+  hipGraph_t graph = nullptr;
+  e = hipStreamEndCapture(hs, &graph);
+  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (e != hipSuccess) return static_cast<int>(e);
+  PendingGraph p{};
+  p.graph = graph;
+  if ((e = hipGraphInstantiate(&p.exec, graph, nullptr, nullptr, 0)) != hipSuccess) { (void)hipGraphDestroy(graph); return static_cast<int>(e); }
+  if ((e = hipGraphLaunch(p.exec, hs)) != hipSuccess) return static_cast<int>(e);
+  if ((e = hipEventCreateWithFlags(&p.done, hipEventDisableTiming)) != hipSuccess) return static_cast<int>(e);
+  if ((e = hipEventRecord(p.done, hs)) != hipSuccess) return static_cast<int>(e);
+  std::lock_guard<std::mutex> lock(pending_mutex());
+  pending_graphs().push_back(p);
+  return 0;
+}
+}  // namespace
+
+extern "C" int mmf_pf_forward_loop(const MmfPfLoopArgs* a, void* stream) {
+  if (a && a->use_graph && !a->events)
+    return run_as_graph(static_cast<hipStream_t>(stream), [&] { return pf_enqueue_steps(a, stream, false); });
+  return pf_enqueue_steps(a, stream, true);
+}
+
+extern "C" void mmf_loop_graphs_release(void) { reap_graphs(true); }
 
 // Open-loop rollout x_t = f(x_{t-1}, u_t): replaces torchfilter's DynamicsModel.forward_loop (call
 // sites /root/reference/crossmodal/eval_helpers.py:135-137, scripts/door_task/eval_dynamics.py:36-38).

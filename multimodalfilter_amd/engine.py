@@ -135,6 +135,11 @@ def image_encoder_precision_code() -> int:
     return _abi.IMAGE_PRECISIONS[IMAGE_ENCODER_PRECISION or DEFAULT_PRECISION]
 
 
+# hipGraph replay of the native particle-filter step loop (A/B switch, off by default: at the reference's
+# evaluation size the launches enqueued from C already keep the GPU 93 % busy -- DESIGN.md, T3)
+LOOP_GRAPH = os.environ.get("MMF_LOOP_GRAPH", "0") not in ("", "0")
+
+
 # Training is opt-in: nothing switches paths silently, and eval() always means the forward-only HIP
 # path.  With a training backend set, modules in train() mode evaluate differentiably:
 #   "hip"       the N*M-row work (per-particle dynamics / measurement networks: ParticleNetFunction;

@@ -328,6 +328,7 @@ class ParticleFilter(base.Filter):
                 self.last_resample_indices = torch.empty((T, N, M), dtype=torch.int32, device=dev)
                 a.indices_steps = ctypes.c_void_p(_abi.ptr(self.last_resample_indices, dtype=torch.int32))
         a.range_flag = ctypes.c_void_p(engine.range_flag(dev).data_ptr())
+        a.use_graph = int(engine.LOOP_GRAPH)
         timer = engine.kernel_timer()
         events = None
         names = ["particle_net_dynamics"] + ["particle_net_measure"] * len(nets) + ["pf_reweight_resample"]
