@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 26
+#define MMF_ABI_VERSION 27
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -231,6 +231,11 @@ int mmf_particle_net_train_backward(const float* packed_t, const float* head_w, 
 int mmf_particle_net_weight_grads(const float* dz, const float* stash, float* partial_w,
                                   float* partial_b, int n_layers, int R, int n_splits, void* stream);
 
+/* The same, ADDING into the caller's partial sums when accumulate != 0 (each (layer, split) block of the
+ * partials belongs to one workgroup: no atomics) -- the native training loop sums over time steps in place. */
+int mmf_particle_net_weight_grads_acc(const float* dz, const float* stash, float* partial_w, float* partial_b,
+                                      int n_layers, int R, int n_splits, int accumulate, void* stream);
+
 /* The narrow reductions of the same backward in one pass over the rows (as GEMMs they are the
  * library's worst shapes, as torch reductions five passes over (R, 64) tensors):
  *   first layer   dW0[c][i]  = sum_r dz_first[r][c] states[r][i]          (64, d)
@@ -384,6 +389,84 @@ void mmf_loop_graphs_release(void);
 int mmf_dynamics_forward_loop(const float* packed, int n_res, int precision, const float* x0,
                               const float* traj_bias, float* out, int32_t* range_flag, int T, int N, int d,
                               void* stream);
+
+/* ---------------------------------------------------------------- K6: the particle filter's training recursion
+ * One C call for the forward recursion of a train-mode (no resampling) particle filter over T steps and
+ * one for its backward -- the caller /root/reference/crossmodal/train_helpers.py:124-162
+ * (torchfilter.train.train_filter: forward_loop over a subsequence, MSE, backward) at any size, including
+ * the reference's own 32 x 30 particles x 16 steps where per-launch host work dominates.
+ *
+ * forward (per step t):  x_t = f(x_{t-1}) + L eps_t  (K2 dynamics);  ll = logsumexp_k(ll_k(x_t) + beta_k)
+ *   (K2 measurement);  logw_t = logw_{t-1} + ll - logsumexp,  est_t = sum_m exp(logw_t) x_t  (K1 mode 0).
+ *   Only the particle sets states (T+1, N, M, d) and log-weights logw (T+1, N, M) are kept.
+ * backward (t = T-1 .. 0): the K6 kernels on RECOMPUTED activations -- the step's stashes are rebuilt by
+ *   mmf_particle_net_train_forward from states[t] / states[t+1] for `chunk_traj` trajectories at a time,
+ *   into ONE reused pair of buffers sized to stay inside the 256 MiB Infinity Cache (stash -> backward data
+ *   path -> weight-gradient GEMM hand-offs are then served on-die); weight-gradient partials accumulate in
+ *   place over steps and chunks.  Peak memory: the two chunk buffers + (T+1) particle sets.
+ *
+ * Buffers (device, fp32, caller-owned).  K = n_meas networks (modalities), NLd = 3 + 2 n_res_dyn, NLm likewise.
+ *  in:   dyn_* / meas_*[k]: packed      forward blob (mmf_pack_particle_net, `precision` for the forward pass),
+ *                           packed_f32  exact-f32 blob (recompute), packed_t  blob of the transposed layers,
+ *                           head_w (n_out, 64)
+ *        dyn_bias (T, N, 64), meas_bias[k] (T, N, 64), meas_logw[k] = &beta[0][0][k] of a (T, N, logw_stride)
+ *        array or null, noise (T, N, M, d), scale_tril (d, d), g_estimates (T, N, d)  [backward]
+ *  io:   states (T+1, N, M, d), logw (T+1, N, M): slot 0 = initial belief (caller), slot t+1 = after step t
+ *  out:  estimates (T, N, d)  [forward]
+ *        backward: d_states0 (N, M, d), d_logw0 (N, M);
+ *        per network: pw (NL+1, n_splits, 64, 64), pb (NL+1, n_splits, 64) weight / bias partials summed over
+ *        steps; p_first (T, N n_slices, 64, 4), p_head (T, N n_slices, 4, 64), p_dout (T, N n_slices, 4),
+ *        p_traj (T, N n_slices, 64): the narrow reductions per step (the caller adds slices / steps;
+ *        d traj_bias[t][n] = sum_s p_traj[t][n][s], d beta_k[t][n] = sum_s p_dout_k[t][n][s][0])
+ *  kept:  ll_steps (T, K, N, M) per-modality log-likelihoods ll_k = raw_k + b_k + beta_k of every step
+ *  scratch: stash, dz (max(NLd, NLm) + 1, chunk_traj M, 64); raw (chunk_traj M, 8); d_raw (chunk_traj M, 8);
+ *        loglik (N, M); g_states_a, g_states_b (N, M, d); g_logw_a, g_logw_b (N, M); d_tmp (chunk_traj M, d)
+ */
+typedef struct MmfTrainNet {
+  const float* packed;      /* forward pass blob                                   */
+  const float* packed_f32;  /* recompute blob (MMF_PREC_F32)                        */
+  const float* packed_t;    /* transposed layers (backward data path)              */
+  const float* head_w;      /* (n_out, 64)                                         */
+  float* pw;                /* (NL+1, n_splits, 64, 64)                             */
+  float* pb;                /* (NL+1, n_splits, 64)                                 */
+  float* p_first;           /* (T, N n_slices, 64, 4)                               */
+  float* p_head;            /* (T, N n_slices, 4, 64)                               */
+  float* p_dout;            /* (T, N n_slices, 4)                                   */
+  float* p_traj;            /* (T, N n_slices, 64)                                  */
+} MmfTrainNet;
+
+typedef struct MmfPfTrainArgs {
+  int32_t T, N, M, d, n_meas, n_res_dyn, n_res_meas, logw_stride, precision;
+  int32_t chunk_traj, n_splits, n_slices;
+  MmfTrainNet dyn;
+  MmfTrainNet meas[MMF_LOOP_MAX_MEAS];
+  const float* dyn_bias;
+  const float* meas_bias[MMF_LOOP_MAX_MEAS];
+  const float* meas_logw[MMF_LOOP_MAX_MEAS];
+  const float* noise;
+  const float* scale_tril;
+  const float* g_estimates;
+  float* states;
+  float* logw;
+  float* estimates;
+  float* d_states0;
+  float* d_logw0;
+  float* stash;
+  float* dz;
+  float* raw;
+  float* d_raw;
+  float* loglik;
+  float* ll_steps;           /* (T, K, N, M): every step's per-modality log-likelihoods (forward -> backward) */
+  float* g_states_a;
+  float* g_states_b;
+  float* g_logw_a;
+  float* g_logw_b;
+  float* d_tmp;
+  int32_t* range_flag;
+} MmfPfTrainArgs;
+
+int mmf_pf_train_forward(const MmfPfTrainArgs* args /* host */, void* stream);
+int mmf_pf_train_backward(const MmfPfTrainArgs* args /* host */, void* stream);
 
 /* ---------------------------------------------------------------- K7: per-trajectory MLP programs
  * The N-row networks around the filters (vector encoders layers.py:11-40,66-95; PF weight

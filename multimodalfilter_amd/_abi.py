@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 26
+ABI_VERSION = 27
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
@@ -68,6 +68,24 @@ class MmfPfLoopArgs(Structure):
                 ("use_graph", c_int32)]
 
 
+class MmfTrainNet(Structure):
+    _fields_ = [("packed", _FP), ("packed_f32", _FP), ("packed_t", _FP), ("head_w", _FP), ("pw", _FP), ("pb", _FP),
+                ("p_first", _FP), ("p_head", _FP), ("p_dout", _FP), ("p_traj", _FP)]
+
+
+class MmfPfTrainArgs(Structure):
+    _fields_ = [("T", c_int32), ("N", c_int32), ("M", c_int32), ("d", c_int32), ("n_meas", c_int32),
+                ("n_res_dyn", c_int32), ("n_res_meas", c_int32), ("logw_stride", c_int32), ("precision", c_int32),
+                ("chunk_traj", c_int32), ("n_splits", c_int32), ("n_slices", c_int32),
+                ("dyn", MmfTrainNet), ("meas", MmfTrainNet * LOOP_MAX_MEAS),
+                ("dyn_bias", _FP), ("meas_bias", _FP * LOOP_MAX_MEAS), ("meas_logw", _FP * LOOP_MAX_MEAS),
+                ("noise", _FP), ("scale_tril", _FP), ("g_estimates", _FP),
+                ("states", _FP), ("logw", _FP), ("estimates", _FP), ("d_states0", _FP), ("d_logw0", _FP),
+                ("stash", _FP), ("dz", _FP), ("raw", _FP), ("d_raw", _FP), ("loglik", _FP), ("ll_steps", _FP),
+                ("g_states_a", _FP), ("g_states_b", _FP), ("g_logw_a", _FP), ("g_logw_b", _FP), ("d_tmp", _FP),
+                ("range_flag", _FP)]
+
+
 class MmfEkfLoopArgs(Structure):
     _fields_ = [("T", c_int32), ("N", c_int32), ("d", c_int32), ("K", c_int32),
                 ("fusion", c_int32), ("feedback", c_int32), ("n_res_dyn", c_int32), ("precision", c_int32),
@@ -112,6 +130,9 @@ SIGNATURES = {
     "mmf_particle_net_train_forward": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_particle_net_weight_grads": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_particle_net_small_grads": (c_int, [_FP] * 9 + [c_int] * 5 + [c_void_p]),
+    "mmf_particle_net_weight_grads_acc": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmf_pf_train_forward": (c_int, [POINTER(MmfPfTrainArgs), c_void_p]),
+    "mmf_pf_train_backward": (c_int, [POINTER(MmfPfTrainArgs), c_void_p]),
     "mmf_particle_net_train_backward": (c_int, [_FP, _FP, c_int, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_image_encoder_floats": (c_size_t, []),
     "mmf_image_encoder_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -333,6 +354,16 @@ def particle_net_small_grads(dz_first, dz_join, h_last, states, d_out, p_first, 
                                                    ptr(p_first), ptr(p_head), ptr(p_dout), ptr(p_traj), N, M,
                                                    states.shape[1], d_out.shape[1], n_slices, stream_of(dz_first)),
                "mmf_particle_net_small_grads")
+
+
+def pf_train_forward(args: MmfPfTrainArgs, like: torch.Tensor):
+    with _on(like):
+        _check(load().mmf_pf_train_forward(ctypes.byref(args), stream_of(like)), "mmf_pf_train_forward")
+
+
+def pf_train_backward(args: MmfPfTrainArgs, like: torch.Tensor):
+    with _on(like):
+        _check(load().mmf_pf_train_backward(ctypes.byref(args), stream_of(like)), "mmf_pf_train_backward")
 
 
 def fuse_virtual_sensors(z, tril, w, z_out, tril_out, mode: int):

@@ -112,6 +112,22 @@ class CrossmodalParticleFilterMeasurementModel(base.ParticleFilterMeasurementMod
                 out.append((net, bias, None if beta is None else beta.view(-1)[i:]))
         return out, K
 
+    def train_plan(self, ctx):
+        """Enabled unimodal networks for the native training recursion (``engine.PfTrainLoopFunction``):
+        ``([(network, column of beta | None)], [hoisted bias (R, 64)], beta (R, K) | None, K)``; ``None`` when a
+        unimodal model is not a fused network.  ``ctx`` comes from ``encode_observations_autograd``."""
+        if ctx is None or not all(hasattr(m, "_net") and hasattr(m, "train_plan") for m in self.measurement_models):
+            return None
+        beta = ctx.get("modality_log_weights")
+        nets, biases = [], []
+        for i, m in enumerate(self.measurement_models):
+            if self._enabled_models[i]:
+                nets.append((m._net, i if beta is not None else None))
+                biases.append(ctx[f"m{i}.bias"])
+        if not nets:
+            return None
+        return nets, biases, beta, self._num_models()
+
     def forward_encoded(self, states: torch.Tensor, ctx) -> torch.Tensor:
         N, M, _ = states.shape
         loglik = torch.empty((N, M), dtype=torch.float32, device=states.device)

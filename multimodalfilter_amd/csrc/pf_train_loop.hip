@@ -1,0 +1,226 @@
+// K6, native recursion: forward and backward of a train-mode (no resampling) particle filter over T
+// steps, each as ONE C call that enqueues every kernel on the caller's stream.
+//
+// Replaces torch autograd through torchfilter's ParticleFilter.forward_loop as the reference trains
+// it (/root/reference/crossmodal/train_helpers.py:124-162 -> torchfilter.train.train_filter; sizes
+// scripts/door_task/train_door.py:63-71: batch 32, 30 particles, subsequences of 16): at that size a
+// step of the torch formulation is ~7,000 tiny launches; here it is ~20 per time step, and the
+// gradient sums over time steps happen in place on the device.
+//
+// Memory / traffic design (MI355X): the forward keeps only the particle sets and log-weights.  The
+// backward RECOMPUTES each step's layer inputs (mmf_particle_net_train_forward) for a chunk of
+// trajectories into one reused stash buffer, runs the transposed network over it
+// (mmf_particle_net_train_backward) and reduces the weight gradients (mmf_particle_net_weight_grads_acc)
+// before the next chunk overwrites the buffers: with the chunk sized so that stash + dz stay below the
+// 256 MiB Infinity Cache, the three kernels hand their (rows, 64) activations over on-die instead of
+// through HBM (5 KB per particle and network call in round 2), and peak memory no longer grows with T.
+#include "mmf_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// loglik = logsumexp_k ll_k        (ll_k = raw_k + b_k + beta_k, written by the measurement kernels)
+__global__ __launch_bounds__(kThreads) void combine_fwd_kernel(const float* __restrict__ ll, float* __restrict__ out, int K,
+                                                               size_t R) {
+  const size_t r = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (r >= R) return;
+  float m = -INFINITY;
+  for (int k = 0; k < K; ++k) m = fmaxf(m, ll[k * R + r]);
+  if (m == -INFINITY) { out[r] = m; return; }
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s += expf(ll[k * R + r] - m);
+  out[r] = m + logf(s);
+}
+
+// d ll_k = d loglik * softmax_k(ll)      rows [r0, r0 + C) of the (K, R) array -> d_raw (K, C)
+__global__ __launch_bounds__(kThreads) void combine_bwd_kernel(const float* __restrict__ ll, const float* __restrict__ d_a,
+                                                               float* __restrict__ d_raw, int K, size_t R, size_t r0,
+                                                               size_t C) {
+  const size_t c = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (c >= C) return;
+  const size_t r = r0 + c;
+  float m = -INFINITY;
+  for (int k = 0; k < K; ++k) m = fmaxf(m, ll[k * R + r]);
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s += (m == -INFINITY) ? 1.f : expf(ll[k * R + r] - m);
+  const float g = d_a[r] / s;
+  for (int k = 0; k < K; ++k) d_raw[k * C + c] = (m == -INFINITY) ? g : g * expf(ll[k * R + r] - m);
+}
+
+// dst[i] = a[i] (+ b[i])
+__global__ __launch_bounds__(kThreads) void sum2_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ dst, size_t n) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (i < n) dst[i] = a[i] + (b ? b[i] : 0.f);
+}
+
+// dst[i] += src[i]
+__global__ __launch_bounds__(kThreads) void add_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
+// x' = x + dir sigmoid(gate) (+ L eps): given g = dL/dx' and the raw head outputs (dir_0..dir_{D-1}, gate; bias
+// included): d dir_i = g_i s, d gate = (sum_i g_i dir_i) s (1 - s)
+template <int D>
+__global__ __launch_bounds__(kThreads) void dyn_epilogue_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ g,
+                                                                    float* __restrict__ d_raw, size_t C) {
+  const size_t c = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (c >= C) return;
+  const float gate = raw[c * (D + 1) + D];
+  const float s = 1.0f / (1.0f + expf(-gate));
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    const float gi = g[c * D + i];
+    d_raw[c * (D + 1) + i] = gi * s;
+    dot += gi * raw[c * (D + 1) + i];
+  }
+  d_raw[c * (D + 1) + D] = dot * s * (1.0f - s);
+}
+
+inline int blocks(size_t n) { return static_cast<int>((n + kThreads - 1) / kThreads); }
+
+int check(const MmfPfTrainArgs* a) {
+  if (!a) return MMF_EINVAL;
+  if (a->T < 0 || a->N < 1 || a->M < 1 || a->n_meas < 1 || a->n_meas > MMF_LOOP_MAX_MEAS) return MMF_EINVAL;
+  if (a->d != 2 && a->d != 3) return MMF_EINVAL;
+  if (!a->dyn.packed || !a->dyn_bias || !a->noise || !a->scale_tril || !a->states || !a->logw || !a->estimates ||
+      !a->loglik || !a->ll_steps)
+    return MMF_EINVAL;
+  for (int k = 0; k < a->n_meas; ++k)
+    if (!a->meas[k].packed || !a->meas_bias[k]) return MMF_EINVAL;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mmf_pf_train_forward(const MmfPfTrainArgs* a, void* stream) {
+  int rc = check(a);
+  if (rc) return rc;
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  const size_t row = static_cast<size_t>(a->N), R = row * a->M;
+  const int K = a->n_meas;
+  for (int t = 0; t < a->T; ++t) {
+    const float* x = a->states + t * R * a->d;
+    float* xn = a->states + (t + 1) * R * a->d;
+    rc = mmf_pf_dynamics(a->dyn.packed, a->n_res_dyn, a->precision, x, a->dyn_bias + t * row * MMF_UNITS,
+                         a->noise + t * R * a->d, a->scale_tril, xn, a->range_flag, a->N, a->M, a->d, stream);
+    if (rc) return rc;
+    float* ll = a->ll_steps + static_cast<size_t>(t) * K * R;  // (K, R): kept for the backward's softmax over modalities
+    for (int k = 0; k < K; ++k) {
+      const float* lw = a->meas_logw[k] ? a->meas_logw[k] + t * row * a->logw_stride : nullptr;
+      rc = mmf_pf_measure(a->meas[k].packed, a->n_res_meas, a->precision, xn, a->meas_bias[k] + t * row * MMF_UNITS, lw,
+                          a->logw_stride, ll + k * R, 0, a->range_flag, a->N, a->M, a->d, stream);
+      if (rc) return rc;
+    }
+    const float* loglik = ll;
+    if (K > 1) {
+      combine_fwd_kernel<<<blocks(R), kThreads, 0, hs>>>(ll, a->loglik, K, R);
+      MMF_CHECK_LAUNCH();
+      loglik = a->loglik;
+    }
+    rc = mmf_pf_reweight_resample(loglik, a->logw + t * R, xn, nullptr, a->estimates + t * row * a->d, nullptr,
+                                  a->logw + (t + 1) * R, nullptr, a->N, a->M, a->M, a->d, 0, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
+  int rc = check(a);
+  if (rc) return rc;
+  if (!a->g_estimates || !a->stash || !a->dz || !a->raw || !a->d_raw || !a->g_states_a || !a->g_states_b || !a->g_logw_a ||
+      !a->g_logw_b || !a->d_tmp || !a->d_states0 || !a->d_logw0 || a->chunk_traj < 1 || a->n_splits < 1 || a->n_slices < 1)
+    return MMF_EINVAL;
+  hipStream_t hs = static_cast<hipStream_t>(stream);
+  const int N = a->N, M = a->M, d = a->d, K = a->n_meas, S = a->n_splits, SL = a->n_slices;
+  const size_t row = static_cast<size_t>(N), R = row * M;
+  const int NLd = 3 + 2 * a->n_res_dyn, NLm = 3 + 2 * a->n_res_meas;
+  float* g_next = a->g_states_a;   // dL/d states[t+1] arriving from step t+1 (none at the last step)
+  float* g_tot = a->g_states_b;
+  float* g_lw = a->g_logw_a;       // dL/d logw[t+1] arriving from step t+1
+  float* d_a = a->g_logw_b;
+  bool first_wgrad_dyn = true;
+  bool first_wgrad_meas[MMF_LOOP_MAX_MEAS];
+  for (int k = 0; k < K; ++k) first_wgrad_meas[k] = true;
+
+  for (int t = a->T - 1; t >= 0; --t) {
+    const bool last = t == a->T - 1;
+    const float* x = a->states + t * R * d;          // input of step t's dynamics
+    const float* xn = a->states + (t + 1) * R * d;   // its output: what was measured and averaged
+    // K1 (mode 0) backward: d_a = dL/d(logw[t] + loglik), g_tot = dL/d states[t+1] through the estimate
+    rc = mmf_pf_reweight_backward(a->logw + (t + 1) * R, xn, a->g_estimates + t * row * d, last ? nullptr : g_lw, d_a, g_tot,
+                                  N, M, d, stream);
+    if (rc) return rc;
+    if (!last) {
+      add_kernel<<<blocks(R * d), kThreads, 0, hs>>>(g_tot, g_next, R * d);
+      MMF_CHECK_LAUNCH();
+    }
+    const float* ll = a->ll_steps + static_cast<size_t>(t) * K * R;
+    for (int n0 = 0; n0 < N; n0 += a->chunk_traj) {
+      const int Nc = (N - n0 < a->chunk_traj) ? N - n0 : a->chunk_traj;
+      const size_t r0 = static_cast<size_t>(n0) * M, C = static_cast<size_t>(Nc) * M;
+      const int Ci = static_cast<int>(C);
+      const size_t slot0 = (static_cast<size_t>(t) * N + n0) * SL;  // first slice slot of this chunk in the per-step partials
+      // ---- measurement networks: d ll_k = d_a softmax_k, then each network's backward on recomputed activations
+      if (K > 1) {
+        combine_bwd_kernel<<<blocks(C), kThreads, 0, hs>>>(ll, d_a, a->d_raw, K, R, r0, C);
+        MMF_CHECK_LAUNCH();
+      }
+      for (int k = 0; k < K; ++k) {
+        const MmfTrainNet& net = a->meas[k];
+        const float* d_out = K > 1 ? a->d_raw + k * C : d_a + r0;
+        rc = mmf_particle_net_train_forward(net.packed_f32, a->n_res_meas, 1, xn + r0 * d,
+                                            a->meas_bias[k] + (t * row + n0) * MMF_UNITS, a->stash, a->raw, Nc, M, d, stream);
+        if (rc) return rc;
+        rc = mmf_particle_net_train_backward(net.packed_t, net.head_w, a->n_res_meas, 1, a->stash, d_out, a->dz, a->d_tmp,
+                                             Ci, d, stream);
+        if (rc) return rc;
+        rc = mmf_particle_net_weight_grads_acc(a->dz, a->stash, net.pw, net.pb, NLm + 1, Ci, S, first_wgrad_meas[k] ? 0 : 1,
+                                               stream);
+        if (rc) return rc;
+        first_wgrad_meas[k] = false;
+        rc = mmf_particle_net_small_grads(a->dz + static_cast<size_t>(NLm) * C * MMF_UNITS, a->dz + 2 * C * MMF_UNITS,
+                                          a->stash + static_cast<size_t>(NLm) * C * MMF_UNITS, xn + r0 * d, d_out,
+                                          net.p_first + slot0 * MMF_UNITS * 4, net.p_head + slot0 * 4 * MMF_UNITS,
+                                          net.p_dout + slot0 * 4, net.p_traj + slot0 * MMF_UNITS, Nc, M, d, 1, SL, stream);
+        if (rc) return rc;
+        add_kernel<<<blocks(C * d), kThreads, 0, hs>>>(g_tot + r0 * d, a->d_tmp, C * d);
+        MMF_CHECK_LAUNCH();
+      }
+      // ---- dynamics network: x' = x + dir sigmoid(gate) + L eps
+      {
+        const MmfTrainNet& net = a->dyn;
+        rc = mmf_particle_net_train_forward(net.packed_f32, a->n_res_dyn, 0, x + r0 * d,
+                                            a->dyn_bias + (t * row + n0) * MMF_UNITS, a->stash, a->raw, Nc, M, d, stream);
+        if (rc) return rc;
+        if (d == 2) dyn_epilogue_bwd_kernel<2><<<blocks(C), kThreads, 0, hs>>>(a->raw, g_tot + r0 * d, a->d_raw, C);
+        else dyn_epilogue_bwd_kernel<3><<<blocks(C), kThreads, 0, hs>>>(a->raw, g_tot + r0 * d, a->d_raw, C);
+        MMF_CHECK_LAUNCH();
+        rc = mmf_particle_net_train_backward(net.packed_t, net.head_w, a->n_res_dyn, 0, a->stash, a->d_raw, a->dz, a->d_tmp,
+                                             Ci, d, stream);
+        if (rc) return rc;
+        rc = mmf_particle_net_weight_grads_acc(a->dz, a->stash, net.pw, net.pb, NLd + 1, Ci, S, first_wgrad_dyn ? 0 : 1, stream);
+        if (rc) return rc;
+        first_wgrad_dyn = false;
+        rc = mmf_particle_net_small_grads(a->dz + static_cast<size_t>(NLd) * C * MMF_UNITS, a->dz + 2 * C * MMF_UNITS,
+                                          a->stash + static_cast<size_t>(NLd) * C * MMF_UNITS, x + r0 * d, a->d_raw,
+                                          net.p_first + slot0 * MMF_UNITS * 4, net.p_head + slot0 * 4 * MMF_UNITS,
+                                          net.p_dout + slot0 * 4, net.p_traj + slot0 * MMF_UNITS, Nc, M, d, d + 1, SL, stream);
+        if (rc) return rc;
+        // dL/d states[t] = direct path + through the network
+        sum2_kernel<<<blocks(C * d), kThreads, 0, hs>>>(g_tot + r0 * d, a->d_tmp, g_next + r0 * d, C * d);
+        MMF_CHECK_LAUNCH();
+      }
+    }
+    // dL/d logw[t] = d_a: becomes the incoming log-weight gradient of step t - 1
+    float* s = g_lw; g_lw = d_a; d_a = s;
+  }
+  if (a->T > 0) {
+    if (hipMemcpyAsync(a->d_states0, g_next, R * d * sizeof(float), hipMemcpyDeviceToDevice, hs) != hipSuccess) return MMF_EINVAL;
+    if (hipMemcpyAsync(a->d_logw0, g_lw, R * sizeof(float), hipMemcpyDeviceToDevice, hs) != hipSuccess) return MMF_EINVAL;
+  }
+  return 0;
+}

@@ -410,6 +410,161 @@ class ParticleNetFunction(torch.autograd.Function):
         return (None, None, None, None, d_states, d_traj_bias, *grads)
 
 
+def _assemble_param_grads(net: PackedParticleNet, params, dW, db, g_first, g_head, g_head_b):
+    """Gradients in the order of ``net._sources()`` from the kernels' reductions: ``dW`` / ``db``
+    ``(NL + 1, 64, 64)`` / ``(NL + 1, 64)`` per 64x64 layer (slot NL of ``db`` = first-layer bias)."""
+    U = _abi.MMF_UNITS
+    NL = 3 + 2 * net.n_res
+    grads = [None] * len(params)
+    grads[0] = g_first
+    grads[1] = db[NL]
+    grads[2], grads[3], grads[4], grads[5] = dW[0], db[0], dW[1], db[1]
+    gj = torch.zeros_like(params[6], dtype=torch.float32)  # join: only the state columns are this network's
+    off = net.join_state_off
+    gj[:, off:off + U] = dW[2]
+    grads[6] = gj
+    for i in range(net.n_res):
+        for k in range(2):
+            layer = 3 + 2 * i + k
+            grads[7 + 4 * i + 2 * k] = dW[layer]
+            grads[8 + 4 * i + 2 * k] = db[layer]
+    grads[-2] = g_head
+    grads[-1] = g_head_b
+    return grads
+
+
+# rows of one backward chunk of the native training recursion: stash + dz of a chunk
+# (2 x (NL + 1) x rows x 256 B, NL <= 9) stay below the 256 MiB Infinity Cache
+TRAIN_CHUNK_ROWS = int(os.environ.get("MMF_TRAIN_CHUNK_ROWS", "32768"))
+
+
+class PfTrainLoopFunction(torch.autograd.Function):
+    """K6, whole recursion: ``T`` train-mode (no resampling) particle-filter steps forward in ONE C call
+    (``mmf_pf_train_forward``) and backward in one (``mmf_pf_train_backward``: activations recomputed per
+    chunk of trajectories into a cache-resident stash, weight gradients accumulated on the device).
+
+    ``apply(nets, T, N, M, states0 (N, M, d), logw0 (N, M), eps (T, N, M, d), tril (d, d), dyn_bias (T*N, 64),
+    beta (T*N, K_all) | empty, *meas_biases (T*N, 64), *params)`` -> ``(estimates (T, N, d), states_T, logw_T)``
+    with ``nets = (dyn_net, [(meas_net, beta column | None)], K_all)`` and ``params`` the concatenated
+    ``_sources()`` of the dynamics network and of every measurement network."""
+
+    @staticmethod
+    def forward(ctx, nets, T, N, M, states0, logw0, eps, tril, dyn_bias, beta, *rest):
+        dyn_net, meas, K_all = nets
+        K = len(meas)
+        meas_biases, params = rest[:K], rest[K:]
+        dev = states0.device
+        require_device(states0, "PfTrainLoopFunction")
+        d = states0.shape[-1]
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        U = _abi.MMF_UNITS
+        R = N * M
+        states = torch.empty((T + 1, N, M, d), dtype=torch.float32, device=dev)
+        logw = torch.empty((T + 1, N, M), dtype=torch.float32, device=dev)
+        states[0].copy_(states0.detach())
+        logw[0].copy_(logw0.detach())
+        est = torch.empty((T, N, d), dtype=torch.float32, device=dev)
+        keep = dict(states=states, logw=logw, est=est, eps=f32(eps), tril=f32(tril), dyn_bias=f32(dyn_bias),
+                    meas_biases=[f32(b) for b in meas_biases], beta=f32(beta) if beta.numel() else None,
+                    loglik=torch.empty((N, M), dtype=torch.float32, device=dev),
+                    ll_steps=torch.empty((T, K, N, M), dtype=torch.float32, device=dev))
+        a = _abi.MmfPfTrainArgs()
+        P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        a.T, a.N, a.M, a.d, a.n_meas = T, N, M, d, K
+        a.n_res_dyn, a.n_res_meas, a.logw_stride = dyn_net.n_res, meas[0][0].n_res, K_all
+        a.precision = _abi.PREC_F32  # the forward the backward recomputes: same arithmetic
+        blobs = [dyn_net.blob(_abi.PREC_F32)] + [m.blob(_abi.PREC_F32) for m, _ in meas]
+        a.dyn.packed = a.dyn.packed_f32 = P(blobs[0])
+        for k, (m, col) in enumerate(meas):
+            a.meas[k].packed = a.meas[k].packed_f32 = P(blobs[1 + k])
+            a.meas_bias[k] = P(keep["meas_biases"][k])
+            if keep["beta"] is not None and col is not None:
+                a.meas_logw[k] = ctypes.c_void_p(keep["beta"].data_ptr() + 4 * col)
+        a.dyn_bias, a.noise, a.scale_tril = P(keep["dyn_bias"]), P(keep["eps"]), P(keep["tril"])
+        a.states, a.logw, a.estimates = P(states), P(logw), P(est)
+        a.loglik, a.ll_steps = P(keep["loglik"]), P(keep["ll_steps"])
+        a.range_flag = None
+        _abi.pf_train_forward(a, states)
+        ctx.nets, ctx.shape, ctx.keep, ctx.blobs = nets, (T, N, M, d), keep, blobs
+        ctx.save_for_backward(*[p.detach() for p in params])
+        sT, lT = states[T], logw[T]
+        ctx.mark_non_differentiable(sT, lT)
+        return est, sT, lT
+
+    @staticmethod
+    def backward(ctx, g_est, _g_states, _g_logw):
+        dyn_net, meas, K_all = ctx.nets
+        T, N, M, d = ctx.shape
+        keep = ctx.keep
+        params = ctx.saved_tensors
+        K = len(meas)
+        dev = keep["states"].device
+        U = _abi.MMF_UNITS
+        chunk_traj = max(1, min(N, TRAIN_CHUNK_ROWS // M))
+        C = chunk_traj * M
+        S = max(1, min(128, C // 512))
+        SL = max(1, min(16, M // 256))
+        nets = [dyn_net] + [m for m, _ in meas]
+        NLmax = max(3 + 2 * n.n_res for n in nets)
+        E = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        a = _abi.MmfPfTrainArgs()
+        a.T, a.N, a.M, a.d, a.n_meas = T, N, M, d, K
+        a.n_res_dyn, a.n_res_meas, a.logw_stride, a.precision = dyn_net.n_res, meas[0][0].n_res, K_all, _abi.PREC_F32
+        a.chunk_traj, a.n_splits, a.n_slices = chunk_traj, S, SL
+        bufs = []
+        head_ws, tblobs = [], []
+        n_par = [len(n._sources()) for n in nets]
+        offs = [0]
+        for c in n_par:
+            offs.append(offs[-1] + c)
+        for i, net in enumerate(nets):
+            NL = 3 + 2 * net.n_res
+            tn = a.dyn if i == 0 else a.meas[i - 1]
+            b = dict(pw=E(NL + 1, S, U, U), pb=E(NL + 1, S, U), p_first=E(T, N * SL, U, 4), p_head=E(T, N * SL, 4, U),
+                     p_dout=E(T, N * SL, 4), p_traj=E(T, N * SL, U))
+            bufs.append(b)
+            head_ws.append(params[offs[i + 1] - 2].to(torch.float32).contiguous())
+            tblobs.append(_transposed_blob(net))
+            tn.packed = tn.packed_f32 = P(ctx.blobs[i])
+            tn.packed_t, tn.head_w = P(tblobs[i]), P(head_ws[i])
+            tn.pw, tn.pb, tn.p_first, tn.p_head, tn.p_dout, tn.p_traj = (P(b[k]) for k in ("pw", "pb", "p_first", "p_head", "p_dout", "p_traj"))
+        for k in range(K):
+            a.meas_bias[k] = P(keep["meas_biases"][k])
+            col = meas[k][1]
+            if keep["beta"] is not None and col is not None:
+                a.meas_logw[k] = ctypes.c_void_p(keep["beta"].data_ptr() + 4 * col)
+        g_est = g_est.to(torch.float32).contiguous()
+        scratch = dict(stash=E(NLmax + 1, C, U), dz=E(NLmax + 1, C, U), raw=E(C, 8), d_raw=E(C, 8), ga=E(N, M, d), gb=E(N, M, d),
+                       la=E(N, M), lb=E(N, M), d_tmp=E(C, d), d_states0=E(N, M, d), d_logw0=E(N, M))
+        a.dyn_bias, a.noise, a.scale_tril, a.g_estimates = P(keep["dyn_bias"]), P(keep["eps"]), P(keep["tril"]), P(g_est)
+        a.states, a.logw, a.estimates = P(keep["states"]), P(keep["logw"]), P(keep["est"])
+        a.loglik, a.ll_steps = P(keep["loglik"]), P(keep["ll_steps"])
+        a.stash, a.dz, a.raw, a.d_raw, a.d_tmp = (P(scratch[k]) for k in ("stash", "dz", "raw", "d_raw", "d_tmp"))
+        a.g_states_a, a.g_states_b, a.g_logw_a, a.g_logw_b = P(scratch["ga"]), P(scratch["gb"]), P(scratch["la"]), P(scratch["lb"])
+        a.d_states0, a.d_logw0 = P(scratch["d_states0"]), P(scratch["d_logw0"])
+        _abi.pf_train_backward(a, g_est)
+        # slices / steps of the narrow reductions, and the param gradients in _sources() order
+        param_grads, bias_grads, d_beta = [], [], None
+        if keep["beta"] is not None:
+            d_beta = torch.zeros((T * N, K_all), dtype=torch.float32, device=dev)
+        for i, net in enumerate(nets):
+            b = bufs[i]
+            dW, db = b["pw"].sum(1), b["pb"].sum(1)
+            n_out = net.n_out
+            g_first = b["p_first"].sum((0, 1))[:, :d]
+            g_head = b["p_head"].sum((0, 1))[:n_out]
+            per_traj_dout = b["p_dout"].view(T * N, SL, 4).sum(1)
+            g_head_b = per_traj_dout.sum(0)[:n_out]
+            bias_grads.append(b["p_traj"].view(T * N, SL, U).sum(1))
+            if i > 0 and d_beta is not None and meas[i - 1][1] is not None:
+                d_beta[:, meas[i - 1][1]] = per_traj_dout[:, 0]
+            param_grads += _assemble_param_grads(net, params[offs[i]:offs[i + 1]], dW, db, g_first, g_head, g_head_b)
+        none7 = (None, None, None, None)
+        return (*none7, scratch["d_states0"], scratch["d_logw0"], None, None, bias_grads[0],
+                d_beta if d_beta is not None else None, *bias_grads[1:], *param_grads)
+
+
 def dynamics_with_jacobian_autograd(net: PackedParticleNet, x: torch.Tensor, traj_bias: torch.Tensor):
     """K6 for K5: differentiable ``(x' (N, d), A (N, d, d))`` of a dynamics network
     ``x' = x + dir(x) * sigmoid(gate(x))``.  The primal and the ``d`` tangent columns ``e_j`` of every

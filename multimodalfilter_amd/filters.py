@@ -351,6 +351,37 @@ class ParticleFilter(base.Filter):
         del keep
         return est
 
+    def _native_train_loop(self, dyn_all, meas_all, T, N):
+        """K6, whole recursion (``engine.PfTrainLoopFunction``): all ``T`` train-mode steps forward in one C
+        call, backward in one; ``None`` -> the caller's step-by-step autograd loop (user models, resampling
+        while training, ``argmax`` estimates, a belief of another particle count)."""
+        dyn, meas = self.dynamics_model, self.measurement_model
+        do_resample = (not self.training) if self.resample is None else bool(self.resample)
+        if (dyn_all is None or meas_all is None or not hasattr(dyn, "_net") or not hasattr(meas, "train_plan")
+                or do_resample or self.estimation_method != "weighted_average" or T == 0 or not self.use_native_loop):
+            return None
+        assert self._initialized, "Particle filter not initialized!"
+        Nb, M, d = self.particle_states.shape
+        if Nb != N or self.num_particles != M:
+            return None
+        plan = meas.train_plan(meas_all)
+        if plan is None:
+            return None
+        nets, biases, beta, K_all = plan
+        if len(nets) > _abi.LOOP_MAX_MEAS:
+            return None
+        eps, _ = self.noise.draw_steps(T, (N, M, d), None, like=self.particle_states)
+        params = list(dyn._net._sources())
+        for net, _col in nets:
+            params += net._sources()
+        empty = torch.empty(0, dtype=torch.float32, device=self.particle_states.device)
+        est, states, logw = engine.PfTrainLoopFunction.apply(
+            (dyn._net, nets, K_all), T, N, M, self.particle_states, self.particle_log_weights, eps,
+            dyn.scale_tril(), dyn_all, beta if beta is not None else empty, *biases, *params)
+        self.particle_states, self.particle_log_weights = states, logw
+        self._spare_states = None
+        return est
+
     def forward(self, *, observations, controls) -> torch.Tensor:
         if use_autograd(self):
             return self._step_autograd(observations, controls)
@@ -374,6 +405,9 @@ class ParticleFilter(base.Filter):
                 dyn_all = self.dynamics_model.encode_controls_autograd(tree_map(controls, flat))
             if hasattr(self.measurement_model, "encode_observations_autograd"):
                 meas_all = self.measurement_model.encode_observations_autograd(tree_map(observations, flat))
+            native = self._native_train_loop(dyn_all, meas_all, T, N)
+            if native is not None:
+                return native
             out = []
             for t in range(T):
                 sl = slice(t * N, (t + 1) * N)

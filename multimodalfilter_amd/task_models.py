@@ -303,6 +303,11 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             native step loop (``mmf_pf_forward_loop``)."""
             return [(self._net, ctx["bias"], None)], 0
 
+        def train_plan(self, ctx):
+            """``([(network, beta column | None)], [bias (R, 64)], beta | None, beta row width)`` for the
+            native training recursion (``engine.PfTrainLoopFunction``); ``ctx`` from ``encode_observations_autograd``."""
+            return [(self._net, None)], [ctx["bias"]], None, 0
+
         def forward_encoded(self, states, ctx, *, loglik=None, combine=False, modality_logw=None,
                             logw_stride=0):
             N, M, _ = states.shape

@@ -91,14 +91,18 @@ def test_particle_filter_training_step_matches_oracle(training_backend, tname, c
     assert eng.num_particles == 30
     eng.noise = mmf.ReplayNoise([eps0] + eps, [])
     eng.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
+    loops = []
+    real_loop = engine.PfTrainLoopFunction.apply
     engine.ParticleNetFunction.apply = lambda *a: (calls.append(1), real(*a))[1]
+    engine.PfTrainLoopFunction.apply = lambda *a: (loops.append(1), real_loop(*a))[1]
     try:
         pred = eng.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
     finally:
         engine.ParticleNetFunction.apply = real
+        engine.PfTrainLoopFunction.apply = real_loop
     assert pred.requires_grad
-    # "hip": dynamics + every enabled measurement network, each step, went through K6
-    assert (len(calls) >= 2 * T) == (training_backend == "hip")
+    # "hip": the whole recursion went through the native K6 loop (one Function for all T steps)
+    assert (len(loops) == 1) == (training_backend == "hip") and not (loops and calls)
     loss_e = torch.mean((pred - target.to(dev)) ** 2)
     _compare_grads(oracle, eng, loss_o, loss_e)
 
@@ -680,3 +684,59 @@ def test_k6_dynamics_with_jacobian_matches_fp64_autograd(tname, N):
     for name, a, b in zip(["x", "controls"] + names, got, want):
         scale = max(1e-6, float(b.abs().max()))
         assert float((a.cpu().double() - b).abs().max()) / scale < 1e-4, name
+
+
+@pytest.mark.parametrize("tname,cls,N,M,T,chunk_rows", [
+    ("door", "DoorCrossmodalParticleFilter", 6, 30, 5, 32768),    # the reference's training size class: one chunk
+    ("door", "DoorCrossmodalParticleFilter", 5, 300, 3, 600),     # several ragged chunks of trajectories (2, 2, 1)
+    ("push", "PushUnimodalParticleFilter", 4, 64, 4, 128),
+    ("door", "DoorParticleFilter", 3, 100, 3, 100),               # single measurement network, no modality weights
+])
+def test_native_training_recursion_matches_stepwise(tname, cls, N, M, T, chunk_rows):
+    """``engine.PfTrainLoopFunction`` (``mmf_pf_train_forward`` / ``mmf_pf_train_backward``: the whole
+    recursion in two C calls, activations recomputed per chunk of trajectories, weight gradients
+    accumulated on the device) against the step-by-step K6 path (one autograd Function per network call):
+    same loss to 1e-6 relative, every parameter gradient to 1e-4 of its largest entry -- whatever the
+    chunking."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine
+
+    dev = torch.device("cuda:0")
+    task = om.TASKS[tname]
+    d = task.state_dim
+    obs, ctrl, x0, target, g = _data(task, T, N, 31)
+    eps0 = torch.randn((N, M, d), generator=g)
+    eps = [torch.randn((N, M, d), generator=g) for _ in range(T)]
+    cov = (torch.eye(d) * 0.1)[None].expand(N, d, d)
+    torch.manual_seed(3)
+    f = mmf.model_types(tname)[cls]().to(dev).train()
+    f.num_particles = M
+    engine.set_training_backend("hip")
+    old_chunk = engine.TRAIN_CHUNK_ROWS
+    engine.TRAIN_CHUNK_ROWS = chunk_rows
+    results = {}
+    try:
+        for native in (False, True):
+            f.use_native_loop = native
+            f.zero_grad(set_to_none=True)
+            f.noise = mmf.ReplayNoise([eps0] + eps, [])
+            f.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
+            pred = f.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
+            loss = torch.mean((pred - target.to(dev)) ** 2)
+            loss.backward()
+            results[native] = (float(loss.detach()), pred.detach().clone(),
+                               {n: p.grad.detach().clone() for n, p in f.named_parameters() if p.grad is not None},
+                               f.particle_states.detach().clone(), f.particle_log_weights.detach().clone())
+    finally:
+        engine.set_training_backend(None)
+        engine.TRAIN_CHUNK_ROWS = old_chunk
+        f.use_native_loop = True
+    (l0, p0, g0, s0, w0), (l1, p1, g1, s1, w1) = results[False], results[True]
+    assert abs(l0 - l1) < 1e-6 * max(1.0, abs(l0))
+    assert float((p0 - p1).abs().max()) < 1e-5 * max(1.0, float(p0.abs().max()))
+    assert float((s0 - s1).abs().max()) < 1e-5 * max(1.0, float(s0.abs().max()))
+    assert float((w0 - w1).abs().max()) < 1e-4
+    assert set(g0) == set(g1) and len(g0) > 20
+    for name in g0:
+        scale = max(1e-9, float(g0[name].abs().max()))
+        assert float((g0[name] - g1[name]).abs().max()) / scale < 1e-4, name
