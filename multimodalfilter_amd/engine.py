@@ -472,18 +472,21 @@ class PfTrainLoopFunction(torch.autograd.Function):
         P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
         a.T, a.N, a.M, a.d, a.n_meas = T, N, M, d, K
         a.n_res_dyn, a.n_res_meas, a.logw_stride = dyn_net.n_res, meas[0][0].n_res, K_all
-        a.precision = _abi.PREC_F32  # the forward the backward recomputes: same arithmetic
+        # forward pass in the engine's arithmetic mode (f16x3 by default: the inference kernels); the backward
+        # recomputes the SAME particle sets' activations with exact fp32 products
+        a.precision = dyn_net.precision_code()
         blobs = [dyn_net.blob(_abi.PREC_F32)] + [m.blob(_abi.PREC_F32) for m, _ in meas]
-        a.dyn.packed = a.dyn.packed_f32 = P(blobs[0])
+        fwd_blobs = [dyn_net.blob()] + [m.blob() for m, _ in meas]
+        a.dyn.packed, a.dyn.packed_f32 = P(fwd_blobs[0]), P(blobs[0])
         for k, (m, col) in enumerate(meas):
-            a.meas[k].packed = a.meas[k].packed_f32 = P(blobs[1 + k])
+            a.meas[k].packed, a.meas[k].packed_f32 = P(fwd_blobs[1 + k]), P(blobs[1 + k])
             a.meas_bias[k] = P(keep["meas_biases"][k])
             if keep["beta"] is not None and col is not None:
                 a.meas_logw[k] = ctypes.c_void_p(keep["beta"].data_ptr() + 4 * col)
         a.dyn_bias, a.noise, a.scale_tril = P(keep["dyn_bias"]), P(keep["eps"]), P(keep["tril"])
         a.states, a.logw, a.estimates = P(states), P(logw), P(est)
         a.loglik, a.ll_steps = P(keep["loglik"]), P(keep["ll_steps"])
-        a.range_flag = None
+        a.range_flag = ctypes.c_void_p(range_flag(dev).data_ptr())
         _abi.pf_train_forward(a, states)
         ctx.nets, ctx.shape, ctx.keep, ctx.blobs = nets, (T, N, M, d), keep, blobs
         ctx.save_for_backward(*[p.detach() for p in params])
