@@ -433,9 +433,12 @@ def _assemble_param_grads(net: PackedParticleNet, params, dW, db, g_first, g_hea
     return grads
 
 
-# rows of one backward chunk of the native training recursion: stash + dz of a chunk
-# (2 x (NL + 1) x rows x 256 B, NL <= 9) stay below the 256 MiB Infinity Cache
-TRAIN_CHUNK_ROWS = int(os.environ.get("MMF_TRAIN_CHUNK_ROWS", "32768"))
+# Rows of one backward chunk of the native training recursion (whole trajectories): bounds the two
+# recompute buffers (stash + dz: 2 x (NL + 1) x rows x 256 B = 1.3 GB at the default) whatever N, M, T.
+# Measured at 32 x 8192 x 16 (push unimodal PF, ms per optimiser step): 16,384 rows 113, 32,768 (both
+# buffers inside the 256 MiB Infinity Cache) 65.7, 65,536 56.1, 262,144 45.0 -- on-die hand-offs do not pay
+# for the small launches (150 KB of weights staged per workgroup for 4 tiles, half-empty grids)
+TRAIN_CHUNK_ROWS = int(os.environ.get("MMF_TRAIN_CHUNK_ROWS", "262144"))
 
 
 class PfTrainLoopFunction(torch.autograd.Function):
