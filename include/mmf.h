@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 27
+#define MMF_ABI_VERSION 28
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -366,12 +366,32 @@ typedef struct MmfPfLoopArgs {
   float* loglik_steps;       /* (T, N, M) or null: step t's fused log-likelihoods are kept here  */
                              /* instead of the shared `loglik` scratch (parity certificates)     */
   int32_t* indices_steps;    /* (T, N, M) int32 or null: ancestors drawn at every resampling step */
+  uint64_t noise_seed;       /* noise_mode 2: key of the counter-based generator (include/mmf_philox.h)       */
+  uint32_t noise_step0;      /* noise_mode 2: step t of the loop draws counter step noise_step0 + t          */
+  uint32_t noise_traj0;      /* noise_mode 2: global index of this shard's first trajectory                  */
+  int32_t noise_mode;        /* 0: `noise` tensor; 2: generated inside the dynamics kernel (`noise` may be null) */
   int32_t use_graph;         /* != 0 (and events == null): capture the loop's launches on `stream` into a   */
                              /* hipGraph and launch that instead (A/B switch; the executable graph is kept  */
                              /* by the library until its launch has completed -- mmf_loop_graphs_release)   */
 } MmfPfLoopArgs;             /* host struct holding device pointers                           */
 
 int mmf_pf_forward_loop(const MmfPfLoopArgs* args /* host */, void* stream);
+
+/* Counter-based process noise (include/mmf_philox.h: Philox4x32-10 + a fixed-order Box-Muller, a pure
+ * function of (seed, step, global trajectory index, particle)): replaces the
+ * MultivariateNormal(...).rsample() torchfilter draws inside every step without a
+ * (T, N, M, d) tensor.  mmf_pf_dynamics_philox = mmf_pf_dynamics with the noise generated in the kernel's
+ * epilogue; mmf_philox_normals materialises the same draws (N, M, d) (initial particles, step-by-step use,
+ * tests); mmf_philox_uniforms the resampling uniforms (T, N) of steps step0 .. step0 + T - 1.
+ */
+int mmf_pf_dynamics_philox(const float* packed, int n_res, int precision, const float* states_in,
+                           const float* traj_bias, unsigned long long seed, unsigned step, unsigned traj0,
+                           const float* scale_tril, float* states_out, int* range_flag, int N, int M, int d,
+                           void* stream);
+int mmf_philox_normals(unsigned long long seed, unsigned step, unsigned traj0, float* out, int N, int M, int d,
+                       void* stream);
+int mmf_philox_uniforms(unsigned long long seed, unsigned step0, unsigned traj0, float* out, int T, int N,
+                        void* stream);
 
 /* Waits for and frees every executable graph a use_graph loop left behind (process shutdown, tests). */
 void mmf_loop_graphs_release(void);

@@ -11,10 +11,10 @@ from . import _abi, base, types, utils  # noqa: F401
 from . import filters, base_models  # noqa: F401
 from . import door_models, push_models  # noqa: F401
 from . import data, train  # noqa: F401
-from .utils import NoiseSource, ReplayNoise, StackedNoise  # noqa: F401
+from .utils import CounterNoise, NoiseSource, ReplayNoise, StackedNoise  # noqa: F401
 
 __all__ = ["base", "filters", "types", "utils", "base_models", "door_models", "push_models", "data", "train",
-           "NoiseSource", "ReplayNoise", "StackedNoise", "model_types"]
+           "NoiseSource", "ReplayNoise", "StackedNoise", "CounterNoise", "model_types"]
 
 
 def model_types(task: str):

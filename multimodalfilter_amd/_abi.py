@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 27
+ABI_VERSION = 28
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
@@ -65,7 +65,8 @@ class MmfPfLoopArgs(Structure):
                 ("loglik", _FP), ("estimates", _FP), ("range_flag", _FP),
                 ("final_location", POINTER(c_int32)), ("events", POINTER(c_void_p)),
                 ("event_stride", c_int32), ("loglik_steps", _FP), ("indices_steps", _FP),
-                ("use_graph", c_int32)]
+                ("noise_seed", ctypes.c_uint64), ("noise_step0", ctypes.c_uint32), ("noise_traj0", ctypes.c_uint32),
+                ("noise_mode", c_int32), ("use_graph", c_int32)]
 
 
 class MmfTrainNet(Structure):
@@ -121,6 +122,10 @@ SIGNATURES = {
     "mmf_pf_init_particles": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_forward_loop": (c_int, [POINTER(MmfPfLoopArgs), c_void_p]),
     "mmf_loop_graphs_release": (None, []),
+    "mmf_pf_dynamics_philox": (c_int, [_FP, c_int, c_int, _FP, _FP, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
+                                       _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
+    "mmf_philox_normals": (c_int, [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _FP, c_int, c_int, c_int, c_void_p]),
+    "mmf_philox_uniforms": (c_int, [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _FP, c_int, c_int, c_void_p]),
     "mmf_dynamics_forward_loop": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_traj_program": (c_int, [_FP, c_int, _FP, POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
     "mmf_fuse_virtual_sensors": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
@@ -247,6 +252,27 @@ def dynamics_forward_loop(packed, n_res, precision, x0, traj_bias, out, range_fl
         _check(load().mmf_dynamics_forward_loop(ptr(packed), n_res, precision, ptr(x0), ptr(traj_bias), ptr(out),
                                                 ptr(range_flag, dtype=torch.int32), T, N, d, stream_of(x0)),
                "mmf_dynamics_forward_loop")
+
+
+def pf_dynamics_philox(packed, n_res, precision, states_in, traj_bias, seed, step, traj0, scale_tril, states_out,
+                       range_flag, N, M, d):
+    with _on(states_in):
+        _check(load().mmf_pf_dynamics_philox(ptr(packed), n_res, precision, ptr(states_in), ptr(traj_bias), seed, step,
+                                             traj0, ptr(scale_tril), ptr(states_out),
+                                             ptr(range_flag, dtype=torch.int32), N, M, d, stream_of(states_in)),
+               "mmf_pf_dynamics_philox")
+
+
+def philox_normals(seed: int, step: int, traj0: int, out: torch.Tensor):
+    N, M, d = out.shape
+    with _on(out):
+        _check(load().mmf_philox_normals(seed, step, traj0, ptr(out), N, M, d, stream_of(out)), "mmf_philox_normals")
+
+
+def philox_uniforms(seed: int, step0: int, traj0: int, out: torch.Tensor):
+    T, N = out.shape
+    with _on(out):
+        _check(load().mmf_philox_uniforms(seed, step0, traj0, ptr(out), T, N, stream_of(out)), "mmf_philox_uniforms")
 
 
 def pf_measure(packed, n_res, precision, states, traj_bias, modality_logw, logw_stride, loglik, combine,

@@ -27,6 +27,7 @@
 
 #include "mmf_common.h"
 #include "../../include/mmf_detmath.h"
+#include "../../include/mmf_philox.h"
 
 namespace {
 
@@ -476,6 +477,9 @@ struct NetArgs {
   int logw_stride;
   int combine;
   int* range_flag;          // f16x3: set to 1 when an activation left the f16-split range
+  unsigned long long noise_seed;  // noise_mode 2: counter-based noise (mmf_philox.h), no tensor
+  unsigned noise_step, noise_traj0;
+  int noise_mode;           // 0: `noise` tensor or none, 2: philox
 };
 
 // blockIdx.y selects one of up to MMF_LOOP_MAX_MEAS independent problems of the same shape (the
@@ -765,15 +769,24 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
         if constexpr (PREC == MMF_PREC_F32) sg = mmf_det_sigmoid(gate);
         else sg = 1.0f / (1.0f + expf(-gate));
         float xo[D], eps[D];
+        const bool noisy = a.noise != nullptr || a.noise_mode == 2;
+        if (a.noise_mode == 2) {
+          // counter-based noise: a pure function of (seed, step, trajectory, particle) -- nothing is read
+          float z[4];
+          const unsigned traj = static_cast<unsigned>(my_row / a.M);
+          mmf_philox_normal4(a.noise_seed, a.noise_step, a.noise_traj0 + traj, static_cast<unsigned>(my_row) - traj * a.M, z);
+#pragma unroll
+          for (int i = 0; i < D; ++i) eps[i] = z[i];
+        }
 #pragma unroll
         for (int i = 0; i < D; ++i) {
           xo[i] = a.states_in[static_cast<size_t>(my_row) * D + i];
-          eps[i] = a.noise ? a.noise[static_cast<size_t>(my_row) * D + i] : 0.f;
+          if (a.noise_mode != 2) eps[i] = a.noise ? a.noise[static_cast<size_t>(my_row) * D + i] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < D; ++i) {
           float v = __builtin_fmaf(mine[i] + bh[i], sg, xo[i]);
-          if (a.noise) {
+          if (noisy) {
 #pragma unroll
             for (int k = 0; k < D; ++k) v = __builtin_fmaf(a.scale_tril[i * D + k], eps[k], v);
           }
@@ -904,6 +917,60 @@ extern "C" int mmf_pf_dynamics(const float* packed, int n_res, int precision, co
   a.scale_tril = scale_tril; a.states_out = states_out; a.R = N * M; a.M = M;
   a.range_flag = range_flag;
   return launch<kDynamics>(a, d, n_res, precision, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mmf_pf_dynamics_philox(const float* packed, int n_res, int precision, const float* states_in,
+                                      const float* traj_bias, unsigned long long seed, unsigned step, unsigned traj0,
+                                      const float* scale_tril, float* states_out, int* range_flag, int N, int M, int d,
+                                      void* stream) {
+  if (!packed || !states_in || !traj_bias || !states_out || !scale_tril) return MMF_EINVAL;
+  if (N < 0 || M < 1) return MMF_EINVAL;
+  if (static_cast<long long>(N) * M > 0x7fffffffLL / 8) return MMF_ETOOLARGE;
+  if (N == 0) return 0;
+  NetArgs a{};
+  a.packed = packed; a.states_in = states_in; a.traj_bias = traj_bias; a.noise = nullptr;
+  a.scale_tril = scale_tril; a.states_out = states_out; a.R = N * M; a.M = M;
+  a.range_flag = range_flag;
+  a.noise_seed = seed; a.noise_step = step; a.noise_traj0 = traj0; a.noise_mode = 2;
+  return launch<kDynamics>(a, d, n_res, precision, static_cast<hipStream_t>(stream));
+}
+
+namespace {
+__global__ void philox_normals_kernel(unsigned long long seed, unsigned step, unsigned traj0, int M, int d, size_t R,
+                                      float* __restrict__ out) {
+  const size_t r = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  float z[4];
+  const unsigned traj = static_cast<unsigned>(r / M);
+  mmf_philox_normal4(seed, step, traj0 + traj, static_cast<unsigned>(r - static_cast<size_t>(traj) * M), z);
+  for (int i = 0; i < d; ++i) out[r * d + i] = z[i];
+}
+__global__ void philox_uniforms_kernel(unsigned long long seed, unsigned step0, unsigned traj0, int T, int N,
+                                       float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T * N) return;
+  out[i] = mmf_philox_uniform(seed, step0 + static_cast<unsigned>(i / N), traj0 + static_cast<unsigned>(i % N));
+}
+}  // namespace
+
+extern "C" int mmf_philox_normals(unsigned long long seed, unsigned step, unsigned traj0, float* out, int N, int M,
+                                  int d, void* stream) {
+  if (!out || N < 0 || M < 1 || d < 1 || d > 4) return MMF_EINVAL;
+  const size_t R = static_cast<size_t>(N) * M;
+  if (R == 0) return 0;
+  philox_normals_kernel<<<static_cast<unsigned>((R + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      seed, step, traj0, M, d, R, out);
+  MMF_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int mmf_philox_uniforms(unsigned long long seed, unsigned step0, unsigned traj0, float* out, int T, int N,
+                                   void* stream) {
+  if (!out || T < 0 || N < 0) return MMF_EINVAL;
+  if (T * N == 0) return 0;
+  philox_uniforms_kernel<<<(T * N + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(seed, step0, traj0, T, N, out);
+  MMF_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int mmf_pf_measure(const float* packed, int n_res, int precision, const float* states,

@@ -14,7 +14,7 @@ static int pf_enqueue_steps(const MmfPfLoopArgs* a, void* stream, bool with_even
   if (!a) return MMF_EINVAL;
   if (a->T < 0 || a->N < 1 || a->M < 1 || a->n_meas < 1 || a->n_meas > MMF_LOOP_MAX_MEAS) return MMF_EINVAL;
   if (a->resample_mode < 0 || a->resample_mode > 2) return MMF_EINVAL;
-  if (!a->dyn_packed || !a->dyn_bias || !a->noise || !a->scale_tril || !a->states_a || !a->states_b ||
+  if (!a->dyn_packed || !a->dyn_bias || (!a->noise && a->noise_mode != 2) || !a->scale_tril || !a->states_a || !a->states_b ||
       !a->logw_a || !a->logw_b || !a->loglik || !a->estimates)
     return MMF_EINVAL;
   if (a->resample_mode != 0 && !a->uniforms) return MMF_EINVAL;
@@ -39,9 +39,14 @@ static int pf_enqueue_steps(const MmfPfLoopArgs* a, void* stream, bool with_even
     int rc;
     sampled = a->events && t % stride == stride / 2;  // the middle step of every stride-long window
     if ((rc = mark())) return rc;
-    rc = mmf_pf_dynamics(a->dyn_packed, a->n_res_dyn, a->precision, cur, a->dyn_bias + t * row * MMF_UNITS,
-                             a->noise + t * nm * a->d, a->scale_tril, other, a->range_flag, a->N, a->M, a->d,
-                             stream);
+    if (a->noise_mode == 2)
+      rc = mmf_pf_dynamics_philox(a->dyn_packed, a->n_res_dyn, a->precision, cur, a->dyn_bias + t * row * MMF_UNITS,
+                                  a->noise_seed, a->noise_step0 + static_cast<unsigned>(t), a->noise_traj0, a->scale_tril,
+                                  other, a->range_flag, a->N, a->M, a->d, stream);
+    else
+      rc = mmf_pf_dynamics(a->dyn_packed, a->n_res_dyn, a->precision, cur, a->dyn_bias + t * row * MMF_UNITS,
+                           a->noise + t * nm * a->d, a->scale_tril, other, a->range_flag, a->N, a->M, a->d,
+                           stream);
     if (rc) return rc;
     if ((rc = mark())) return rc;
     // parity certificates keep every step's log-likelihoods and ancestors (null on the timed path)

@@ -20,7 +20,7 @@ import torch
 
 from . import _abi, base, engine
 from .engine import _timed, check_range, require_device, reserve_memory, use_autograd
-from .utils import NoiseSource, tree_index, tree_leading_shape, tree_map
+from .utils import CounterBlock, NoiseSource, tree_index, tree_leading_shape, tree_map
 
 _MODES = {"none": 0, "systematic": 1, "multinomial": 2}
 
@@ -317,7 +317,12 @@ class ParticleFilter(base.Filter):
         a.dyn_packed, a.dyn_bias = P(dyn._net.blob()), P(ctrl_all["bias"])
         for k, (net, bias, lw) in enumerate(nets):
             a.meas_packed[k], a.meas_bias[k], a.meas_logw[k] = P(net.blob()), P(bias), P(lw)
-        a.noise, a.scale_tril, a.uniforms = P(eps), P(tril), P(u)
+        if isinstance(eps, CounterBlock):   # counter-based noise: generated inside the dynamics kernel
+            a.noise, a.noise_mode = None, 2
+            a.noise_seed, a.noise_step0, a.noise_traj0 = eps.seed, eps.step0, eps.traj0
+        else:
+            a.noise = P(eps)
+        a.scale_tril, a.uniforms = P(tril), P(u)
         a.states_a, a.states_b, a.logw_a, a.logw_b = P(states_a), P(states_b), P(logw_a), P(logw_b)
         a.loglik, a.estimates = P(loglik), P(est)
         if self.record_indices:
@@ -371,6 +376,11 @@ class ParticleFilter(base.Filter):
         if len(nets) > _abi.LOOP_MAX_MEAS:
             return None
         eps, _ = self.noise.draw_steps(T, (N, M, d), None, like=self.particle_states)
+        if isinstance(eps, CounterBlock):  # the training recursion reads its noise from a tensor
+            blk = eps
+            eps = torch.empty((T, N, M, d), dtype=torch.float32, device=self.particle_states.device)
+            for t in range(T):
+                _abi.philox_normals(blk.seed, blk.step0 + t, blk.traj0, eps[t])
         params = list(dyn._net._sources())
         for net, _col in nets:
             params += net._sources()

@@ -129,3 +129,59 @@ class StackedNoise(NoiseSource):
             self._tu += T
         return g.to(device=like.device, dtype=torch.float32).contiguous(), \
             None if u is None else u.to(device=like.device, dtype=torch.float32).contiguous()
+
+
+class CounterBlock:
+    """Marker returned by ``CounterNoise.draw_steps`` in place of a ``(T, N, M, d)`` tensor: the ``T``
+    per-step noise blocks are counter steps ``step0 .. step0 + T - 1`` of ``seed`` -- generated inside the
+    dynamics kernel, never materialised."""
+
+    def __init__(self, seed: int, step0: int, traj0: int, T: int, shape):
+        self.seed, self.step0, self.traj0, self.T, self.shape = seed, step0, traj0, T, tuple(shape)
+
+
+class CounterNoise(NoiseSource):
+    """Counter-based randomness (``include/mmf_philox.h``): every ``(N, M, d)`` Gaussian block is counter
+    step ``t`` of Philox4x32-10 under ``seed`` -- a pure function of (seed, t, global trajectory index,
+    particle) -- and every ``(N,)`` block of resampling uniforms likewise.  A native ``forward_loop``
+    generates the Gaussians inside the dynamics kernel (no ``(T, N, M, d)`` tensor exists); step-by-step
+    use materialises one block per call with ``mmf_philox_normals``; ``oracle.strict.philox_normals``
+    reproduces every draw bit for bit on the CPU.  ``traj_offset``: index of this shard's first
+    trajectory, so a sharded run draws what the unsharded one would."""
+
+    def __init__(self, seed: int = 0, traj_offset: int = 0):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.traj_offset = int(traj_offset)
+        self.step_gaussian = 0
+        self.step_uniform = 0
+
+    def gaussian(self, shape, *, like: torch.Tensor) -> torch.Tensor:
+        from . import _abi
+
+        assert len(shape) == 3 and shape[2] <= 4, "counter noise draws (N, M, d <= 4) blocks"
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=like.device)
+        _abi.philox_normals(self.seed, self.step_gaussian, self.traj_offset, out)
+        self.step_gaussian += 1
+        return out
+
+    def uniform(self, shape, *, like: torch.Tensor) -> torch.Tensor:
+        from . import _abi
+
+        assert len(shape) == 1, "counter noise draws one uniform per trajectory (systematic resampling)"
+        out = torch.empty((1, shape[0]), dtype=torch.float32, device=like.device)
+        _abi.philox_uniforms(self.seed, self.step_uniform, self.traj_offset, out)
+        self.step_uniform += 1
+        return out[0]
+
+    def draw_steps(self, T: int, gauss_shape, unif_shape, *, like: torch.Tensor):
+        from . import _abi
+
+        block = CounterBlock(self.seed, self.step_gaussian, self.traj_offset, T, gauss_shape)
+        self.step_gaussian += T
+        u = None
+        if unif_shape is not None:
+            assert len(unif_shape) == 1
+            u = torch.empty((T, unif_shape[0]), dtype=torch.float32, device=like.device)
+            _abi.philox_uniforms(self.seed, self.step_uniform, self.traj_offset, u)
+            self.step_uniform += T
+        return block, u

@@ -14,7 +14,7 @@ import ctypes
 import math
 import os
 import subprocess
-from ctypes import POINTER, c_float, c_int, c_int32, c_long, c_void_p
+from ctypes import POINTER, c_float, c_int, c_int32, c_long, c_uint32, c_uint64, c_void_p
 
 import numpy as np
 import torch
@@ -25,7 +25,7 @@ from .. import resample as _rs
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "mmf_strict.c")
 LIB = os.path.join(HERE, "_build", "libmmf_strict.so")
-HEADER = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "mmf_detmath.h")
+HEADERS = [os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", h) for h in ("mmf_detmath.h", "mmf_philox.h")]
 # -mavx2 -mfma (x86-64-v3): the build container and the GPU box's EPYC hosts both have them;
 # -ffp-contract=off: the only fused operations are the explicit fmaf calls
 CFLAGS = ["-O3", "-mavx2", "-mfma", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", "-std=c11"]
@@ -36,7 +36,7 @@ _lib = None
 
 def build(force: bool = False) -> str:
     stale = force or not os.path.exists(LIB) or any(
-        os.path.getmtime(f) > os.path.getmtime(LIB) for f in (SRC, HEADER))
+        os.path.getmtime(f) > os.path.getmtime(LIB) for f in [SRC] + HEADERS)
     if stale:
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
         subprocess.run(["gcc", *CFLAGS, "-o", LIB + ".tmp", SRC, "-lm"], check=True)
@@ -66,9 +66,14 @@ def lib():
         L.strict_measure_epilogue.argtypes = [P, c_float, P, c_int, c_long, c_int, c_int, P]
         L.strict_dynamics_epilogue.argtypes = [P, P, P, P, P, c_long, c_int, P]
         L.strict_estimate.argtypes = [P, P, c_long, c_int, c_int, c_int, P]
+        L.strict_philox_normals.argtypes = [c_uint64, c_uint32, c_uint32, c_long, c_int, c_int, P]
+        L.strict_philox_uniforms.argtypes = [c_uint64, c_uint32, c_uint32, c_int, c_int, P]
+        L.strict_philox_raw.argtypes = [c_uint32] * 6 + [P]
+        L.strict_philox_raw.restype = None
         for f in ("strict_det_exp_nonpos", "strict_det_log", "strict_det_sigmoid", "strict_det_logaddexp",
                   "strict_linear", "strict_conv", "strict_fc_tail", "strict_particle_net",
-                  "strict_measure_epilogue", "strict_dynamics_epilogue", "strict_estimate"):
+                  "strict_measure_epilogue", "strict_dynamics_epilogue", "strict_estimate",
+                  "strict_philox_normals", "strict_philox_uniforms"):
             getattr(L, f).restype = None
         _lib = L
     return _lib
@@ -109,6 +114,28 @@ def det_logaddexp(a, b):
     y = np.empty_like(a)
     lib().strict_det_logaddexp(_p(a), _p(b), _p(y), a.size)
     return y
+
+
+# ------------------------------------------------------------------ counter-based noise
+def philox_normals(seed: int, step: int, N: int, M: int, d: int, traj0: int = 0) -> np.ndarray:
+    """``(N, M, d)`` standard normals of counter step ``step`` (``include/mmf_philox.h``): what
+    ``mmf_pf_dynamics_philox`` generates in its epilogue / ``mmf_philox_normals`` materialises."""
+    out = np.empty((N, M, d), dtype=_F)
+    lib().strict_philox_normals(seed, step, traj0, N, M, d, _p(out))
+    return out
+
+
+def philox_raw(key, counter):
+    """Philox4x32-10 block: ``key`` (2 u32), ``counter`` (4 u32) -> 4 u32."""
+    out = np.empty(4, dtype=np.uint32)
+    lib().strict_philox_raw(*[int(k) for k in key], *[int(c) for c in counter], _p(out))
+    return [int(x) for x in out]
+
+
+def philox_uniforms(seed: int, step0: int, T: int, N: int, traj0: int = 0) -> np.ndarray:
+    out = np.empty((T, N), dtype=_F)
+    lib().strict_philox_uniforms(seed, step0, traj0, T, N, _p(out))
+    return out
 
 
 # ------------------------------------------------------------------ layers

@@ -33,6 +33,7 @@
 #include <string.h>
 
 #include "../../include/mmf_detmath.h"
+#include "../../include/mmf_philox.h"
 
 #define UNITS 64
 #define PB 16 /* particles evaluated together (the inner, vectorised loop) */
@@ -327,4 +328,23 @@ void strict_estimate(const float* e, const float* states, long N, int M, int D, 
     for (int c = 0; c < D; ++c) estimate[n * D + c] = tot[1 + c] / tot[0];
     free(part);
   }
+}
+
+/* ------------------------------------------------------------------ counter-based noise (include/mmf_philox.h)
+ * the draws the dynamics kernel generates in its epilogue (mmf_pf_dynamics_philox), materialised */
+void strict_philox_normals(uint64_t seed, uint32_t step, uint32_t traj0, long N, int M, int d, float* out) {
+#pragma omp parallel for schedule(static)
+  for (long r = 0; r < N * M; ++r) {
+    float z[4];
+    mmf_philox_normal4(seed, step, traj0 + (uint32_t)(r / M), (uint32_t)(r % M), z);
+    for (int i = 0; i < d; ++i) out[r * d + i] = z[i];
+  }
+}
+
+void strict_philox_uniforms(uint64_t seed, uint32_t step0, uint32_t traj0, int T, int N, float* out) {
+  for (int i = 0; i < T * N; ++i) out[i] = mmf_philox_uniform(seed, step0 + (uint32_t)(i / N), traj0 + (uint32_t)(i % N));
+}
+
+void strict_philox_raw(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t* out) {
+  mmf_philox4x32_10(k0, k1, c0, c1, c2, c3, out);
 }

@@ -194,3 +194,63 @@ def test_strict_free_running_filter_bit_exact(f32_mode, cls, N, M, T):
     truth = traj["states"][1:].numpy()
     rmse = lambda est: np.sqrt(((est - truth) ** 2).mean((0, 1)))
     assert np.array_equal(rmse(got), rmse(np.stack(wants)))
+
+
+def test_counter_noise_kernels_match_the_checker():
+    """``mmf_philox_normals`` / ``mmf_philox_uniforms`` (and therefore the draws ``mmf_pf_dynamics_philox``
+    makes in its epilogue: same header, ``include/mmf_philox.h``) against ``oracle.strict``: every bit."""
+    from multimodalfilter_amd import _abi
+
+    dev = _dev()
+    for seed, step, traj0, (N, M, d) in [(0, 0, 0, (3, 300, 3)), (2 ** 63 + 12345, 999, 7, (5, 4096, 2)),
+                                          (77, 3, 100000, (2, 65, 4))]:
+        out = torch.empty((N, M, d), device=dev)
+        _abi.philox_normals(seed, step, traj0, out)
+        _eq(out, strict.philox_normals(seed, step, N, M, d, traj0), "philox normals")
+    u = torch.empty((40, 33), device=dev)
+    _abi.philox_uniforms(5, 11, 2, u)
+    _eq(u, strict.philox_uniforms(5, 11, 40, 33, traj0=2), "philox uniforms")
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_counter_noise_in_kernel_equals_materialised_tensor(precision):
+    """The native loop with ``CounterNoise`` (noise generated inside the dynamics kernel, no
+    ``(T, N, M, d)`` tensor) == the same loop fed the checker's materialised draws through
+    ``StackedNoise`` == step-by-step evaluation with ``CounterNoise``: estimates and belief, bit for bit."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine, synthetic
+
+    dev = _dev()
+    N, M, d, T, seed = 9, 1000, 3, 6, 4242
+    old = engine.DEFAULT_PRECISION
+    engine.set_default_precision(precision)
+    try:
+        torch.manual_seed(0)
+        f = mmf.door_models.DoorCrossmodalParticleFilter().to(dev).eval()
+        f.num_particles = M
+        traj = {k: v.to(dev) for k, v in synthetic.make_trajectories(state_dim=d, T=T, N=N, seed=5).items()}
+        obs = {k: traj[k][1:] for k in ("image", "gripper_pos", "gripper_sensors")}
+        ctrl = traj["controls"][1:]
+        cov = (torch.eye(d, device=dev) * 0.1)[None].expand(N, d, d)
+
+        def run(noise, loop=True):
+            f.noise = noise
+            f.initialize_beliefs(mean=traj["states"][0], covariance=cov)
+            if loop:
+                est = f.forward_loop(observations=obs, controls=ctrl)
+            else:
+                est = torch.stack([f(observations={k: v[t] for k, v in obs.items()}, controls=ctrl[t]) for t in range(T)])
+            return est, f.particle_states.clone(), f.particle_log_weights.clone()
+
+        a = run(mmf.CounterNoise(seed))
+        eps0 = torch.from_numpy(strict.philox_normals(seed, 0, N, M, d)).to(dev)
+        eps = torch.from_numpy(np.stack([strict.philox_normals(seed, 1 + t, N, M, d) for t in range(T)])).to(dev)
+        us = torch.from_numpy(strict.philox_uniforms(seed, 0, T, N)).to(dev)
+        b = run(mmf.StackedNoise(eps0, eps, us))
+        c = run(mmf.CounterNoise(seed), loop=False)
+    finally:
+        engine.set_default_precision(old)
+    for x, y, z in zip(a, b, c):
+        assert torch.equal(x, y) and torch.equal(x, z)
+    # sharding: trajectories 4.. of the batch, run alone with traj_offset = 4, draw the same noise
+    assert torch.equal(torch.from_numpy(strict.philox_normals(seed, 3, 5, M, d, traj0=4)).to(dev), eps[2][4:9])

@@ -100,3 +100,49 @@ def test_strict_particle_filter_tracks_the_torch_oracle(cls):
             idx_o = o.last_resample_indices.numpy()
             bad = int((idx_o != s.last_resample_indices).sum())
             assert bad <= 2, (t, bad)
+
+
+def _philox_python(key, ctr, rounds=10):
+    """Philox4x32 from its definition (Salmon et al., SC'11), in Python integers."""
+    M0, M1, W0, W1, mask = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85, 0xFFFFFFFF
+    k0, k1 = key
+    c = list(ctr)
+    for _ in range(rounds):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k0) & mask, p1 & mask, ((p0 >> 32) ^ c[3] ^ k1) & mask, p0 & mask]
+        k0, k1 = (k0 + W0) & mask, (k1 + W1) & mask
+    return c
+
+
+def test_counter_based_noise_generator():
+    """``include/mmf_philox.h`` as compiled into the checker: Philox4x32-10 against the Random123
+    known-answer vectors and a from-the-definition Python restatement; the Box-Muller normals and the
+    resampling uniforms against their distributions; blocks are functions of (seed, step, trajectory,
+    particle) only, so a shard draws what the whole batch would."""
+    kat = [((0, 0), (0, 0, 0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff, 0xffffffff), (0xffffffff,) * 4, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0xa4093822, 0x299f31d0), (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for key, ctr, want in kat:
+        assert tuple(_philox_python(key, ctr)) == want
+        assert tuple(strict.philox_raw(key, ctr)) == want
+    g = np.random.default_rng(5)
+    for _ in range(50):
+        key = [int(x) for x in g.integers(0, 2 ** 32, 2)]
+        ctr = [int(x) for x in g.integers(0, 2 ** 32, 4)]
+        assert strict.philox_raw(key, ctr) == _philox_python(key, ctr)
+    from scipy import stats
+
+    z = strict.philox_normals(1234, 7, 64, 4096, 4)
+    assert np.all(np.isfinite(z)) and abs(float(z.mean())) < 5e-3 and abs(float(z.var()) - 1.0) < 5e-3
+    for i in range(4):
+        assert stats.kstest(z[..., i].ravel()[:200000], "norm").pvalue > 1e-3
+    assert abs(float(np.corrcoef(z[..., 0].ravel(), z[..., 1].ravel())[0, 1])) < 5e-3
+    assert float(np.abs(z).max()) > 4.0          # tails are there (Box-Muller on 23-bit uniforms: up to 5.7 sigma)
+    u = strict.philox_uniforms(1234, 0, 500, 100)
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0 and stats.kstest(u.ravel(), "uniform").pvalue > 1e-3
+    # another step / seed / stream: different draws; a shard reproduces its slice of the whole batch
+    assert not np.array_equal(z, strict.philox_normals(1234, 8, 64, 4096, 4))
+    assert not np.array_equal(z, strict.philox_normals(1235, 7, 64, 4096, 4))
+    assert np.array_equal(strict.philox_normals(1234, 7, 16, 4096, 4, traj0=32), z[32:48])
+    assert np.array_equal(strict.philox_normals(1234, 7, 64, 4096, 3), z[..., :3])
