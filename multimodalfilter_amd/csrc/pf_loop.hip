@@ -113,14 +113,20 @@ void reap_graphs(bool wait) {
   }
 }
 
+// The caller's stream is usually the legacy default stream, which cannot be captured
+// (hipErrorStreamCaptureUnsupported): the launches are captured on a private non-blocking stream and the
+// instantiated graph is launched on the caller's stream, in order with everything already enqueued there.
 template <class F>
 int run_as_graph(hipStream_t hs, F&& enqueue) {
   reap_graphs(false);
-  hipError_t e = hipStreamBeginCapture(hs, hipStreamCaptureModeThreadLocal);
-  if (e != hipSuccess) return static_cast<int>(e);
-  const int rc = enqueue();
+  static hipStream_t capture_stream = nullptr;
+  hipError_t e;
+  if (!capture_stream && (e = hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking)) != hipSuccess)
+    return static_cast<int>(e);
+  if ((e = hipStreamBeginCapture(capture_stream, hipStreamCaptureModeThreadLocal)) != hipSuccess) return static_cast<int>(e);
+  const int rc = enqueue(static_cast<void*>(capture_stream));
   hipGraph_t graph = nullptr;
-  e = hipStreamEndCapture(hs, &graph);
+  e = hipStreamEndCapture(capture_stream, &graph);
   if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
   if (e != hipSuccess) return static_cast<int>(e);
   PendingGraph p{};
@@ -137,7 +143,7 @@ int run_as_graph(hipStream_t hs, F&& enqueue) {
 
 extern "C" int mmf_pf_forward_loop(const MmfPfLoopArgs* a, void* stream) {
   if (a && a->use_graph && !a->events)
-    return run_as_graph(static_cast<hipStream_t>(stream), [&] { return pf_enqueue_steps(a, stream, false); });
+    return run_as_graph(static_cast<hipStream_t>(stream), [&](void* cs) { return pf_enqueue_steps(a, cs, false); });
   return pf_enqueue_steps(a, stream, true);
 }
 

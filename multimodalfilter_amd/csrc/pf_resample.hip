@@ -15,6 +15,22 @@
 
 #include "mmf_common.h"
 
+// Phase stamps for scripts/ubench/k1_phases.hip (compiled out of the library): thread 0 of every
+// workgroup stores s_memtime at phase boundaries into a buffer of its own.
+#ifdef MMF_K1_PHASE_CLOCKS
+__device__ unsigned long long g_k1_stamps[1024][8];
+#define K1_STAMP(i)                                                                          \
+  do {                                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {                                             \
+      unsigned long long t_;                                                                 \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+      g_k1_stamps[blockIdx.x][i] = t_;                                                       \
+    }                                                                                        \
+  } while (0)
+#else
+#define K1_STAMP(i)
+#endif
+
 namespace {
 
 constexpr int kBlock = 1024;  // 16 waves; M = 4096 -> one float4 chunk per thread
@@ -72,6 +88,7 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
     return need_cdf ? reinterpret_cast<const float*>(cdf + i)[0] : xf[i];
   };
 
+  K1_STAMP(0);
   // the first chunk's particle states are requested before anything waits on memory: their
   // latency overlaps pass 1 (log-weights, row maximum, two barriers)
   float st0[4 * D];
@@ -114,6 +131,7 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
   mx = sc.red[0][0];
   for (int w = 1; w < nwaves; ++w) mx = fmaxf(mx, sc.red[w][0]);
   __syncthreads();
+  K1_STAMP(1);
 
   // ---- pass 2: e_i = detexp(x_i - max); float sums for the estimate; integer CDF
   float S = 0.f, acc[D];
@@ -253,6 +271,7 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
     }
     __syncthreads();
   }
+  K1_STAMP(2);
   S = sc.bcast[0];
   if (tid < D) estimate[static_cast<size_t>(n) * D + tid] = sc.bcast[1 + tid] / S;
 
@@ -352,6 +371,7 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
       }
     }
   }
+  K1_STAMP(3);
   if (SOFT) {  // normalise the survivors' weights (every thread revisits the outputs it wrote)
     rsum = mmf::wave_sum(rsum);
     __syncthreads();

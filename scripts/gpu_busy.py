@@ -16,6 +16,7 @@ def main():
     ap.add_argument("trace")
     ap.add_argument("--gap-ms", type=float, default=2.0)
     ap.add_argument("--top", type=int, default=6)
+    ap.add_argument("--kernels", type=int, default=3, help="kernels listed per region")
     args = ap.parse_args()
     rows = []
     with open(args.trace) as fh:
@@ -36,9 +37,9 @@ def main():
         busy = sum(e - s for s, e, _ in reg)
         names = {}
         for s, e, n in reg:
-            k = n.split("(")[0][:60]
+            k = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:70]
             names[k] = names.get(k, 0) + (e - s)
-        top = sorted(names.items(), key=lambda kv: -kv[1])[:3]
+        top = sorted(names.items(), key=lambda kv: -kv[1])[:args.kernels]
         out.append({"span_ms": span / 1e6, "kernel_ms": busy / 1e6, "busy": busy / max(span, 1), "launches": len(reg),
                     "mean_gap_us": (span - busy) / max(len(reg) - 1, 1) / 1e3,
                     "top": [(k, round(v / 1e6, 3)) for k, v in top]})
