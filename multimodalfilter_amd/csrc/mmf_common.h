@@ -15,32 +15,66 @@
 
 namespace mmf {
 
+// ---- wave-wide reductions and scans on DPP (row / bank data paths of the VALU) instead of ds_bpermute:
+// a __shfl_xor is an LDS-pipe instruction (~100+ cycles of latency each, 16 waves of K1 sharing the pipe);
+// the DPP forms are plain VALU operands.  Tree of the reductions: xor 1, 2 (quad_perm), 4 (row_half_mirror
+// on quad-uniform values), 8 (row_mirror), then row_bcast15 / row_bcast31 carry the row totals to row 3 --
+// lane 63 holds ((r3 + r2) + (r1 + r0)) with every r_k an ascending-xor butterfly of its 16 lanes, i.e. the
+// result of the butterfly with offsets 1, 2, 4, 8, 16, 32 (oracle/strict restates that tree); it is
+// broadcast with v_readlane.
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppRowHalfMirror = 0x141, kDppRowMirror = 0x140;
+constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+
+// lanes whose DPP source is masked off (row_mask) or out of the row (shifts) get `fill`
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f32(float fill, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ unsigned dpp_u32(unsigned fill, unsigned v) {
+  return static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(fill), static_cast<int>(v), CTRL, ROW_MASK, 0xf, false));
+}
+
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+  v = fmaxf(v, dpp_f32<kDppXor1>(v, v));
+  v = fmaxf(v, dpp_f32<kDppXor2>(v, v));
+  v = fmaxf(v, dpp_f32<kDppRowHalfMirror>(v, v));
+  v = fmaxf(v, dpp_f32<kDppRowMirror>(v, v));
+  v = fmaxf(v, dpp_f32<kDppRowBcast15, 0xa>(v, v));
+  v = fmaxf(v, dpp_f32<kDppRowBcast31, 0xc>(v, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+#pragma clang fp contract(off)
+  v = v + dpp_f32<kDppXor1>(0.f, v);
+  v = v + dpp_f32<kDppXor2>(0.f, v);
+  v = v + dpp_f32<kDppRowHalfMirror>(0.f, v);
+  v = v + dpp_f32<kDppRowMirror>(0.f, v);
+  v = v + dpp_f32<kDppRowBcast15, 0xa>(0.f, v);
+  v = v + dpp_f32<kDppRowBcast31, 0xc>(0.f, v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Inclusive scan across the 64 lanes of a wave (u32; Kogge-Stone inside each row of 16 with row_shr, then the
+// row totals through row_bcast15 / row_bcast31).  The caller guarantees the wave total fits 32 bits.
+__device__ __forceinline__ unsigned wave_inclusive_scan_u32(unsigned v) {
+  v += dpp_u32<kDppRowShr1>(0u, v);
+  v += dpp_u32<kDppRowShr2>(0u, v);
+  v += dpp_u32<kDppRowShr4>(0u, v);
+  v += dpp_u32<kDppRowShr8>(0u, v);
+  v += dpp_u32<kDppRowBcast15, 0xa>(0u, v);
+  v += dpp_u32<kDppRowBcast31, 0xc>(0u, v);
   return v;
 }
 
-__device__ __forceinline__ unsigned long long shfl_up_u64(unsigned long long v, int o) {
-  unsigned lo = __shfl_up(static_cast<unsigned>(v), o);
-  unsigned hi = __shfl_up(static_cast<unsigned>(v >> 32), o);
-  return (static_cast<unsigned long long>(hi) << 32) | lo;
-}
-
-// Inclusive scan across the 64 lanes of a wave.
-__device__ __forceinline__ unsigned long long wave_inclusive_scan(unsigned long long v, int lane) {
-#pragma unroll
-  for (int o = 1; o < MMF_WAVE; o <<= 1) {
-    unsigned long long t = shfl_up_u64(v, o);
-    if (lane >= o) v += t;
-  }
-  return v;
+// u64 inclusive scan of per-lane values below 2^40: two u32 scans of the low 20 and the high 20 bits (each
+// wave total below 2^26), recombined -- exact, no carries to propagate across lanes.
+__device__ __forceinline__ unsigned long long wave_inclusive_scan(unsigned long long v, int /*lane*/) {
+  const unsigned lo = wave_inclusive_scan_u32(static_cast<unsigned>(v) & 0xFFFFFu);
+  const unsigned hi = wave_inclusive_scan_u32(static_cast<unsigned>(v >> 20));
+  return (static_cast<unsigned long long>(hi) << 20) + lo;
 }
 
 // Deterministic fp32 exp for x <= 0: the exact operation sequence of

@@ -41,6 +41,7 @@ struct Scratch {  // lives behind the slots in dynamic LDS
   float red[kMaxWaves][MMF_MAX_STATE_DIM + 1];
   unsigned long long wave_tot[kMaxWaves];
   float bcast[MMF_MAX_STATE_DIM + 2];
+  unsigned wave_cnt[kMaxWaves];
 };
 
 // STAGE: the particle states are kept in LDS next to the CDF (M * 4D more bytes), so the gather
@@ -389,6 +390,247 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
   }
 }
 
+
+// ---- plain systematic resampling WITHOUT a search (the bench's and the reference's evaluation mode).
+// Same fixed-point definition (oracle/resample.py), evaluated from the input side: particle i is the
+// ancestor of the outputs k with cdf_{i-1} <= p_k < cdf_i, and since p_k = (k Q + R) // M_out is
+// non-decreasing, #{k : p_k < cdf_i} = k_end(i) = ceil((cdf_i M_out - R) / Q) (0 when cdf_i M_out <= R,
+// at most M_out).  So:  marks[k_end(i)] += 1  (LDS atomics; particles whose k_end is M_out have no later
+// output to influence),  ancestor(k) = #{i : k_end(i) <= k} = inclusive prefix sum of marks  (one more block
+// scan, on DPP).  No dependent chain of LDS reads per output (the bisection / galloping search was a third
+// of the kernel, a constant ~73 of ~230 stamp units whatever M: scripts/ubench/k1_phases.hip), and a thread
+// needs only the CDF entries of its own four particles, which it still holds in registers.
+template <int D, bool STAGE>
+__global__ __launch_bounds__(kBlock) void pf_resample_systematic_kernel(
+    const float* __restrict__ loglik, const float* __restrict__ logw_in, const float* __restrict__ states_in,
+    const float* __restrict__ u, float* __restrict__ estimate, float* states_out, float* logw_out,
+    int32_t* __restrict__ indices_out, int M, int M_out, float lw_uniform, float log_uniform) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const size_t slots_sz = (static_cast<size_t>(M) * 8 + 15) & ~static_cast<size_t>(15);
+  unsigned long long* cdf = reinterpret_cast<unsigned long long*>(smem);  // first the fp32 x_i, then the u64 CDF
+  Scratch& sc = *reinterpret_cast<Scratch*>(smem + slots_sz);
+  const size_t sc_sz = (sizeof(Scratch) + 15) & ~static_cast<size_t>(15);
+  unsigned* marks = reinterpret_cast<unsigned*>(smem + slots_sz + sc_sz);                       // [M_out + 4]
+  const size_t marks_sz = ((static_cast<size_t>(M_out) + 4) * 4 + 15) & ~static_cast<size_t>(15);
+  float* xs_lds = reinterpret_cast<float*>(smem + slots_sz + sc_sz + marks_sz);                 // STAGE: [M][D]
+
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & (MMF_WAVE - 1), wave = tid >> 6, nwaves = blockDim.x >> 6;
+  const int chunk = blockDim.x * 4;
+  const float* ll = loglik + static_cast<size_t>(n) * M;
+  const float* lw = logw_in ? logw_in + static_cast<size_t>(n) * M : nullptr;
+  const float* xs = states_in + static_cast<size_t>(n) * M * D;
+  const bool vec = (M & 3) == 0;
+  K1_STAMP(0);
+
+  // first chunk's states in flight before anything waits; marks cleared (ordered by pass 1's barriers)
+  float st0[4 * D];
+  {
+    const int i0 = tid * 4;
+    if (vec && i0 + 3 < M) {
+      const float4* p = reinterpret_cast<const float4*>(xs + static_cast<size_t>(i0) * D);
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const float4 t = p[k];
+        st0[4 * k] = t.x; st0[4 * k + 1] = t.y; st0[4 * k + 2] = t.z; st0[4 * k + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4 * D; ++k) st0[k] = (i0 * D + k < M * D) ? xs[static_cast<size_t>(i0) * D + k] : 0.f;
+    }
+  }
+  for (int k = tid; k < M_out + 4; k += blockDim.x) marks[k] = 0u;
+
+  // ---- pass 1: x_i = logw_i + loglik_i -> LDS, row max
+  float mx = -INFINITY;
+  for (int base = 0; base < M; base += chunk) {
+    const int i0 = base + tid * 4;
+    float v[4];
+    if (vec && i0 + 3 < M) {
+      const float4 a = *reinterpret_cast<const float4*>(ll + i0);
+      const float4 b = lw ? *reinterpret_cast<const float4*>(lw + i0) : make_float4(lw_uniform, lw_uniform, lw_uniform, lw_uniform);
+      v[0] = b.x + a.x; v[1] = b.y + a.y; v[2] = b.z + a.z; v[3] = b.w + a.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (i0 + j < M) ? (lw ? lw[i0 + j] : lw_uniform) + ll[i0 + j] : -INFINITY;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i0 + j < M) { reinterpret_cast<float*>(cdf + i0 + j)[0] = v[j]; mx = fmaxf(mx, v[j]); }
+  }
+  mx = mmf::wave_max(mx);
+  if (lane == 0) sc.red[wave][0] = mx;
+  __syncthreads();
+  mx = sc.red[0][0];
+  for (int w = 1; w < nwaves; ++w) mx = fmaxf(mx, sc.red[w][0]);
+  __syncthreads();
+  K1_STAMP(1);
+
+  // ---- pass 2: e_i, fixed-point q_i, float sums of the estimate, integer CDF (kept in LDS for multi-chunk rows)
+  float S = 0.f, acc[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) acc[c] = 0.f;
+  unsigned long long carry = 0;
+  unsigned long long own[4] = {0, 0, 0, 0};  // CDF of this thread's particles in the LAST chunk it owns
+  for (int base = 0; base < M; base += chunk) {
+    const int i0 = base + tid * 4;
+    float e[4];
+    unsigned long long q[4], tsum = 0;
+    float st[4 * D];
+    if (base == 0) {
+#pragma unroll
+      for (int k = 0; k < 4 * D; ++k) st[k] = st0[k];
+    } else if (vec && i0 + 3 < M) {
+      const float4* p = reinterpret_cast<const float4*>(xs + static_cast<size_t>(i0) * D);
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const float4 t = p[k];
+        st[4 * k] = t.x; st[4 * k + 1] = t.y; st[4 * k + 2] = t.z; st[4 * k + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4 * D; ++k) st[k] = (i0 * D + k < M * D) ? xs[static_cast<size_t>(i0) * D + k] : 0.f;
+    }
+    if (STAGE) {
+#pragma unroll
+      for (int k = 0; k < 4 * D; ++k)
+        if (i0 * D + k < M * D) xs_lds[i0 * D + k] = st[k];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = i0 + j < M;
+      e[j] = ok ? mmf::detexp(reinterpret_cast<const float*>(cdf + i0 + j)[0] - mx) : 0.f;
+      q[j] = static_cast<unsigned long long>(floorf(e[j] * 16777216.0f));
+      tsum += q[j];
+      S += e[j];
+#pragma unroll
+      for (int c = 0; c < D; ++c) acc[c] = __builtin_fmaf(e[j], st[j * D + c], acc[c]);  // explicit: oracle/strict restates this chain
+    }
+    const unsigned long long incl = mmf::wave_inclusive_scan(tsum, lane);
+    if (lane == MMF_WAVE - 1) sc.wave_tot[wave] = incl;
+    const bool last_chunk = base + chunk >= M;
+    if (last_chunk) {  // the float sums of the estimate ride on the last chunk's barriers
+      const float Sw = mmf::wave_sum(S);
+      float aw[D];
+#pragma unroll
+      for (int c = 0; c < D; ++c) aw[c] = mmf::wave_sum(acc[c]);
+      if (lane == 0) {
+        sc.red[wave][0] = Sw;
+#pragma unroll
+        for (int c = 0; c < D; ++c) sc.red[wave][1 + c] = aw[c];
+      }
+    }
+    __syncthreads();
+    if (last_chunk && tid <= D) {
+      float t = 0.f;
+      for (int w = 0; w < nwaves; ++w) t += sc.red[w][tid];
+      sc.bcast[tid] = t;
+    }
+    unsigned long long before = carry, total = 0;
+    for (int w = 0; w < nwaves; ++w) {
+      const unsigned long long t = sc.wave_tot[w];
+      if (w < wave) before += t;
+      total += t;
+    }
+    unsigned long long run = before + incl - tsum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      run += q[j];
+      own[j] = run;
+      if (!last_chunk && i0 + j < M) cdf[i0 + j] = run;  // earlier chunks wait in LDS for Q
+    }
+    carry += total;
+    __syncthreads();
+  }
+  K1_STAMP(2);
+  const unsigned long long Q = carry;  // every thread has added every chunk's total
+  S = sc.bcast[0];
+  if (tid < D) estimate[static_cast<size_t>(n) * D + tid] = sc.bcast[1 + tid] / S;
+
+  // ---- offspring boundaries: marks[k_end(i)] += 1
+  {
+    const unsigned long long U = static_cast<unsigned long long>(floorf(u[n] * 16777216.0f));
+    const unsigned long long R = (U * Q) >> kFixBits;
+    const double rq = 1.0 / static_cast<double>(Q);
+    const unsigned long long Mo = static_cast<unsigned long long>(M_out);
+    for (int base = 0; base < M; base += chunk) {
+      const int i0 = base + tid * 4;
+      const bool last_chunk = base + chunk >= M;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (i0 + j >= M) continue;
+        const unsigned long long c = (last_chunk ? own[j] : cdf[i0 + j]) * Mo;   // < 2^53 for M, M_out <= 20000
+        unsigned long long kend = 0;
+        if (c > R) {
+          const unsigned long long num = c - R;
+          kend = static_cast<unsigned long long>(static_cast<double>(num) * rq);  // floor(num / Q) up to +-1
+          while (kend * Q < num) ++kend;                                          // -> ceil(num / Q), exactly
+          while (kend > 0 && (kend - 1) * Q >= num) --kend;
+        }
+        if (kend < Mo) atomicAdd(&marks[static_cast<int>(kend)], 1u);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- ancestor(k) = inclusive prefix sum of marks; gather; store
+  float* so = states_out + static_cast<size_t>(n) * M_out * D;
+  float* lo = logw_out ? logw_out + static_cast<size_t>(n) * M_out : nullptr;
+  int32_t* io = indices_out ? indices_out + static_cast<size_t>(n) * M_out : nullptr;
+  const bool vec_out = (M_out & 3) == 0;
+  unsigned carry2 = 0;
+  for (int base = 0; base < M_out; base += chunk) {
+    const int k0 = base + tid * 4;
+    unsigned m[4] = {0u, 0u, 0u, 0u};
+    if (k0 < M_out) {
+      const uint4 t = *reinterpret_cast<const uint4*>(marks + k0);  // marks is padded by 4 zero entries
+      m[0] = t.x; m[1] = t.y; m[2] = t.z; m[3] = t.w;
+    }
+    const unsigned tsum = m[0] + m[1] + m[2] + m[3];
+    const unsigned incl = mmf::wave_inclusive_scan_u32(tsum);
+    if (lane == MMF_WAVE - 1) sc.wave_cnt[wave] = incl;
+    __syncthreads();
+    unsigned before = carry2, total = 0;
+    for (int w = 0; w < nwaves; ++w) {
+      const unsigned t = sc.wave_cnt[w];
+      if (w < wave) before += t;
+      total += t;
+    }
+    carry2 += total;
+    int idx[4];
+    float g[4 * D];
+    unsigned run = before + incl - tsum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      run += m[j];
+      idx[j] = static_cast<int>(run);
+      const int src = (k0 + j < M_out) ? idx[j] : 0;
+#pragma unroll
+      for (int c = 0; c < D; ++c) g[j * D + c] = STAGE ? xs_lds[src * D + c] : xs[static_cast<size_t>(src) * D + c];
+    }
+    if (vec_out && k0 + 3 < M_out) {
+      float4* p = reinterpret_cast<float4*>(so + static_cast<size_t>(k0) * D);
+#pragma unroll
+      for (int k = 0; k < D; ++k) p[k] = make_float4(g[4 * k], g[4 * k + 1], g[4 * k + 2], g[4 * k + 3]);
+      if (lo) *reinterpret_cast<float4*>(lo + k0) = make_float4(log_uniform, log_uniform, log_uniform, log_uniform);
+      if (io) *reinterpret_cast<int4*>(io + k0) = make_int4(idx[0], idx[1], idx[2], idx[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + j;
+        if (k < M_out) {
+#pragma unroll
+          for (int c = 0; c < D; ++c) so[static_cast<size_t>(k) * D + c] = g[j * D + c];
+          if (lo) lo[k] = log_uniform;
+          if (io) io[k] = idx[j];
+        }
+      }
+    }
+    if (base + chunk < M_out) __syncthreads();  // wave_cnt is reused by the next chunk
+  }
+  K1_STAMP(3);
+}
+
 }  // namespace
 
 extern "C" size_t mmf_pf_reweight_resample_lds_bytes(int M, int mode) {
@@ -431,6 +673,35 @@ int launch_reweight_resample(const float* loglik, const float* logw_in, const fl
   hipStream_t s = static_cast<hipStream_t>(stream);
   const float lw_uniform = static_cast<float>(-std::log(static_cast<double>(M)));
   const float log_uniform = static_cast<float>(-std::log(static_cast<double>(M_out)));
+  if (mode == 1 && !soft && M <= 20000 && M_out <= 20000) {
+    // plain systematic resampling: the search-free kernel (offspring boundaries + prefix sum of marks)
+    const size_t slots = (static_cast<size_t>(M) * 8 + 15) & ~static_cast<size_t>(15);
+    const size_t sc_sz = (sizeof(Scratch) + 15) & ~static_cast<size_t>(15);
+    const size_t marks_sz = ((static_cast<size_t>(M_out) + 4) * 4 + 15) & ~static_cast<size_t>(15);
+    const size_t base_sz = slots + sc_sz + marks_sz;
+    const size_t with_states = base_sz + static_cast<size_t>(M) * d * sizeof(float);
+    if (base_sz <= 160 * 1024) {
+      const bool st = N <= 256 ? with_states <= 160 * 1024 : with_states <= 80 * 1024;
+      const size_t bytes = st ? with_states : base_sz;
+#define MMF_K1S_LAUNCH(D, ST)                                                                        \
+  {                                                                                                  \
+    if (bytes > 64 * 1024) {                                                                         \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_resample_systematic_kernel<D, ST>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)); \
+      if (e != hipSuccess) return static_cast<int>(e);                                               \
+    }                                                                                                \
+    pf_resample_systematic_kernel<D, ST><<<N, block, bytes, s>>>(loglik, logw_in, states_in, u, estimate, states_out, \
+                                                                 logw_out, indices_out, M, M_out, lw_uniform, log_uniform); \
+  }
+#define MMF_K1S(D) \
+  case D: { if (st) MMF_K1S_LAUNCH(D, true) else MMF_K1S_LAUNCH(D, false) } break;
+      switch (d) { MMF_K1S(1) MMF_K1S(2) MMF_K1S(3) MMF_K1S(4) }
+#undef MMF_K1S
+#undef MMF_K1S_LAUNCH
+      MMF_CHECK_LAUNCH();
+      return 0;
+    }
+  }
 #define MMF_K1_LAUNCH(D, ST, SO)                                                               \
   {                                                                                            \
     if (lds > 64 * 1024) {                                                                     \

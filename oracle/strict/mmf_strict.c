@@ -292,7 +292,7 @@ void strict_dynamics_epilogue(const float* raw, const float* b_head, const float
 /* ------------------------------------------------------------------ K1 weighted-mean estimate
  * pf_resample.hip pass 2: thread `tid` of a `block`-thread workgroup owns particles base + 4 tid + j
  * (j = 0..3) of every chunk base = 0, 4 block, ..; it accumulates S += e and acc_c = fma(e, x_c, acc_c) in
- * that order; a wave's 64 partials are summed by an xor butterfly (offsets 32, 16, .., 1), the waves'
+ * that order; a wave's 64 partials are summed by the DPP tree of mmf::wave_sum (= xor butterfly with offsets 1, 2, .., 32), the waves'
  * totals sequentially; estimate_c = acc_c / S.   e (N, M) = the fp32 weights detexp(x - max). */
 void strict_estimate(const float* e, const float* states, long N, int M, int D, int block, float* estimate) {
 #pragma omp parallel for schedule(static)
@@ -318,12 +318,12 @@ void strict_estimate(const float* e, const float* states, long N, int M, int D, 
       for (int c = 0; c <= D; ++c) {
         float v[64];
         for (int l = 0; l < 64; ++l) v[l] = part[(w * 64 + l) * (D + 1) + c];
-        for (int o = 32; o > 0; o >>= 1) {
+        for (int o = 1; o < 64; o <<= 1) {  /* mmf::wave_sum: DPP tree = xor butterfly 1, 2, 4, .., 32, read at lane 63 */
           float t[64];
           for (int l = 0; l < 64; ++l) t[l] = v[l] + v[l ^ o];
           memcpy(v, t, sizeof(v));
         }
-        tot[c] = tot[c] + v[0];
+        tot[c] = tot[c] + v[63];
       }
     for (int c = 0; c < D; ++c) estimate[n * D + c] = tot[1 + c] / tot[0];
     free(part);
