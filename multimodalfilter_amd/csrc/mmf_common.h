@@ -25,6 +25,7 @@ namespace mmf {
 constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppRowHalfMirror = 0x141, kDppRowMirror = 0x140;
 constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
 constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppWaveShr1 = 0x138;  // lane l reads lane l - 1 across the whole wave (lane 0: fill)
 
 // lanes whose DPP source is masked off (row_mask) or out of the row (shifts) get `fill`
 template <int CTRL, int ROW_MASK = 0xf>
@@ -66,6 +67,17 @@ __device__ __forceinline__ unsigned wave_inclusive_scan_u32(unsigned v) {
   v += dpp_u32<kDppRowShr8>(0u, v);
   v += dpp_u32<kDppRowBcast15, 0xa>(0u, v);
   v += dpp_u32<kDppRowBcast31, 0xc>(0u, v);
+  return v;
+}
+
+// Inclusive prefix maximum across the 64 lanes (same data movement as the sum scan)
+__device__ __forceinline__ unsigned wave_inclusive_scan_max_u32(unsigned v) {
+  v = max(v, dpp_u32<kDppRowShr1>(0u, v));
+  v = max(v, dpp_u32<kDppRowShr2>(0u, v));
+  v = max(v, dpp_u32<kDppRowShr4>(0u, v));
+  v = max(v, dpp_u32<kDppRowShr8>(0u, v));
+  v = max(v, dpp_u32<kDppRowBcast15, 0xa>(0u, v));
+  v = max(v, dpp_u32<kDppRowBcast31, 0xc>(0u, v));
   return v;
 }
 

@@ -471,7 +471,8 @@ __global__ __launch_bounds__(kBlock) void pf_resample_systematic_kernel(
 #pragma unroll
   for (int c = 0; c < D; ++c) acc[c] = 0.f;
   unsigned long long carry = 0;
-  unsigned long long own[4] = {0, 0, 0, 0};  // CDF of this thread's particles in the LAST chunk it owns
+  unsigned long long own[4] = {0, 0, 0, 0};  // CDF of this thread's particles in the LAST chunk
+  unsigned long long own_prev = 0;           // ... and of the particle just before them
   for (int base = 0; base < M; base += chunk) {
     const int i0 = base + tid * 4;
     float e[4];
@@ -533,6 +534,7 @@ __global__ __launch_bounds__(kBlock) void pf_resample_systematic_kernel(
       total += t;
     }
     unsigned long long run = before + incl - tsum;
+    own_prev = run;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       run += q[j];
@@ -547,33 +549,47 @@ __global__ __launch_bounds__(kBlock) void pf_resample_systematic_kernel(
   S = sc.bcast[0];
   if (tid < D) estimate[static_cast<size_t>(n) * D + tid] = sc.bcast[1 + tid] / S;
 
-  // ---- offspring boundaries: marks[k_end(i)] += 1
+  // ---- offspring boundaries: the first particle of every run of equal k_end announces itself,
+  // marks[k_end(i - 1)] = i  when  k_end(i - 1) < k_end(i)  -- one writer per entry, plain LDS stores
   {
     const unsigned long long U = static_cast<unsigned long long>(floorf(u[n] * 16777216.0f));
     const unsigned long long R = (U * Q) >> kFixBits;
-    const double rq = 1.0 / static_cast<double>(Q);
+    const float rq = 1.0f / static_cast<float>(Q);
     const unsigned long long Mo = static_cast<unsigned long long>(M_out);
+    // k_end(c) = #{k >= 0 : k Q + R < c M_out} = ceil((c M_out - R) / Q), at most M_out <= 2^15: a float32
+    // quotient is within 1 of the floor (relative error 2^-22 on a value below 2^15); ONE u64 multiply corrects it
+    auto k_end = [&](unsigned long long cdf_i) -> unsigned {
+      const unsigned long long c = cdf_i * Mo;
+      if (c <= R) return 0u;
+      const unsigned long long num = c - R;
+      const float numf = static_cast<float>(static_cast<unsigned>(num >> 32)) * 4294967296.0f + static_cast<float>(static_cast<unsigned>(num));
+      long long fl = static_cast<long long>(numf * rq);
+      long long rem = static_cast<long long>(num) - fl * static_cast<long long>(Q);
+      if (rem < 0) { --fl; rem += static_cast<long long>(Q); }
+      if (rem >= static_cast<long long>(Q)) { ++fl; rem -= static_cast<long long>(Q); }
+      const unsigned long long ke = static_cast<unsigned long long>(fl) + (rem > 0 ? 1u : 0u);
+      return static_cast<unsigned>(ke < Mo ? ke : Mo);
+    };
     for (int base = 0; base < M; base += chunk) {
       const int i0 = base + tid * 4;
+      if (i0 >= M) continue;
       const bool last_chunk = base + chunk >= M;
+      unsigned long long c[5];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (i0 + j >= M) continue;
-        const unsigned long long c = (last_chunk ? own[j] : cdf[i0 + j]) * Mo;   // < 2^53 for M, M_out <= 20000
-        unsigned long long kend = 0;
-        if (c > R) {
-          const unsigned long long num = c - R;
-          kend = static_cast<unsigned long long>(static_cast<double>(num) * rq);  // floor(num / Q) up to +-1
-          while (kend * Q < num) ++kend;                                          // -> ceil(num / Q), exactly
-          while (kend > 0 && (kend - 1) * Q >= num) --kend;
-        }
-        if (kend < Mo) atomicAdd(&marks[static_cast<int>(kend)], 1u);
-      }
+      for (int j = 0; j < 4; ++j) c[j + 1] = last_chunk ? own[j] : cdf[i0 + j < M ? i0 + j : M - 1];
+      // CDF just before this thread's first particle: its own running sum before q[0] (last chunk), LDS otherwise
+      c[0] = last_chunk ? own_prev : (i0 == 0 ? 0ull : cdf[i0 - 1]);
+      unsigned ke[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) ke[j] = k_end(c[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i0 + j < M && ke[j] < ke[j + 1] && ke[j] < static_cast<unsigned>(M_out)) marks[ke[j]] = static_cast<unsigned>(i0 + j);
     }
   }
   __syncthreads();
 
-  // ---- ancestor(k) = inclusive prefix sum of marks; gather; store
+  // ---- ancestor(k) = the latest announcement at or before k = inclusive prefix MAX of marks; gather; store
   float* so = states_out + static_cast<size_t>(n) * M_out * D;
   float* lo = logw_out ? logw_out + static_cast<size_t>(n) * M_out : nullptr;
   int32_t* io = indices_out ? indices_out + static_cast<size_t>(n) * M_out : nullptr;
@@ -586,24 +602,24 @@ __global__ __launch_bounds__(kBlock) void pf_resample_systematic_kernel(
       const uint4 t = *reinterpret_cast<const uint4*>(marks + k0);  // marks is padded by 4 zero entries
       m[0] = t.x; m[1] = t.y; m[2] = t.z; m[3] = t.w;
     }
-    const unsigned tsum = m[0] + m[1] + m[2] + m[3];
-    const unsigned incl = mmf::wave_inclusive_scan_u32(tsum);
+    m[1] = max(m[1], m[0]); m[2] = max(m[2], m[1]); m[3] = max(m[3], m[2]);
+    const unsigned incl = mmf::wave_inclusive_scan_max_u32(m[3]);
     if (lane == MMF_WAVE - 1) sc.wave_cnt[wave] = incl;
     __syncthreads();
-    unsigned before = carry2, total = 0;
+    unsigned before = carry2, total = carry2;
     for (int w = 0; w < nwaves; ++w) {
       const unsigned t = sc.wave_cnt[w];
-      if (w < wave) before += t;
-      total += t;
+      if (w < wave) before = max(before, t);
+      total = max(total, t);
     }
-    carry2 += total;
+    carry2 = total;
+    // everything announced before this thread's first output: previous waves / chunks and the lanes below
+    const unsigned below = max(before, mmf::dpp_u32<mmf::kDppWaveShr1>(0u, incl));
     int idx[4];
     float g[4 * D];
-    unsigned run = before + incl - tsum;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      run += m[j];
-      idx[j] = static_cast<int>(run);
+      idx[j] = static_cast<int>(max(below, m[j]));
       const int src = (k0 + j < M_out) ? idx[j] : 0;
 #pragma unroll
       for (int c = 0; c < D; ++c) g[j * D + c] = STAGE ? xs_lds[src * D + c] : xs[static_cast<size_t>(src) * D + c];
