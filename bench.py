@@ -116,14 +116,17 @@ def make_inputs(wl, steps, batch, seed, device, state_dim):
     return traj, to_device(traj, device)
 
 
-def run_pf(f, traj_dev, noise_dev, M, mode="systematic"):
+def run_pf(f, traj_dev, noise_dev, M, mode="systematic", traj_offset=0):
     """initialize at states[0] / 0.1 I (eval_helpers.py:125-131), then K steps."""
     import multimodalfilter_amd as mmf
     from multimodalfilter_amd import evaluation
 
-    eps0, eps, us = noise_dev
     f.num_particles = M
     f.resample_mode = mode
+    if noise_dev[0] == "philox":
+        f.noise = mmf.CounterNoise(noise_dev[1], traj_offset=traj_offset)
+        return evaluation.run_filter(f, traj_dev)
+    eps0, eps, us = noise_dev
     # contiguous (T, ...) blocks: the native step loop reads them in place
     eps = eps if torch.is_tensor(eps) else torch.stack(list(eps))
     us = us if torch.is_tensor(us) else torch.stack(list(us))
@@ -591,6 +594,9 @@ def main():
                     help="skip the per-network error measurement against fp64")
     ap.add_argument("--no-f32-mode", action="store_true",
                     help="skip the extra timed pass in exact-f32 mode")
+    ap.add_argument("--noise", default="tensor", choices=["tensor", "philox"],
+                    help="process noise of the timed particle-filter passes: pre-drawn (T, N, M, d) tensor, or "
+                         "counter-based, generated inside the dynamics kernel")
     ap.add_argument("--preroll-seconds", type=float, default=0.3,
                     help="untimed repetitions of the warm-up pass before the W warm-up steps (GPU clock ramp)")
     ap.add_argument("--global-batch", type=int, default=None,
@@ -651,12 +657,17 @@ def main():
         cal_states = traj["states"][0][:, None, :] + 0.3 * torch.randn((B, 256, d), device=device)
         synthetic.calibrate_measurement_heads(
             f, {k: traj[k][0] for k in ("image", "gripper_pos", "gripper_sensors")}, cal_states)
-        noise_w = synthetic.draw_filter_noise(T=max(W, 1), N=B, M=M, state_dim=d, seed=77 + rank)
-        noise = synthetic.draw_filter_noise(T=K, N=B, M=M, state_dim=d, seed=78 + rank)
-        mv = lambda nz: (nz[0].to(device), torch.stack(nz[1]).to(device), torch.stack(nz[2]).to(device))
-        noise_w, noise = mv(noise_w), mv(noise)
+        if args.noise == "philox":
+            # counter-based noise generated inside the dynamics kernel (include/mmf_philox.h): no (T, N, M, d)
+            # tensor exists; trajectories keep their global index, so any sharding draws the same numbers
+            noise_w, noise = ("philox", 77), ("philox", 78)
+        else:
+            noise_w = synthetic.draw_filter_noise(T=max(W, 1), N=B, M=M, state_dim=d, seed=77 + rank)
+            noise = synthetic.draw_filter_noise(T=K, N=B, M=M, state_dim=d, seed=78 + rank)
+            mv = lambda nz: (nz[0].to(device), torch.stack(nz[1]).to(device), torch.stack(nz[2]).to(device))
+            noise_w, noise = mv(noise_w), mv(noise)
         f.reserve(steps=K, batch=B, particles=M)  # memory planned before the warm-up
-        run = lambda tr, nz: run_pf(f, tr, nz, M)
+        run = lambda tr, nz: run_pf(f, tr, nz, M, traj_offset=rank * B)
     else:
         noise_w = noise = None
         run = lambda tr, nz: evaluation.run_filter(f, tr)
@@ -746,7 +757,7 @@ def main():
                    "world_size_seen": world,
                    "parallelism": f"trajectory-sharded x{world}"},
         "posterior_rmse_vs_truth": [float(x) for x in rmse],
-        "preroll_seconds": args.preroll_seconds,
+        "preroll_seconds": args.preroll_seconds, "process_noise": args.noise if wl["kind"] == "pf" else None,
         "pass_order": None if second is None else {
             "headline_first_ms_per_step": 1e3 * elapsed / K,
             "headline_again_after_f32_pass_fp64_study_and_1s_idle_ms_per_step": 1e3 * second / K,
@@ -777,10 +788,10 @@ def main():
             k1 = ks.get("pf_reweight_resample")
             if k1:
                 gbs = k1["bytes_per_launch"] / (k1["avg_ms"] * 1e-3) / 1e9
-                out["roofline_k1"] = {"kernel": f"pf_reweight_resample_kernel<{d}, true>", "bound": "hbm",
+                out["roofline_k1"] = {"kernel": f"pf_resample_systematic_kernel<{d}, true>", "bound": "hbm",
                                       "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": gbs / HBM_PEAK_GBS,
-                                      "traffic": pmc_traffic("pf_reweight_resample_kernel") if default_shape else None}
+                                      "traffic": pmc_traffic("pf_resample_systematic_kernel") if default_shape else None}
         if wl["kind"] != "pf" and "image_encoder" in ks:
             # EKF steps are > 99 % image-encoder MACs: the K4 launch sequence
             # (stem + four 3x3 convolutions + linear tail) is the dominant "kernel"

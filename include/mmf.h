@@ -496,7 +496,10 @@ int mmf_pf_train_backward(const MmfPfTrainArgs* args /* host */, void* stream);
  * LDS slots.
  *   LOAD        slot[dst][0:out_dim] = io[io][row*io_stride + io_off + 0:out_dim]
  *   LINEAR      slot[dst] = act(W cat(slot[src[s]][src_off[s] : src_off[s]+src_dim[s]] ..) + b (+ slot[res]));  W is stored
- *               TRANSPOSED in `weights` at w_off as [sum(src_dim)][out_dim <= 64 ? 64 : 128]
+ *               in `weights` at w_off as the A fragments of v_mfma_f32_16x16x4_f32: per source s, per group g of 16
+ *               input columns (zero-padded), per tile mt of 16 outputs (out_pad = out_dim <= 64 ? 64 : 128):
+ *               [g][mt][lane = 16 q + i][ks] = W[16 mt + i][first column of s + 16 g + 4 ks + q]; the bias (128
+ *               floats, zero-padded) at b_off
  *   STORE       io[io][row*io_stride + io_off + 0:out_dim] = act(slot[src[0]])
  *   STORE_DIAG  io[io][row*io_stride + io_off + 0:d*d] = diag(act(slot[src[0]][0:d])), d = out_dim
  */

@@ -70,8 +70,9 @@ class TrajProgram:
         assert out_dim <= 128 and len(srcs) <= 4
         out_pad = 64 if out_dim <= 64 else 128
         w_off = self._blob_floats
-        self._blob_parts.append(("wT", lin.weight, (c0, c1), out_pad))
-        self._blob_floats += in_total * out_pad
+        dims = [w for _, _, w in srcs]
+        self._blob_parts.append(("wT", lin.weight, (c0, c1, dims), out_pad))
+        self._blob_floats += sum(-(-w // 16) * 16 for w in dims) * out_pad
         b_off = -1
         if bias and lin.bias is not None:
             b_off = self._blob_floats
@@ -115,10 +116,18 @@ class TrajProgram:
         for kind, p, cols, out_pad in self._blob_parts:
             t = p.detach().to(torch.float32)
             if kind == "wT":
-                wt = t[:, cols[0]:cols[1]].t()                     # (in, out)
-                pad = torch.zeros((wt.shape[0], out_pad), dtype=torch.float32, device=t.device)
-                pad[:, : wt.shape[1]] = wt
-                parts.append(pad.reshape(-1))
+                # MFMA A fragments of v_mfma_f32_16x16x4_f32 (csrc/traj_program.hip): per source, per group of
+                # 4 k-steps, per 16-output tile, lane (i, q) holds W[16 mt + i][16 g + 4 ks + q], ks = 0..3
+                c0, _c1, dims = cols
+                MT = out_pad // 16
+                col = c0
+                for dim in dims:
+                    groups = -(-dim // 16)
+                    Wp = torch.zeros((out_pad, 16 * groups), dtype=torch.float32, device=t.device)
+                    Wp[: t.shape[0], :dim] = t[:, col:col + dim]
+                    frag = Wp.view(MT, 16, groups, 4, 4).permute(2, 0, 4, 1, 3)    # (g, mt, q, i, ks)
+                    parts.append(frag.reshape(-1))
+                    col += dim
             else:
                 pad = torch.zeros(128, dtype=torch.float32, device=t.device)
                 pad[: t.numel()] = t
