@@ -715,8 +715,12 @@ def test_native_training_recursion_matches_stepwise(tname, cls, N, M, T, chunk_r
     f = mmf.model_types(tname)[cls]().to(dev).train()
     f.num_particles = M
     engine.set_training_backend("hip")
-    old_chunk = engine.TRAIN_CHUNK_ROWS
+    old_chunk, old_prec = engine.TRAIN_CHUNK_ROWS, engine.DEFAULT_PRECISION
     engine.TRAIN_CHUNK_ROWS = chunk_rows
+    # both paths on exact-fp32 products: with the default f16x3 forward the two particle sets differ by ~1e-6,
+    # and on these tiny problems (a few hundred rows) ONE flipped ReLU moves a weight gradient by ~1e-2 of its
+    # largest entry -- a property of the comparison, not of the kernels
+    engine.set_default_precision("f32")
     results = {}
     try:
         for native in (False, True):
@@ -733,6 +737,7 @@ def test_native_training_recursion_matches_stepwise(tname, cls, N, M, T, chunk_r
     finally:
         engine.set_training_backend(None)
         engine.TRAIN_CHUNK_ROWS = old_chunk
+        engine.set_default_precision(old_prec)
         f.use_native_loop = True
     (l0, p0, g0, s0, w0), (l1, p1, g1, s1, w1) = results[False], results[True]
     assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0))
@@ -740,6 +745,6 @@ def test_native_training_recursion_matches_stepwise(tname, cls, N, M, T, chunk_r
     assert float((s0 - s1).abs().max()) < 1e-5 * max(1.0, float(s0.abs().max()))
     assert float((w0 - w1).abs().max()) < 1e-4
     assert set(g0) == set(g1) and len(g0) > 20
-    for name in g0:
-        scale = max(1e-9, float(g0[name].abs().max()))
-        assert float((g0[name] - g1[name]).abs().max()) / scale < GRAD_TOL, name
+    worst = max((float((g0[k] - g1[k]).abs().max()) / max(1e-9, float(g0[k].abs().max())), k) for k in g0)
+    print("largest relative gradient difference:", worst)
+    assert worst[0] < GRAD_TOL, worst
