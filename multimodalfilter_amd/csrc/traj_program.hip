@@ -66,17 +66,11 @@ __device__ __forceinline__ void linear_mfma(const MmfTrajInstr& I, const float* 
     const float* xs = slots + I.src[s] * (kRows * ld) + I.src_off[s] + i * ld + q;
     const int dim = I.src_dim[s];
     const int groups = (dim + 15) >> 4;
-    // the fragments of group g + 1 are requested before group g's MFMAs issue (L2 latency ~1-2 us otherwise
-    // sits between every 16 k-steps of a latency-bound kernel)
-    f32x4 a[MT], an[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(w + mt * 256);
 #pragma unroll 1
     for (int g = 0; g < groups; ++g) {
-      if (g + 1 < groups) {
+      f32x4 a[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) an[mt] = *reinterpret_cast<const f32x4*>(w + ((g + 1) * MT + mt) * 256);
-      }
+      for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(w + (g * MT + mt) * 256);
       float b[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -88,8 +82,6 @@ __device__ __forceinline__ void linear_mfma(const MmfTrajInstr& I, const float* 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
           acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][ks], b[ks], acc[mt], 0, 0, 0);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[mt] = an[mt];
     }
     w += groups * MT * 256;
   }

@@ -696,11 +696,8 @@ def test_native_training_recursion_matches_stepwise(tname, cls, N, M, T, chunk_r
     """``engine.PfTrainLoopFunction`` (``mmf_pf_train_forward`` / ``mmf_pf_train_backward``: the whole
     recursion in two C calls, activations recomputed per chunk of trajectories, weight gradients
     accumulated on the device) against the step-by-step K6 path (one autograd Function per network call):
-    same loss to 1e-5 relative (the native forward runs the inference kernels in the engine's arithmetic
-    mode, the stepwise path evaluates exact-f32 training kernels), every parameter gradient within the
-    file's fp32-vs-fp32 tolerance GRAD_TOL of its largest entry (observed up to 1.3e-3: the two forwards
-    differ by ~1e-6, which flips ReLUs of pre-activations at rounding distance from zero) -- whatever the
-    chunking.  A dropped chunk or step would show as an O(1) difference."""
+    same loss to 1e-5 relative, every parameter gradient within 1e-3 of its scale (observed <= 9e-5) --
+    whatever the chunking.  A dropped chunk or step would show as an O(1) difference."""
     import multimodalfilter_amd as mmf
     from multimodalfilter_amd import engine
 
@@ -745,6 +742,11 @@ def test_native_training_recursion_matches_stepwise(tname, cls, N, M, T, chunk_r
     assert float((s0 - s1).abs().max()) < 1e-5 * max(1.0, float(s0.abs().max()))
     assert float((w0 - w1).abs().max()) < 1e-4
     assert set(g0) == set(g1) and len(g0) > 20
-    worst = max((float((g0[k] - g1[k]).abs().max()) / max(1e-9, float(g0[k].abs().max())), k) for k in g0)
+    # a gradient that is zero analytically (the head bias of a single measurement network: the log-weights are
+    # normalised, a constant added to every log-likelihood changes nothing) is pure rounding noise in both
+    # paths: differences are measured against the larger of the tensor's own scale and 1e-3 of the largest
+    # gradient entry of the model
+    top = max(float(v.abs().max()) for v in g0.values())
+    worst = max((float((g0[k] - g1[k]).abs().max()) / max(1e-3 * top, float(g0[k].abs().max())), k) for k in g0)
     print("largest relative gradient difference:", worst)
-    assert worst[0] < GRAD_TOL, worst
+    assert worst[0] < 1e-3, worst
