@@ -63,21 +63,26 @@ def pmc_traffic(kernel_key: str):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
     collected in separate runs of this same command; FETCH_SIZE doubled as the gfx950 note of
     MI355X_MICROARCH.md prescribes).  ``None`` when no profile of this workload is committed."""
-    path = os.path.join(ROOT, "profiles", "r02", "pmc_hbm_traffic.json")
-    try:
-        with open(path) as fh:
-            kernels = json.load(fh)["kernels"]
-        hits = [v for name, v in kernels.items() if name.startswith(kernel_key)]
-        return hits[0]["hbm_bytes_corrected"] if hits else None
-    except (OSError, KeyError, ValueError):
-        return None
+    for rnd in ("r03", "r02"):       # the newest committed round that profiled this kernel
+        for fname in ("pmc_hbm_traffic.json", "pmc_hbm_traffic_f32.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", rnd, fname)) as fh:
+                    kernels = json.load(fh)["kernels"]
+                hits = [v for name, v in kernels.items() if name.startswith(kernel_key)]
+                if hits:
+                    return hits[0]["hbm_bytes_corrected"]
+            except (OSError, KeyError, ValueError):
+                pass
+    return None
 
 
 def pmc_traffic_k4_sequence(n_images: int, nets: int):
     """HBM bytes of ONE fused image-encoder launch sequence (stem+conv2a, conv2b+conv3, conv 16->8,
     linear partials + tail) from the committed K4 PMC passes (``scripts/bench_k4.py`` under
     rocprofv3, ``profiles/r02/pmc_k4_traffic.json``), for the launch shape that was profiled."""
-    path = os.path.join(ROOT, "profiles", "r02", "pmc_k4_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03", "pmc_k4_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r02", "pmc_k4_traffic.json")
     shapes = {(2048, 2): ("131072", "131072", "131072", "131072", "262144"), (1024, 3): ("130560", "130560", "130560", "98304", "196608")}
     if (n_images, nets) not in shapes:
         return None
@@ -284,6 +289,57 @@ def strict_parity(cls, engine_filter, traj, eps0, eps, us, M):
             "rmse_rel_diff": float((np.abs(rm_e - rm_o) / rm_o).max()),
             "checker": "oracle/strict (C, fmaf chains in the kernels' k-order; <= 2e-6 from the torch oracle)",
             "checker_seconds": round(time.perf_counter() - t0, 1)}
+
+
+def reference_sized_regimes(device):
+    """The sizes the REFERENCE runs (scripts/bench_reference_sizes.py has the CPU twins): evaluation of the door
+    crossmodal PF at 32 trajectories x 300 particles (``door_models/pf.py:24-27``, ``eval_helpers.py:125-142``)
+    and one end-to-end training step at 32 x 30 particles x 16 steps (``train_door.py:63-71``), forward +
+    backward + Adam through the native K6 recursion."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine, synthetic, train
+
+    d = 3
+    out = {}
+    # --- evaluation
+    N, M, T = 32, 300, 200
+    torch.manual_seed(0)
+    f = mmf.door_models.DoorCrossmodalParticleFilter().to(device).eval()
+    synthetic.stabilise_dynamics(f)
+    traj = to_device(synthetic.make_trajectories(state_dim=d, T=T, N=N, seed=5), device)
+    eps0, eps, us = synthetic.draw_filter_noise(T=T, N=N, M=M, state_dim=d, seed=6)
+    noise = (eps0.to(device), torch.stack(eps).to(device), torch.stack(us).to(device))
+    times = []
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_pf(f, traj, noise, M)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    out["eval_32x300"] = {"steps": T, "ms_per_step": 1e3 * best / T, "particle_steps_per_s": N * M * T / best}
+    # --- training
+    N, M, L = 32, 30, 16
+    ft = mmf.door_models.DoorCrossmodalParticleFilter().to(device).train()
+    batch = to_device(synthetic.make_trajectories(state_dim=d, T=L - 1, N=N, seed=11), device)
+    cov = torch.eye(d, device=device) * 0.1
+    engine.set_training_backend("hip")
+    try:
+        opt = torch.optim.Adam(ft.parameters(), lr=1e-4)
+        ft.noise = mmf.NoiseSource(seed=5)
+        times = []
+        for _ in range(7):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            train.train_filter_step(ft, batch, opt, initial_covariance=cov, noise=ft.noise)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    finally:
+        engine.set_training_backend(None)
+    times = sorted(times[2:])
+    out["train_e2e_32x30x16"] = {"ms_per_optimiser_step": 1e3 * times[len(times) // 2],
+                                 "backend": "hip (native K6 recursion: mmf_pf_train_forward / _backward)"}
+    return out
 
 
 def cpu_baseline_pf(wl, engine_filter, state_dim, cores, sample_batch=32, sample_steps=24, warm=1):
@@ -597,6 +653,8 @@ def main():
     ap.add_argument("--noise", default="tensor", choices=["tensor", "philox"],
                     help="process noise of the timed particle-filter passes: pre-drawn (T, N, M, d) tensor, or "
                          "counter-based, generated inside the dynamics kernel")
+    ap.add_argument("--no-reference-sizes", action="store_true",
+                    help="skip the two extra lines at the sizes the reference itself runs (32 x 300 eval, 32 x 30 x 16 training)")
     ap.add_argument("--preroll-seconds", type=float, default=0.3,
                     help="untimed repetitions of the warm-up pass before the W warm-up steps (GPU clock ramp)")
     ap.add_argument("--global-batch", type=int, default=None,
@@ -762,7 +820,7 @@ def main():
             "headline_first_ms_per_step": 1e3 * elapsed / K,
             "headline_again_after_f32_pass_fp64_study_and_1s_idle_ms_per_step": 1e3 * second / K,
             "note": "value / ms_per_step are the FIRST pass (W warm-up steps, then K timed)"},
-        "traffic_source": "profiles/r02/pmc_hbm_traffic.json, pmc_k4_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+        "traffic_source": "profiles/r03 (r02 where a kernel was not re-profiled): pmc_hbm_traffic*.json, pmc_k4_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                           "separate passes; bytes per launch = 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction)",
     }
 
@@ -858,6 +916,9 @@ def main():
                             "dynamics Jacobians f32-equivalent via f16x3 (operands split into two round-to-nearest f16 "
                             f"halves, 3 f16 MFMA products per product, f32 accumulate; error vs fp64 within {worst:.2f}x "
                             "of the exact-f32-product mode on every network, precision_vs_fp64)")
+
+    if world == 1 and wl["kind"] == "pf" and not args.no_reference_sizes:
+        out["reference_sized"] = reference_sized_regimes(device)
 
     if world == 1 and not args.no_cpu_baseline:
         cores = min(CPU_THREADS, os.cpu_count() or 1)

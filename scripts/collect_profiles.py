@@ -81,6 +81,28 @@ def main(src, dst):
         hits = glob.glob(f"{src}/stats_{tag}/**/*_kernel_stats.csv", recursive=True)
         if hits:
             shutil.copy(max(hits, key=os.path.getmtime), f"{dst}/door_{'pf_f32_mode' if tag == 'f32' else 'ekf'}_kernel_stats.csv")
+    # HBM traffic of the variants (exact-f32 kernels, in-kernel philox noise): same reduction, own files
+    for tag in ("f32", "philox"):
+        per_v = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            hits = glob.glob(f"{src}/pmc_{tag}_{counter}/**/*_counter_collection.csv", recursive=True)
+            if not hits:
+                continue
+            with open(max(hits, key=os.path.getmtime)) as fh:
+                for row in csv.DictReader(fh):
+                    if any(k in row["Kernel_Name"] for k in OURS) and row["Counter_Name"] == counter:
+                        per_v.setdefault(short(row["Kernel_Name"]), {}).setdefault(counter, []).append(float(row["Counter_Value"]))
+        rows_v = {}
+        for name, c in sorted(per_v.items()):
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                f = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
+                w = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
+                rows_v[name] = {"FETCH_SIZE": f, "WRITE_SIZE": w, "hbm_bytes_corrected": (2.0 * f + w) * 1024.0,
+                                "launches": len(c["FETCH_SIZE"])}
+        if rows_v:
+            with open(f"{dst}/pmc_hbm_traffic_{tag}.json", "w") as fh:
+                json.dump({"workload": f"door crossmodal PF, N=256, M=4096, variant {tag} (bench.py --{'precision f32' if tag == 'f32' else 'noise philox'})",
+                           "unit": "KB per launch; hbm_bytes_corrected = (2 FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": rows_v}, fh, indent=1)
     k4 = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         hits = glob.glob(f"{src}/pmc_k4_{counter}/**/*_counter_collection.csv", recursive=True)
