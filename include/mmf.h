@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 28
+#define MMF_ABI_VERSION 29
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -217,11 +217,14 @@ int mmf_dynamics_jacobian_multi(const float* const* packed, int n_res, int preci
  *   dW_l = dz[l]^T stash[l], db_l = sum_rows dz[l], d traj_bias[n] = sum_m dz[2][n, m],
  *   dW_in = dz[NL]^T [states, 1], dW_head = d_out^T stash[NL].
  */
+/* `mask` (NL + 1, R, 2) uint32: the sign bits of the stashed activations (bit 16 t + r of word h = feature
+ * 32 t + (r & 3) + 8 (r >> 2) + 4 h), written by the forward, read by the backward's ReLU masks -- 8 B per
+ * particle and layer where round 2 re-read the 256-B activation. */
 int mmf_particle_net_train_forward(const float* packed, int n_res, int kind, const float* states,
-                                   const float* traj_bias, float* stash, float* out, int N, int M,
+                                   const float* traj_bias, float* stash, uint32_t* mask, float* out, int N, int M,
                                    int d, void* stream);
 int mmf_particle_net_train_backward(const float* packed_t, const float* head_w, int n_res, int kind,
-                                    const float* stash, const float* d_out, float* dz, float* d_states,
+                                    const uint32_t* mask, const float* d_out, float* dz, float* d_states,
                                     int R, int d, void* stream);
 
 /* dW_l = dz[l]^T stash[l] and db_l = column sums of dz[l] for l < n_layers, as per-slice partial
@@ -472,6 +475,7 @@ typedef struct MmfPfTrainArgs {
   float* d_states0;
   float* d_logw0;
   float* stash;
+  uint32_t* mask;            /* scratch (max(NLd, NLm) + 1, chunk_traj M, 2): ReLU sign bits of the recomputed activations */
   float* dz;
   float* raw;
   float* d_raw;

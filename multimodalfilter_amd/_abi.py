@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 28
+ABI_VERSION = 29
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
@@ -82,7 +82,7 @@ class MmfPfTrainArgs(Structure):
                 ("dyn_bias", _FP), ("meas_bias", _FP * LOOP_MAX_MEAS), ("meas_logw", _FP * LOOP_MAX_MEAS),
                 ("noise", _FP), ("scale_tril", _FP), ("g_estimates", _FP),
                 ("states", _FP), ("logw", _FP), ("estimates", _FP), ("d_states0", _FP), ("d_logw0", _FP),
-                ("stash", _FP), ("dz", _FP), ("raw", _FP), ("d_raw", _FP), ("loglik", _FP), ("ll_steps", _FP),
+                ("stash", _FP), ("mask", _FP), ("dz", _FP), ("raw", _FP), ("d_raw", _FP), ("loglik", _FP), ("ll_steps", _FP),
                 ("g_states_a", _FP), ("g_states_b", _FP), ("g_logw_a", _FP), ("g_logw_b", _FP), ("d_tmp", _FP),
                 ("range_flag", _FP)]
 
@@ -132,7 +132,7 @@ SIGNATURES = {
     "mmf_ekf_forward_loop": (c_int, [POINTER(MmfEkfLoopArgs), c_void_p]),
     "mmf_dynamics_jacobian_multi": (c_int, [POINTER(c_void_p), c_int, c_int, _FP, POINTER(c_void_p), _FP, _FP, _FP,
                                             c_int, c_int, c_int, c_void_p]),
-    "mmf_particle_net_train_forward": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
+    "mmf_particle_net_train_forward": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_particle_net_weight_grads": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_particle_net_small_grads": (c_int, [_FP] * 9 + [c_int] * 5 + [c_void_p]),
     "mmf_particle_net_weight_grads_acc": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
@@ -352,17 +352,19 @@ def ukf_moments(points, wm0: float, wc0: float, wi: float, q_tril, mu_pred, Sigm
                                       ptr(Sigma_pred), N, d, stream_of(points)), "mmf_ukf_moments")
 
 
-def particle_net_train_forward(packed, n_res: int, kind: int, states, traj_bias, stash, out, N: int, M: int, d: int):
+def particle_net_train_forward(packed, n_res: int, kind: int, states, traj_bias, stash, mask, out, N: int, M: int, d: int):
     with _on(states):
         _check(load().mmf_particle_net_train_forward(ptr(packed), n_res, kind, ptr(states), ptr(traj_bias),
-                                                     ptr(stash), ptr(out), N, M, d, stream_of(states)),
+                                                     ptr(stash), ptr(mask, dtype=torch.int32), ptr(out), N, M, d,
+                                                     stream_of(states)),
                "mmf_particle_net_train_forward")
 
 
-def particle_net_train_backward(packed_t, head_w, n_res: int, kind: int, stash, d_out, dz, d_states, R: int, d: int):
-    with _on(stash):
-        _check(load().mmf_particle_net_train_backward(ptr(packed_t), ptr(head_w), n_res, kind, ptr(stash),
-                                                      ptr(d_out), ptr(dz), ptr(d_states), R, d, stream_of(stash)),
+def particle_net_train_backward(packed_t, head_w, n_res: int, kind: int, mask, d_out, dz, d_states, R: int, d: int):
+    with _on(d_out):
+        _check(load().mmf_particle_net_train_backward(ptr(packed_t), ptr(head_w), n_res, kind,
+                                                      ptr(mask, dtype=torch.int32), ptr(d_out), ptr(dz), ptr(d_states),
+                                                      R, d, stream_of(d_out)),
                "mmf_particle_net_train_backward")
 
 

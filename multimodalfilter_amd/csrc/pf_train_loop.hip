@@ -131,7 +131,7 @@ extern "C" int mmf_pf_train_forward(const MmfPfTrainArgs* a, void* stream) {
 extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
   int rc = check(a);
   if (rc) return rc;
-  if (!a->g_estimates || !a->stash || !a->dz || !a->raw || !a->d_raw || !a->g_states_a || !a->g_states_b || !a->g_logw_a ||
+  if (!a->g_estimates || !a->stash || !a->mask || !a->dz || !a->raw || !a->d_raw || !a->g_states_a || !a->g_states_b || !a->g_logw_a ||
       !a->g_logw_b || !a->d_tmp || !a->d_states0 || !a->d_logw0 || a->chunk_traj < 1 || a->n_splits < 1 || a->n_slices < 1)
     return MMF_EINVAL;
   hipStream_t hs = static_cast<hipStream_t>(stream);
@@ -173,9 +173,9 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
         const MmfTrainNet& net = a->meas[k];
         const float* d_out = K > 1 ? a->d_raw + k * C : d_a + r0;
         rc = mmf_particle_net_train_forward(net.packed_f32, a->n_res_meas, 1, xn + r0 * d,
-                                            a->meas_bias[k] + (t * row + n0) * MMF_UNITS, a->stash, a->raw, Nc, M, d, stream);
+                                            a->meas_bias[k] + (t * row + n0) * MMF_UNITS, a->stash, a->mask, a->raw, Nc, M, d, stream);
         if (rc) return rc;
-        rc = mmf_particle_net_train_backward(net.packed_t, net.head_w, a->n_res_meas, 1, a->stash, d_out, a->dz, a->d_tmp,
+        rc = mmf_particle_net_train_backward(net.packed_t, net.head_w, a->n_res_meas, 1, a->mask, d_out, a->dz, a->d_tmp,
                                              Ci, d, stream);
         if (rc) return rc;
         rc = mmf_particle_net_weight_grads_acc(a->dz, a->stash, net.pw, net.pb, NLm + 1, Ci, S, first_wgrad_meas[k] ? 0 : 1,
@@ -194,12 +194,12 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
       {
         const MmfTrainNet& net = a->dyn;
         rc = mmf_particle_net_train_forward(net.packed_f32, a->n_res_dyn, 0, x + r0 * d,
-                                            a->dyn_bias + (t * row + n0) * MMF_UNITS, a->stash, a->raw, Nc, M, d, stream);
+                                            a->dyn_bias + (t * row + n0) * MMF_UNITS, a->stash, a->mask, a->raw, Nc, M, d, stream);
         if (rc) return rc;
         if (d == 2) dyn_epilogue_bwd_kernel<2><<<blocks(C), kThreads, 0, hs>>>(a->raw, g_tot + r0 * d, a->d_raw, C);
         else dyn_epilogue_bwd_kernel<3><<<blocks(C), kThreads, 0, hs>>>(a->raw, g_tot + r0 * d, a->d_raw, C);
         MMF_CHECK_LAUNCH();
-        rc = mmf_particle_net_train_backward(net.packed_t, net.head_w, a->n_res_dyn, 0, a->stash, a->d_raw, a->dz, a->d_tmp,
+        rc = mmf_particle_net_train_backward(net.packed_t, net.head_w, a->n_res_dyn, 0, a->mask, a->d_raw, a->dz, a->d_tmp,
                                              Ci, d, stream);
         if (rc) return rc;
         rc = mmf_particle_net_weight_grads_acc(a->dz, a->stash, net.pw, net.pb, NLd + 1, Ci, S, first_wgrad_dyn ? 0 : 1, stream);

@@ -340,23 +340,24 @@ class ParticleNetFunction(torch.autograd.Function):
         st = states.detach().to(torch.float32).contiguous()
         tb = traj_bias.detach().to(torch.float32).contiguous()
         stash = torch.empty((NL + 1, R, _abi.MMF_UNITS), dtype=torch.float32, device=states.device)
+        mask = torch.empty((NL + 1, R, 2), dtype=torch.int32, device=states.device)  # ReLU sign bits of the stash
         out = torch.empty((R, net.n_out), dtype=torch.float32, device=states.device)
-        _abi.particle_net_train_forward(net.blob(_abi.PREC_F32), net.n_res, kind, st, tb, stash, out, N, M, d)
+        _abi.particle_net_train_forward(net.blob(_abi.PREC_F32), net.n_res, kind, st, tb, stash, mask, out, N, M, d)
         ctx.net, ctx.kind, ctx.N, ctx.M = net, kind, N, M
-        ctx.save_for_backward(st, stash, *[p.detach() for p in params])
+        ctx.save_for_backward(st, stash, mask, *[p.detach() for p in params])
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         net, kind, N, M = ctx.net, ctx.kind, ctx.N, ctx.M
-        st, stash, *params = ctx.saved_tensors
+        st, stash, mask, *params = ctx.saved_tensors
         R, d = st.shape
         NL = 3 + 2 * net.n_res
         d_out = d_out.to(torch.float32).contiguous()
         head_w = params[-2].to(torch.float32).contiguous()
         dz = torch.empty_like(stash)
         d_states = torch.empty_like(st)
-        _abi.particle_net_train_backward(_transposed_blob(net), head_w, net.n_res, kind, stash, d_out, dz,
+        _abi.particle_net_train_backward(_transposed_blob(net), head_w, net.n_res, kind, mask, d_out, dz,
                                          d_states, R, d)
         grads = [None] * len(params)
         U = _abi.MMF_UNITS
@@ -541,12 +542,13 @@ class PfTrainLoopFunction(torch.autograd.Function):
             if keep["beta"] is not None and col is not None:
                 a.meas_logw[k] = ctypes.c_void_p(keep["beta"].data_ptr() + 4 * col)
         g_est = g_est.to(torch.float32).contiguous()
-        scratch = dict(stash=E(NLmax + 1, C, U), dz=E(NLmax + 1, C, U), raw=E(C, 8), d_raw=E(C, 8), ga=E(N, M, d), gb=E(N, M, d),
+        scratch = dict(stash=E(NLmax + 1, C, U), mask=torch.empty((NLmax + 1, C, 2), dtype=torch.int32, device=dev),
+                       dz=E(NLmax + 1, C, U), raw=E(C, 8), d_raw=E(C, 8), ga=E(N, M, d), gb=E(N, M, d),
                        la=E(N, M), lb=E(N, M), d_tmp=E(C, d), d_states0=E(N, M, d), d_logw0=E(N, M))
         a.dyn_bias, a.noise, a.scale_tril, a.g_estimates = P(keep["dyn_bias"]), P(keep["eps"]), P(keep["tril"]), P(g_est)
         a.states, a.logw, a.estimates = P(keep["states"]), P(keep["logw"]), P(keep["est"])
         a.loglik, a.ll_steps = P(keep["loglik"]), P(keep["ll_steps"])
-        a.stash, a.dz, a.raw, a.d_raw, a.d_tmp = (P(scratch[k]) for k in ("stash", "dz", "raw", "d_raw", "d_tmp"))
+        a.stash, a.mask, a.dz, a.raw, a.d_raw, a.d_tmp = (P(scratch[k]) for k in ("stash", "mask", "dz", "raw", "d_raw", "d_tmp"))
         a.g_states_a, a.g_states_b, a.g_logw_a, a.g_logw_b = P(scratch["ga"]), P(scratch["gb"]), P(scratch["la"]), P(scratch["lb"])
         a.d_states0, a.d_logw0 = P(scratch["d_states0"]), P(scratch["d_logw0"])
         _abi.pf_train_backward(a, g_est)

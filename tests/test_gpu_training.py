@@ -233,9 +233,17 @@ def test_k6_particle_net_function_matches_autograd(task, kind, N, M):
         from multimodalfilter_amd import _abi
         stash = torch.empty((NL + 1, R, 64), dtype=torch.float32, device=dev)
         scratch = torch.empty((R, net.n_out), dtype=torch.float32, device=dev)
+        bits = torch.empty((NL + 1, R, 2), dtype=torch.int32, device=dev)
         _abi.particle_net_train_forward(net.blob(_abi.PREC_F32), net.n_res, 0 if kind == "dynamics" else 1,
-                                        states.detach().contiguous(), tbias.detach().contiguous(), stash, scratch, N, M, d)
+                                        states.detach().contiguous(), tbias.detach().contiguous(), stash, bits, scratch, N, M, d)
         masks = (stash > 0).double()
+        # the sign bits the backward reads are those of the stash: bit 16 t + r of word h <-> feature
+        # 32 t + (r & 3) + 8 (r >> 2) + 4 h
+        feat = torch.tensor([[32 * (b // 16) + ((b % 16) & 3) + 8 * ((b % 16) >> 2) + 4 * h for b in range(32)] for h in range(2)],
+                            device=dev)
+        got = ((bits.long()[..., None] >> torch.arange(32, device=dev)) & 1)          # (NL + 1, R, 2, 32)
+        want = (stash > 0).long()[:, :, feat]                                          # (NL + 1, R, 2, 32)
+        assert torch.equal(got, want)
     layer = [0]
 
     def relu(z):  # the output of every ReLU is the input of the next 64x64 layer (or of the head)
