@@ -50,11 +50,11 @@ int mmf_version(void);
  * dependency; call sites crossmodal/eval_helpers.py:139-142):
  *     logw += loglik; logw -= logsumexp(logw); estimate = sum exp(logw) x;
  *     indices ~ resample(logw); states = gather(states, indices); logw = -log(M_out)
- * as ONE kernel, one workgroup per trajectory: wave-shuffle max/sum reductions, an
- * integer (fixed-point, 2^-24 of the row max) CDF built by an LDS-staged block scan, then
- * systematic (mode 1) or multinomial (mode 2) selection by binary search in LDS.  The
- * integer CDF makes the indices independent of the scan order: bit-exact against
- * oracle/resample.py.
+ * as ONE kernel, one workgroup per trajectory: DPP wave reductions / scans, an integer
+ * (fixed-point, 2^-24 of the row max) CDF, then systematic (mode 1: search-free -- every run of
+ * particles announces the first output it owns, ancestors = prefix maximum of the announcements)
+ * or multinomial (mode 2: binary search in LDS) selection.  The integer CDF makes the indices
+ * independent of the scan order: bit-exact against oracle/resample.py.
  *
  *  loglik      (N, M)          measurement log-likelihoods
  *  logw_in     (N, M)          current log-weights; modes 1/2: null = uniform -log M (nothing is read)
@@ -424,9 +424,10 @@ int mmf_dynamics_forward_loop(const float* packed, int n_res, int precision, con
  *   Only the particle sets states (T+1, N, M, d) and log-weights logw (T+1, N, M) are kept.
  * backward (t = T-1 .. 0): the K6 kernels on RECOMPUTED activations -- the step's stashes are rebuilt by
  *   mmf_particle_net_train_forward from states[t] / states[t+1] for `chunk_traj` trajectories at a time,
- *   into ONE reused pair of buffers sized to stay inside the 256 MiB Infinity Cache (stash -> backward data
- *   path -> weight-gradient GEMM hand-offs are then served on-die); weight-gradient partials accumulate in
- *   place over steps and chunks.  Peak memory: the two chunk buffers + (T+1) particle sets.
+ *   into ONE reused pair of buffers (stash, dz) + the ReLU sign bits; weight-gradient partials accumulate in
+ *   place over steps and chunks.  Peak memory: the chunk buffers + (T+1) particle sets, whatever T.
+ *   (Chunks small enough to keep stash + dz inside the 256 MiB Infinity Cache were measured and lose to
+ *   large ones -- DESIGN.md, K6: the caller picks chunk_traj for memory, not for cache residency.)
  *
  * Buffers (device, fp32, caller-owned).  K = n_meas networks (modalities), NLd = 3 + 2 n_res_dyn, NLm likewise.
  *  in:   dyn_* / meas_*[k]: packed      forward blob (mmf_pack_particle_net, `precision` for the forward pass),

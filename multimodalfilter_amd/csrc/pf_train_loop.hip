@@ -10,10 +10,12 @@
 // Memory / traffic design (MI355X): the forward keeps only the particle sets and log-weights.  The
 // backward RECOMPUTES each step's layer inputs (mmf_particle_net_train_forward) for a chunk of
 // trajectories into one reused stash buffer, runs the transposed network over it
-// (mmf_particle_net_train_backward) and reduces the weight gradients (mmf_particle_net_weight_grads_acc)
-// before the next chunk overwrites the buffers: with the chunk sized so that stash + dz stay below the
-// 256 MiB Infinity Cache, the three kernels hand their (rows, 64) activations over on-die instead of
-// through HBM (5 KB per particle and network call in round 2), and peak memory no longer grows with T.
+// (mmf_particle_net_train_backward, ReLU masks as bits) and reduces the weight gradients
+// (mmf_particle_net_weight_grads_acc) before the next chunk overwrites the buffers: peak memory no longer
+// grows with T (25.4 -> 2.2 GB at 32 x 8192 x 16).  Chunks small enough for stash + dz to stay inside the
+// 256 MiB Infinity Cache were measured and LOSE (32,768 rows: 65.7 ms per step, 262,144 rows: 45.0): each
+// small launch re-stages 150 KB of weights per workgroup and half-fills the chip.  The caller sizes chunks
+// for memory (engine.TRAIN_CHUNK_ROWS).
 #include "mmf_common.h"
 
 namespace {
