@@ -221,8 +221,10 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
     float* s = g_lw; g_lw = d_a; d_a = s;
   }
   if (a->T > 0) {
-    if (hipMemcpyAsync(a->d_states0, g_next, R * d * sizeof(float), hipMemcpyDeviceToDevice, hs) != hipSuccess) return MMF_EINVAL;
-    if (hipMemcpyAsync(a->d_logw0, g_lw, R * sizeof(float), hipMemcpyDeviceToDevice, hs) != hipSuccess) return MMF_EINVAL;
+    hipError_t e = hipMemcpyAsync(a->d_states0, g_next, R * d * sizeof(float), hipMemcpyDeviceToDevice, hs);
+    if (e != hipSuccess) return static_cast<int>(e);
+    e = hipMemcpyAsync(a->d_logw0, g_lw, R * sizeof(float), hipMemcpyDeviceToDevice, hs);
+    if (e != hipSuccess) return static_cast<int>(e);
   }
   return 0;
 }
