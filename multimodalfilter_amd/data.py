@@ -22,10 +22,11 @@ What it restates (host-side numpy; nothing here is on the timed path):
   ``ParticleFilterMeasurementBatcher``; published behaviour of the absent package, restated in
   ``oracle/tf/data.py`` too).
 
-Reading the recordings themselves needs ``h5py`` (``load_hdf5``); the container this was built in
-has neither ``h5py`` nor the datasets (Drive URLs, ``tasks/_door.py:11-20``), so that one function
-is exercised only through a stand-in ``h5py`` module (``tests/test_data_cpu.py``).  Everything after
-the file read is pinned against the reference's own loaders (``tests/golden/loaders.npz``).
+Reading the recordings themselves (``load_hdf5``) goes through ``h5py`` when it is installed and
+otherwise through ``libhdf5`` directly (``hdf5lite.py``, ctypes): the container has no ``h5py`` and no
+datasets (Drive URLs, ``tasks/_door.py:11-20``), but it has the HDF5 C library, so the tests write real
+HDF5 recordings of the synthetic raw trajectories and read them back.  Everything after the file read is
+pinned against the reference's own loaders (``tests/golden/loaders.npz``).
 """
 from dataclasses import dataclass
 from typing import Dict, Iterator, List, Optional, Sequence, Tuple
@@ -189,20 +190,37 @@ def trajectory_from_raw(raw: Dict[str, np.ndarray], spec: DatasetSpec, *, use_vi
                            controls[start_timestep:])
 
 
+def _trajectory_order(name: str) -> int:
+    return int("".join(ch for ch in name if ch.isdigit()) or 0)
+
+
 def load_hdf5(path: str, spec: DatasetSpec, *, max_trajectories: Optional[int] = None,
               **dataset_args) -> List[TrajectoryNumpy]:
     """Read a ``fannypack.data.TrajectoriesFile``-style HDF5 recording (one group per trajectory,
-    one dataset per key).  Needs ``h5py``; untested here (see module docstring)."""
+    one dataset per key; ``tasks/_door.py:121-126``) and normalise every trajectory as the reference's
+    loader does.  With ``h5py`` when it is installed; otherwise through the HDF5 C library itself
+    (``hdf5lite``: ``H5Fopen`` / ``H5Literate`` / ``H5Dread`` via ctypes -- what ``h5py`` wraps), so the
+    read is a real one either way (``tests/test_data_cpu.py`` writes recordings with the same library,
+    contiguous and chunked + deflate)."""
     try:
         import h5py
-    except ImportError as e:  # pragma: no cover
-        raise ImportError("load_hdf5 needs h5py, which is not installed in this image") from e
+    except ImportError:
+        h5py = None
     out = []
-    with h5py.File(path, "r") as f:  # pragma: no cover
-        for name in sorted(f.keys(), key=lambda s: int("".join(ch for ch in s if ch.isdigit()) or 0)):
-            if max_trajectories is not None and len(out) >= max_trajectories:
-                break
-            out.append(trajectory_from_raw({k: np.array(v) for k, v in f[name].items()}, spec, **dataset_args))
+    if h5py is not None:
+        with h5py.File(path, "r") as f:
+            for name in sorted(f.keys(), key=_trajectory_order):
+                if max_trajectories is not None and len(out) >= max_trajectories:
+                    break
+                out.append(trajectory_from_raw({k: np.array(v) for k, v in f[name].items()}, spec, **dataset_args))
+        return out
+    from . import hdf5lite
+
+    groups = hdf5lite.read_groups(path)
+    for name in sorted(groups, key=_trajectory_order):
+        if max_trajectories is not None and len(out) >= max_trajectories:
+            break
+        out.append(trajectory_from_raw(groups[name], spec, **dataset_args))
     return out
 
 

@@ -223,3 +223,36 @@ def test_particle_filter_measurement_batcher_targets_and_spread():
     assert len(ds) == b.count
     n, o, ll = ds[7]
     np.testing.assert_allclose(ll, gaussian_log_pdf(n[None], trajs[0].states[0][None], cov)[0], rtol=1e-5)
+
+
+@pytest.mark.parametrize("compress", [False, True])
+def test_load_hdf5_reads_a_real_hdf5_recording(tmp_path, compress):
+    """A REAL HDF5 file in ``fannypack.data.TrajectoriesFile`` layout (groups ``trajectory<i>``, one dataset per
+    key; contiguous, and chunked + deflate as ``compress=True`` stores them), written with the HDF5 C library and
+    read back by ``data.load_hdf5`` (``h5py`` if installed, else ``hdf5lite`` on the same library): the
+    normalised trajectories equal the REFERENCE loader's outputs for the same raw recordings
+    (``tests/golden/loaders.npz``)."""
+    from multimodalfilter_amd import hdf5lite
+
+    try:
+        hdf5lite.lib()
+    except (ImportError, OSError) as e:
+        pytest.skip(f"no libhdf5 in this environment: {e}")
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "loaders.npz"))
+    for task, spec in (("door", data.DOOR), ("push", data.PUSH_MUJOCO)):
+        n = len({k.split("/")[2] for k in z.files if k.startswith(f"raw/{task}/")})
+        raws = [{k.split("/", 3)[3]: z[k] for k in z.files if k.startswith(f"raw/{task}/{i}/")} for i in range(n)]
+        path = str(tmp_path / f"{task}.hdf5")
+        # group names as TrajectoriesFile writes them; lexicographic order would put 10 before 2
+        names = [f"trajectory{i if i == 0 else i + 9}" for i in range(n)]
+        hdf5lite.write_groups(path, dict(zip(names, raws)), compress=compress)
+        with open(path, "rb") as fh:
+            assert fh.read(8) == b"\x89HDF\r\n\x1a\n"
+        got = data.load_hdf5(path, spec)
+        assert len(got) == n
+        for i, t in enumerate(got):
+            np.testing.assert_allclose(t.states, z[f"{task}/default/{i}/states"], rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(t.controls, z[f"{task}/default/{i}/controls"], rtol=1e-6, atol=1e-6)
+            for k in ("image", "gripper_pos", "gripper_sensors"):
+                np.testing.assert_allclose(t.observations[k], z[f"{task}/default/{i}/{k}"], rtol=1e-6, atol=1e-6)
+        assert len(data.load_hdf5(path, spec, max_trajectories=1)) == 1
