@@ -241,9 +241,9 @@ def test_k6_particle_net_function_matches_autograd(task, kind, N, M):
         # 32 t + (r & 3) + 8 (r >> 2) + 4 h
         feat = torch.tensor([[32 * (b // 16) + ((b % 16) & 3) + 8 * ((b % 16) >> 2) + 4 * h for b in range(32)] for h in range(2)],
                             device=dev)
-        got = ((bits.long()[..., None] >> torch.arange(32, device=dev)) & 1)          # (NL + 1, R, 2, 32)
-        want = (stash > 0).long()[:, :, feat]                                          # (NL + 1, R, 2, 32)
-        assert torch.equal(got, want)
+        bits_got = ((bits.long()[..., None] >> torch.arange(32, device=dev)) & 1)     # (NL + 1, R, 2, 32)
+        bits_want = (stash > 0).long()[:, :, feat]                                     # (NL + 1, R, 2, 32)
+        assert torch.equal(bits_got, bits_want)
     layer = [0]
 
     def relu(z):  # the output of every ReLU is the input of the next 64x64 layer (or of the head)
