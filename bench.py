@@ -655,7 +655,7 @@ def main():
                          "counter-based, generated inside the dynamics kernel")
     ap.add_argument("--no-reference-sizes", action="store_true",
                     help="skip the two extra lines at the sizes the reference itself runs (32 x 300 eval, 32 x 30 x 16 training)")
-    ap.add_argument("--preroll-seconds", type=float, default=0.3,
+    ap.add_argument("--preroll-seconds", type=float, default=1.0,
                     help="untimed repetitions of the warm-up pass before the W warm-up steps (GPU clock ramp)")
     ap.add_argument("--global-batch", type=int, default=None,
                     help="STRONG scaling: this many trajectories in total, sharded over the ranks "
@@ -732,14 +732,17 @@ def main():
 
     def timed_pass():
         """(clock pre-roll,) W untimed warm-up steps, then exactly K timed steps; returns (seconds, timer, mse)."""
-        # DVFS: out of idle the chip needs ~0.1-0.2 s of load to reach its sustained clocks; the contract's
-        # W warm-up steps are 3 ms at the driver's flags (W = 5), and a 20-step timed region then runs its
-        # kernels 7 % slower than a 128-step one (measured: dynamics 208 vs 193 us).  The pre-roll repeats
-        # the warm-up pass, untimed, until `--preroll-seconds` of wall time have gone by.
+        # DVFS: out of idle the chip needs sustained load to reach and hold its clocks; the contract's W warm-up
+        # steps are 3 ms at the driver's flags (W = 5), and a 20-step timed region opened on a cold chip runs
+        # its kernels 16 % slower than a 128-step one (measured round 3: dynamics 221 vs 190 us, measurement 167
+        # vs 142; a duty-cycled 0.3 s pre-roll of 5-step passes with a sync after each did not help: 0.711 ms
+        # per step first, 0.643 when the same pass ran again after the f32 pass and the fp64 study).  The
+        # pre-roll therefore repeats the TIMED pass itself, untimed and without synchronising in between,
+        # until `--preroll-seconds` of wall time have gone by.
         t_pre = time.perf_counter()
         while W > 0 and time.perf_counter() - t_pre < args.preroll_seconds:
-            run(traj_w, noise_w)
-            torch.cuda.synchronize()
+            run(traj, noise)  # back to back, no synchronisation: the GPU stays loaded while the host enqueues
+        torch.cuda.synchronize()
         if W > 0:  # the warm-up covers the whole path, including the evaluation statistic
             pred_w = run(traj_w, noise_w)
             distributed.all_gather_rows(
