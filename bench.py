@@ -655,7 +655,7 @@ def main():
                          "counter-based, generated inside the dynamics kernel")
     ap.add_argument("--no-reference-sizes", action="store_true",
                     help="skip the two extra lines at the sizes the reference itself runs (32 x 300 eval, 32 x 30 x 16 training)")
-    ap.add_argument("--preroll-seconds", type=float, default=1.0,
+    ap.add_argument("--preroll-seconds", type=float, default=0.5,
                     help="untimed repetitions of the warm-up pass before the W warm-up steps (GPU clock ramp)")
     ap.add_argument("--global-batch", type=int, default=None,
                     help="STRONG scaling: this many trajectories in total, sharded over the ranks "
