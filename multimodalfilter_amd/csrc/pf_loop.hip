@@ -119,7 +119,7 @@ void reap_graphs(bool wait) {
 template <class F>
 int run_as_graph(hipStream_t hs, F&& enqueue) {
   reap_graphs(false);
-  static hipStream_t capture_stream = nullptr;
+  static thread_local hipStream_t capture_stream = nullptr;  // one per calling thread
   hipError_t e;
   if (!capture_stream && (e = hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking)) != hipSuccess)
     return static_cast<int>(e);

@@ -158,9 +158,15 @@ extern "C" int mmf_traj_program(const MmfTrajInstr* prog, int n_instr, const flo
   IoPtrs p{};
   for (int i = 0; i < MMF_TRAJ_MAX_IO; ++i) p.p[i] = io[i];
   const size_t per_wave = static_cast<size_t>(n_slots) * kRows * (vec_width + kPad) * sizeof(float);
-  int waves = static_cast<int>((160 * 1024) / per_wave);
-  if (waves < 1) return MMF_ETOOLARGE;
-  if (waves > kWaves) waves = kWaves;
+  if (per_wave > 160 * 1024) return MMF_ETOOLARGE;
+  // waves per workgroup: whatever puts the most waves on a CU (the kernel is a chain of L2 round trips: what
+  // it needs is waves to switch to).  A 5-slot, 64-wide program takes 21 KB per wave: as a 4-wave workgroup
+  // one fits a CU (4 waves), as 1-wave workgroups seven do.
+  int waves = 1, best = 0;
+  for (int w = kWaves; w >= 1; w >>= 1) {
+    const int on_cu = w * static_cast<int>((160 * 1024) / (w * per_wave));
+    if (on_cu > best) { best = on_cu; waves = w; }
+  }
   const size_t lds = per_wave * waves;
   auto k = traj_program_kernel;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
@@ -168,7 +174,7 @@ extern "C" int mmf_traj_program(const MmfTrajInstr* prog, int n_instr, const flo
   if (e != hipSuccess) return static_cast<int>(e);
   const int tasks = (R + kRows - 1) / kRows;
   int grid = (tasks + waves - 1) / waves;
-  const int per_cu = static_cast<int>((160 * 1024) / lds) < 8 ? static_cast<int>((160 * 1024) / lds) : 8;
+  const int per_cu = static_cast<int>((160 * 1024) / lds) < 16 ? static_cast<int>((160 * 1024) / lds) : 16;
   if (grid > 256 * per_cu) grid = 256 * per_cu;
   k<<<grid, waves * MMF_WAVE, lds, static_cast<hipStream_t>(stream)>>>(prog, n_instr, weights, p, R, n_slots, vec_width);
   MMF_CHECK_LAUNCH();
