@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 29
+#define MMF_ABI_VERSION 30
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -314,7 +314,10 @@ int mmf_image_encoder(const float* const* packed, int n_nets, const float* image
  *                                  (`packed_bwd` = mmf_pack_image_convs_backward), ReLU masks fused
  *  mmf_conv_weight_grads           dW[tap][co][ci] partials of one 3x3 layer from its output gradient g
  *                                  (N,co,32,32) and input act (N,ci,32,32): (co,ci) in {(32,32),(16,32),(8,16)};
- *                                  partial (n_blocks*8, 9, 32, 32), summed over dim 0 by the caller.
+ *                                  partial (n_blocks, 9, 32, 32) and the bias gradient's partial_b
+ *                                  (n_blocks, 32) = sums of g per channel, both summed over dim 0 by the
+ *                                  caller (one slot per workgroup; a workgroup walks half-images, so
+ *                                  n_blocks <= 2N, 256 fills the chip).
  *                                  (co,ci) = (32,1): the 5x5 stem, act = images (N,32,32); the head of each
  *                                  partial slot holds dW1 as [co 32][tap 32] (25 taps live)
  */
@@ -326,8 +329,8 @@ int mmf_image_convs_train_forward(const float* packed, const float* images, floa
 int mmf_image_convs_train_backward(const float* packed_bwd, const float* a1, const float* h,
                                    const float* a2, const float* a3, const float* g_a4, float* g1,
                                    float* gh, float* g2, float* g3, int N, void* stream);
-int mmf_conv_weight_grads(const float* g, const float* act, float* partial, int N, int co, int ci,
-                          int n_blocks, void* stream);
+int mmf_conv_weight_grads(const float* g, const float* act, float* partial, float* partial_b, int N, int co,
+                          int ci, int n_blocks, void* stream);
 
 /* ---------------------------------------------------------------- particle-filter step loop
  * Replaces the Python loop of torchfilter's Filter.forward_loop (call site

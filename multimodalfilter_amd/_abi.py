@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 29
+ABI_VERSION = 30
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
@@ -146,7 +146,7 @@ SIGNATURES = {
     "mmf_pack_image_convs_backward": (c_int, [POINTER(MmfImageEncoderDesc), _FP, c_void_p]),
     "mmf_image_convs_train_forward": (c_int, [_FP] * 8 + [c_int, c_int, c_void_p]),
     "mmf_image_convs_train_backward": (c_int, [_FP] * 10 + [c_int, c_void_p]),
-    "mmf_conv_weight_grads": (c_int, [_FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmf_conv_weight_grads": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_image_encoder": (c_int, [POINTER(c_void_p), c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
 }
 
@@ -314,10 +314,12 @@ def image_convs_train_backward(packed_bwd, a1, h, a2, a3, g_a4, g1, gh, g2, g3):
                "mmf_image_convs_train_backward")
 
 
-def conv_weight_grads(g, act, partial, n_blocks: int):
+def conv_weight_grads(g, act, partial, partial_b, n_blocks: int):
+    """``partial (n_blocks, 9, 32, 32)``, ``partial_b (n_blocks, 32)``: one slot per workgroup."""
+    assert partial.numel() >= n_blocks * 9 * 32 * 32 and partial_b.numel() >= n_blocks * 32
     with _on(g):
-        _check(load().mmf_conv_weight_grads(ptr(g), ptr(act), ptr(partial), g.shape[0], g.shape[1], act.shape[1], n_blocks,
-                                            stream_of(g)), "mmf_conv_weight_grads")
+        _check(load().mmf_conv_weight_grads(ptr(g), ptr(act), ptr(partial), ptr(partial_b), g.shape[0], g.shape[1],
+                                            act.shape[1], n_blocks, stream_of(g)), "mmf_conv_weight_grads")
 
 
 def image_convs_backward_floats() -> int:

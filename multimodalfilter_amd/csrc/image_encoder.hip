@@ -849,13 +849,64 @@ __global__ void pack_convs_backward_kernel(MmfImageEncoderDesc d, float* __restr
 }
 
 // dW[tap][co][ci] = sum over images, rows, pixels of g[n][co][y][x] * act[n][ci][y + ky - 1][x + kx - 1]
-// as v_mfma_f32_32x32x2_f32: A = g (rows = co, k = pixel), B = shifted act (k = pixel, cols = ci).  A wave
-// owns output rows y = wave, wave + 8, ... of its images and keeps all nine taps' 32x32 accumulators
-// in registers; k-step s of a row pairs pixels (s, 16 + s), so the A fragment of a row is 16
-// consecutive pixels per lane and is reused by the nine taps.  Per-wave partials, summed by the caller.
+// as v_mfma_f32_32x32x2_f32: A = g (rows = co, k = pixel), B = shifted act (k = pixel, cols = ci).  Work
+// unit = half an image (16 output rows): a wave owns two rows of the unit and keeps all nine taps' 32x32
+// accumulators in registers; k-step s of a row pairs pixels (s, 16 + s), so a lane holds 16 consecutive
+// pixels of g (reused by the nine taps) and 18 of each of the three act rows (reused by the three kx).
+// The eight waves' accumulators meet in LDS in a fixed tree; ONE partial per workgroup, summed by the
+// caller.  db[co] = sum of g comes from the same A registers (`partial_b`).
+constexpr int kWgradTile = 9 * 32 * 32;
+constexpr size_t kLdsWgrad = 4 * kWgradTile * sizeof(float);
+static_assert(kLdsWgrad <= 160 * 1024, "weight-gradient reduction must fit LDS");
+
+__device__ __forceinline__ void wgrad_load16(const float* __restrict__ p, bool ok, float* v) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 t = ok ? *reinterpret_cast<const float4*>(p + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+  }
+}
+
+// sum of the eight waves' `acc[T]` into wave 0's, fixed order ((0+4)+(2+6)) + ((1+5)+(3+7))
+template <int T>
+__device__ __forceinline__ void wgrad_tree(f32x16* acc, float* red, int wave, int lane) {
+#pragma unroll
+  for (int step = 4; step >= 1; step >>= 1) {
+    if (wave >= step && wave < 2 * step) {
+      float* slot = red + (wave - step) * kWgradTile;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slot[(t * 16 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wave < step) {
+      const float* slot = red + wave * kWgradTile;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] += slot[(t * 16 + r) * 64 + lane];
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void wgrad_bias(float bsum, float* red, float* __restrict__ partial_b, int wave, int lane) {
+  bsum += __shfl_xor(bsum, 32);
+  if (lane < 32) red[wave * 32 + lane] = bsum;
+  __syncthreads();
+  if (wave == 0 && lane < 32) {
+    float t = red[lane];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) t += red[w * 32 + lane];
+    partial_b[blockIdx.x * 32 + lane] = t;
+  }
+}
+
 template <int CO, int CI>
 __global__ __launch_bounds__(512) void conv_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ act,
-                                                         float* __restrict__ partial, int N) {
+                                                         float* __restrict__ partial, float* __restrict__ partial_b, int N) {
+  extern __shared__ float red[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, kk = lane >> 5;
   f32x16 acc[9];
@@ -863,68 +914,84 @@ __global__ __launch_bounds__(512) void conv_wgrad_kernel(const float* __restrict
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  for (int n = blockIdx.x; n < N; n += gridDim.x) {
-    const float* gn = g + (static_cast<size_t>(n) * CO + (i < CO ? i : 0)) * kImg * kImg;
-    const float* an = act + (static_cast<size_t>(n) * CI + (i < CI ? i : 0)) * kImg * kImg;
-    for (int y = wave; y < kImg; y += 8) {
+  float bsum = 0.f;
+  for (int u = blockIdx.x; u < 2 * N; u += gridDim.x) {
+    const int n = u >> 1, y0 = 16 * (u & 1);
+    const float* gn = g + (static_cast<size_t>(n) * CO + (i < CO ? i : 0)) * kImg * kImg + 16 * kk;
+    const float* an = act + (static_cast<size_t>(n) * CI + (i < CI ? i : 0)) * kImg * kImg + 16 * kk;
+#pragma unroll 1
+    for (int y = y0 + wave; y < y0 + 16; y += 8) {
       float a[16];
+      wgrad_load16(gn + y * kImg, i < CO, a);
 #pragma unroll
-      for (int s = 0; s < 16; ++s) a[s] = i < CO ? gn[y * kImg + 16 * kk + s] : 0.f;
+      for (int s = 0; s < 16; ++s) bsum += a[s];
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap % 3;
+      for (int ky = 0; ky < 3; ++ky) {
         const int yy = y + ky - 1;
         if (yy < 0 || yy >= kImg) continue;  // wave-uniform
-        float b[16];
+        float b[18];                         // pixels 16 kk - 1 .. 16 kk + 16 of the act row
+        wgrad_load16(an + yy * kImg, i < CI, b + 1);
+        b[0] = (i < CI && kk == 1) ? an[yy * kImg - 1] : 0.f;
+        b[17] = (i < CI && kk == 0) ? an[yy * kImg + 16] : 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          const int x = 16 * kk + s + kx - 1;
-          b[s] = (i < CI && x >= 0 && x < kImg) ? an[yy * kImg + x] : 0.f;
-        }
+        for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc[tap], 0, 0, 0);
+          for (int s = 0; s < 16; ++s)
+            acc[3 * ky + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s + kx], acc[3 * ky + kx], 0, 0, 0);
       }
     }
   }
-  // lane (column ci = i, half kk), register r -> row co = (r & 3) + 8 (r >> 2) + 4 kk
-  float* p = partial + (static_cast<size_t>(blockIdx.x) * 8 + wave) * 9 * 32 * 32;
+  wgrad_tree<9>(acc, red, wave, lane);
+  wgrad_bias(bsum, red, partial_b, wave, lane);
+  if (wave == 0) {
+    // lane (column ci = i, half kk), register r -> row co = (r & 3) + 8 (r >> 2) + 4 kk
+    float* p = partial + static_cast<size_t>(blockIdx.x) * kWgradTile;
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
+    for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) p[(tap * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * 32 + i] = acc[tap][r];
+      for (int r = 0; r < 16; ++r) p[(tap * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk) * 32 + i] = acc[tap][r];
+  }
 }
 
 // The 5x5 stem's weight gradient, same scheme with the 25 taps as the B columns:
 // dW1[co][t] = sum g1[n][co][y][x] * image[n][y + t / 5 - 2][x + t % 5 - 2]; one 32x32 accumulator
-// (co x tap, 7 columns idle) per wave, partial [co][32] at the head of the wave's slot.
+// (co x tap, 7 columns idle) per wave, partial [co][32] at the head of the workgroup's slot.
 __global__ __launch_bounds__(512) void conv_wgrad_stem_kernel(const float* __restrict__ g, const float* __restrict__ images,
-                                                              float* __restrict__ partial, int N) {
+                                                              float* __restrict__ partial, float* __restrict__ partial_b, int N) {
+  extern __shared__ float red[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, kk = lane >> 5;
   const int ty = i / 5 - 2, tx = i % 5 - 2;
-  f32x16 acc;
+  f32x16 acc[1];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int n = blockIdx.x; n < N; n += gridDim.x) {
-    const float* gn = g + (static_cast<size_t>(n) * 32 + i) * kImg * kImg;
+  for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+  float bsum = 0.f;
+  for (int u = blockIdx.x; u < 2 * N; u += gridDim.x) {
+    const int n = u >> 1, y0 = 16 * (u & 1);
+    const float* gn = g + (static_cast<size_t>(n) * 32 + i) * kImg * kImg + 16 * kk;
     const float* im = images + static_cast<size_t>(n) * kImg * kImg;
-    for (int y = wave; y < kImg; y += 8) {
+    for (int y = y0 + wave; y < y0 + 16; y += 8) {
       const int yy = y + ty;
       const bool row_ok = i < 25 && yy >= 0 && yy < kImg;
       float a[16], b[16];
+      wgrad_load16(gn + y * kImg, true, a);
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        a[s] = gn[y * kImg + 16 * kk + s];
+        bsum += a[s];
         const int x = 16 * kk + s + tx;
         b[s] = (row_ok && x >= 0 && x < kImg) ? im[yy * kImg + x] : 0.f;
       }
 #pragma unroll
-      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+      for (int s = 0; s < 16; ++s) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc[0], 0, 0, 0);
     }
   }
-  float* p = partial + (static_cast<size_t>(blockIdx.x) * 8 + wave) * 9 * 32 * 32;
+  wgrad_tree<1>(acc, red, wave, lane);
+  wgrad_bias(bsum, red, partial_b, wave, lane);
+  if (wave == 0) {
+    float* p = partial + static_cast<size_t>(blockIdx.x) * kWgradTile;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2) + 4 * kk) * 32 + i] = acc[r];
+    for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2) + 4 * kk) * 32 + i] = acc[0][r];
+  }
 }
 
 #include "image_encoder_fused.inc"
@@ -1126,15 +1193,27 @@ extern "C" int mmf_image_convs_train_backward(const float* packed_bwd, const flo
   return launch_conv<32, 32, 3, false, true, true>(c, 1, s);
 }
 
-extern "C" int mmf_conv_weight_grads(const float* g, const float* act, float* partial, int N, int co, int ci,
-                                     int n_blocks, void* stream) {
-  if (!g || !act || !partial || N < 0 || n_blocks < 1) return MMF_EINVAL;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (co == 32 && ci == 32) conv_wgrad_kernel<32, 32><<<n_blocks, 512, 0, s>>>(g, act, partial, N);
-  else if (co == 16 && ci == 32) conv_wgrad_kernel<16, 32><<<n_blocks, 512, 0, s>>>(g, act, partial, N);
-  else if (co == 8 && ci == 16) conv_wgrad_kernel<8, 16><<<n_blocks, 512, 0, s>>>(g, act, partial, N);
-  else if (co == 32 && ci == 1) conv_wgrad_stem_kernel<<<n_blocks, 512, 0, s>>>(g, act, partial, N);
-  else return MMF_EINVAL;
+using WgradKernel = void (*)(const float*, const float*, float*, float*, int);
+
+static int launch_wgrad(WgradKernel k, const float* g, const float* act, float* partial, float* partial_b, int N,
+                        int n_blocks, hipStream_t s) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(kLdsWgrad));
+  if (e != hipSuccess) return static_cast<int>(e);
+  k<<<n_blocks, 512, kLdsWgrad, s>>>(g, act, partial, partial_b, N);
   MMF_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int mmf_conv_weight_grads(const float* g, const float* act, float* partial, float* partial_b, int N, int co,
+                                     int ci, int n_blocks, void* stream) {
+  if (!g || !act || !partial || !partial_b || N < 0 || n_blocks < 1) return MMF_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  WgradKernel k = nullptr;
+  if (co == 32 && ci == 32) k = conv_wgrad_kernel<32, 32>;
+  else if (co == 16 && ci == 32) k = conv_wgrad_kernel<16, 32>;
+  else if (co == 8 && ci == 16) k = conv_wgrad_kernel<8, 16>;
+  else if (co == 32 && ci == 1) k = conv_wgrad_stem_kernel;
+  else return MMF_EINVAL;
+  return launch_wgrad(k, g, act, partial, partial_b, N, n_blocks, s);
 }

@@ -364,7 +364,7 @@ class ParticleNetFunction(torch.autograd.Function):
         # every reduction over the R particles of the 64x64 layers in one launch: dW_l = dz_l^T
         # stash_l and db_l = column sums, as per-slice partials (slot NL of dW pairs unrelated
         # tensors and is ignored; its db is the first layer's bias gradient)
-        S = max(1, min(128, R // 512))  # 32 x 8192 particles: 64 slices 51.8 ms / training step, 128 49.9, 256 49.9
+        S = max(1, min(128, R // 64))  # >= 64 rows per slice; 32 x 8192 particles: 64 slices 51.8 ms / training step, 128 49.9, 256 49.9
         pw = torch.empty((NL + 1, S, U, U), dtype=torch.float32, device=st.device)
         pb = torch.empty((NL + 1, S, U), dtype=torch.float32, device=st.device)
         _abi.particle_net_weight_grads(dz, stash, pw, pb, NL + 1, R, S)
@@ -509,7 +509,7 @@ class PfTrainLoopFunction(torch.autograd.Function):
         U = _abi.MMF_UNITS
         chunk_traj = max(1, min(N, TRAIN_CHUNK_ROWS // M))
         C = chunk_traj * M
-        S = max(1, min(128, C // 512))
+        S = max(1, min(128, C // 64))  # weight-gradient slices: >= 64 rows each (960 rows -> 15 workgroups per layer)
         SL = max(1, min(16, M // 256))
         nets = [dyn_net] + [m for m, _ in meas]
         NLmax = max(3 + 2 * n.n_res for n in nets)
@@ -781,7 +781,7 @@ class ImageConvsFunction(torch.autograd.Function):
     ReLU masks fused (``mmf_image_convs_train_backward``) and the 3x3 weight gradients as split-K MFMA
     correlations (``mmf_conv_weight_grads``): no MIOpen kernel in a training step.  Exact fp32.
     ``apply(seq, images (N, 32, 32), *conv weights and biases) -> (N, 8, 32, 32)``; the flatten + linear
-    + ResLinear behind it stay torch modules (library GEMMs); bias gradients are sums."""
+    + ResLinear behind it stay torch modules (library GEMMs); bias gradients come out of the same kernels."""
 
     @staticmethod
     def forward(ctx, seq, images, *params):
@@ -824,20 +824,20 @@ class ImageConvsFunction(torch.autograd.Function):
         g1, gh, g2 = torch.empty_like(a1), torch.empty_like(a1), torch.empty_like(a1)
         g3 = torch.empty_like(a3)
         _abi.image_convs_train_backward(cached[1], a1, h, a2, a3, g_a4, g1, gh, g2, g3)
-        blocks = max(1, min(N, 128))
-        partial = torch.empty((blocks * 8, 9, 32, 32), dtype=torch.float32, device=img.device)
+        blocks = max(1, min(2 * N, 256))  # a workgroup walks half-images; one partial per workgroup
+        partial = torch.empty((blocks, 9, 32, 32), dtype=torch.float32, device=img.device)
+        partial_b = torch.empty((5, blocks, 32), dtype=torch.float32, device=img.device)
 
-        def wgrad(g, act):
+        def wgrad(g, act, slot):
             co, ci = g.shape[1], act.shape[1]
-            _abi.conv_weight_grads(g, act, partial, blocks)
+            _abi.conv_weight_grads(g, act, partial, partial_b[slot], blocks)
             return partial.sum(0)[:, :co, :ci].permute(1, 2, 0).reshape(co, ci, 3, 3).contiguous()
 
-        gw4, gw3, gw2b, gw2a = wgrad(g_a4, a3), wgrad(g3, a2), wgrad(g2, h), wgrad(gh, a1)
-        _abi.conv_weight_grads(g1, img[:, None], partial, blocks)                       # the 5x5 stem: [co][tap]
-        gw1 = partial.view(blocks * 8, -1)[:, :1024].sum(0).view(32, 32)[:, :25].reshape(32, 1, 5, 5).contiguous()
-        bsum = lambda g: g.sum(dim=(0, 2, 3))
-        # parameter order = PackedImageEncoder._sources()[:10]: w1 w2a w2b w3 w4 | b1 b2a b2b b3 b4
-        return (None, None, gw1, gw2a, gw2b, gw3, gw4, bsum(g1), bsum(gh), bsum(g2), bsum(g3), bsum(g_a4))
+        gw4, gw3, gw2b, gw2a = wgrad(g_a4, a3, 4), wgrad(g3, a2, 3), wgrad(g2, h, 2), wgrad(gh, a1, 1)
+        _abi.conv_weight_grads(g1, img[:, None], partial, partial_b[0], blocks)          # the 5x5 stem: [co][tap]
+        gw1 = partial.view(blocks, -1)[:, :1024].sum(0).view(32, 32)[:, :25].reshape(32, 1, 5, 5).contiguous()
+        gb = partial_b.sum(1)                                                            # (5, 32): b1 b2a b2b b3 b4
+        return (None, None, gw1, gw2a, gw2b, gw3, gw4, gb[0], gb[1], gb[2], gb[3, :16], gb[4, :8])
 
 
 def image_features_autograd(seq, images: torch.Tensor) -> torch.Tensor:

@@ -124,12 +124,13 @@ def main():
     ap.add_argument("--train-iters", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--only", default="eval,train")
+    ap.add_argument("--backends", default="hip,autograd")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if "eval" in args.only:
         print(json.dumps(eval_regime(args, dev)), flush=True)
     if "train" in args.only:
-        for backend in ("hip", "autograd"):
+        for backend in args.backends.split(","):
             print(json.dumps(train_regime(args, dev, backend)), flush=True)
         if not args.no_cpu:
             print(json.dumps(train_cpu_twin(args)), flush=True)

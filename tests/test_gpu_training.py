@@ -61,9 +61,11 @@ def _compare_grads(oracle, engine_model, loss_o, loss_e, min_checked=20):
     assert checked > min_checked
 
 
-@pytest.mark.parametrize("tname,cls,kind", [("door", "DoorCrossmodalParticleFilter", "crossmodal"),
-                                            ("push", "PushUnimodalParticleFilter", "unimodal")])
-def test_particle_filter_training_step_matches_oracle(training_backend, tname, cls, kind):
+@pytest.mark.parametrize("tname,cls,kind,N,M", [("door", "DoorCrossmodalParticleFilter", "crossmodal", 4, 30),
+                                                ("push", "PushUnimodalParticleFilter", "unimodal", 4, 30),
+                                                # config 5's particle count against the CPU oracle itself
+                                                ("push", "PushUnimodalParticleFilter", "unimodal", 2, 8192)])
+def test_particle_filter_training_step_matches_oracle(training_backend, tname, cls, kind, N, M):
     import multimodalfilter_amd as mmf
     from multimodalfilter_amd import engine
 
@@ -72,7 +74,7 @@ def test_particle_filter_training_step_matches_oracle(training_backend, tname, c
 
     dev = torch.device("cuda:0")
     task = om.TASKS[tname]
-    d, T, N, M = task.state_dim, 3, 4, 30  # the reference's training particle count
+    d, T = task.state_dim, 3  # M = 30: the reference's training particle count
     obs, ctrl, x0, target, g = _data(task, T, N, 21)
     eps0 = torch.randn((N, M, d), generator=g)
     eps = [torch.randn((N, M, d), generator=g) for _ in range(T)]
@@ -81,6 +83,8 @@ def test_particle_filter_training_step_matches_oracle(training_backend, tname, c
     oracle = om.ParticleFilter(task, kind)
     oracle.load_state_dict(om.seeded_state_dict(oracle, seed=8, gain=1.0))
     oracle.train()
+    assert oracle.num_particles == 30
+    oracle.num_particles = M
     oracle.noise = ReplayNoise([eps0] + eps, [])
     oracle.initialize_beliefs(mean=x0, covariance=cov)
     loss_o = torch.mean((oracle.forward_loop(observations=obs, controls=ctrl) - target) ** 2)
@@ -89,6 +93,7 @@ def test_particle_filter_training_step_matches_oracle(training_backend, tname, c
     eng.load_state_dict(oracle.state_dict())
     eng.to(dev).train()
     assert eng.num_particles == 30
+    eng.num_particles = M
     eng.noise = mmf.ReplayNoise([eps0] + eps, [])
     eng.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
     loops = []
