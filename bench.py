@@ -731,37 +731,68 @@ def main():
         run = lambda tr, nz: evaluation.run_filter(f, tr)
 
     def timed_pass():
-        """(clock pre-roll,) W untimed warm-up steps, then exactly K timed steps; returns (seconds, timer, mse)."""
-        # DVFS: out of idle the chip needs sustained load to reach and hold its clocks; the contract's W warm-up
-        # steps are 3 ms at the driver's flags (W = 5), and a 20-step timed region opened on a cold chip runs
-        # its kernels 16 % slower than a 128-step one (measured round 3: dynamics 221 vs 190 us, measurement 167
-        # vs 142; a duty-cycled 0.3 s pre-roll of 5-step passes with a sync after each did not help: 0.711 ms
-        # per step first, 0.643 when the same pass ran again after the f32 pass and the fp64 study).  The
-        # pre-roll therefore repeats the TIMED pass itself, untimed and without synchronising in between,
-        # until `--preroll-seconds` of wall time have gone by.
-        t_pre = time.perf_counter()
-        while W > 0 and time.perf_counter() - t_pre < args.preroll_seconds:
-            run(traj, noise)  # back to back, no synchronisation: the GPU stays loaded while the host enqueues
+        """(pre-roll + one untimed rehearsal,) W untimed warm-up steps, then exactly K timed steps; returns
+        (seconds, timer, mse, prediction)."""
+        # Round 3, measured (profiles/r03/bench_pass_timecourse.txt, MMF_BENCH_TIMECOURSE): only the FIRST K-step
+        # pass of a process is slow -- 0.70 ms per step at the driver's flags against 0.645-0.66 for every later
+        # one, whatever lies in between (idle 1 / 5 / 10 s, 5 s of load, the f32 pass) and whatever the pre-roll
+        # (0 - 6 s); its kernels are not slower.  The ~1 ms is one-time host work inside the timed region: the code
+        # objects of the torch kernels the K-step statistic selects (the W-step warm-up has other shapes), the
+        # allocator's first blocks of those sizes, the first event records of the kernel timer.  So the pre-roll
+        # ends with ONE untimed rehearsal of exactly the timed sequence; the W warm-up steps the contract asks
+        # for follow it, then the K timed steps.
+        def measure(sync_clock):
+            timer = None if args.no_kernel_timers else engine.KernelTimer(loop_stride=K if K < 64 else (K + 2) // 3)  # 3 sampled steps (1 for short passes)
+            engine.set_kernel_timer(timer)
+            distributed.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pred = run(traj, noise)
+            mse_local = evaluation.per_trajectory_mse(pred, traj["states"][1:], start=min(30, K // 2))
+            mse_all = distributed.all_gather_rows(mse_local)  # RCCL all-gather of per-sequence errors
+            torch.cuda.synchronize()
+            distributed.barrier()
+            dt = time.perf_counter() - t0
+            engine.set_kernel_timer(None)
+            return (distributed.max_over_ranks(dt, device) if sync_clock else dt), timer, mse_all, pred
+
+        if W > 0 and args.preroll_seconds > 0:
+            t_pre = time.perf_counter()
+            while time.perf_counter() - t_pre < args.preroll_seconds:
+                run(traj, noise)  # back to back, no synchronisation: the GPU stays loaded while the host enqueues
+            measure(False)        # the rehearsal: untimed
         torch.cuda.synchronize()
         if W > 0:  # the warm-up covers the whole path, including the evaluation statistic
             pred_w = run(traj_w, noise_w)
             distributed.all_gather_rows(
                 evaluation.per_trajectory_mse(pred_w, traj_w["states"][1:], start=min(30, W // 2)))
         torch.cuda.synchronize()
-        timer = None if args.no_kernel_timers else engine.KernelTimer(loop_stride=K if K < 64 else (K + 2) // 3)  # 3 sampled steps (1 for short passes)
-        engine.set_kernel_timer(timer)
-        distributed.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        pred = run(traj, noise)
-        mse_local = evaluation.per_trajectory_mse(pred, traj["states"][1:], start=min(30, K // 2))
-        mse_all = distributed.all_gather_rows(mse_local)  # RCCL all-gather of per-sequence errors
-        torch.cuda.synchronize()
-        distributed.barrier()
-        dt = time.perf_counter() - t0
-        engine.set_kernel_timer(None)
-        return distributed.max_over_ranks(dt, device), timer, mse_all, pred
+        return measure(True)
 
+    if os.environ.get("MMF_BENCH_TIMECOURSE"):
+        # debug: the same K-step pass over and over, with idles / an f32 pass in between -- what the pass's speed
+        # depends on (scripts/profile_round.sh does not run this)
+        t_proc = time.perf_counter()
+        plan = os.environ["MMF_BENCH_TIMECOURSE"].split(",")  # "p" pass, "s<sec>" sleep, "f" f32 pass, "b<sec>" busy
+        for step in plan:
+            if step[0] == "s":
+                torch.cuda.synchronize()
+                time.sleep(float(step[1:]))
+                continue
+            if step[0] == "b":
+                t_b = time.perf_counter()
+                while time.perf_counter() - t_b < float(step[1:]):
+                    run(traj, noise)
+                torch.cuda.synchronize()
+                continue
+            if step[0] == "f":
+                engine.set_default_precision("f32")
+            dt, timer, _, _ = timed_pass()
+            engine.set_default_precision(precision)
+            ks = timer.summary() if timer else {}
+            print(json.dumps({"t": round(time.perf_counter() - t_proc, 2), "what": step, "ms_per_step": 1e3 * dt / K,
+                              "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in ks.items()}}), flush=True)
+        return
     # Order of the GPU work (one GPU): the headline pass, the comparison pass in exact-f32 mode, the error study
     # against fp64, one second of idle, and the headline pass AGAIN -- each pass does its own pre-roll and W
     # warm-up steps and times exactly K.  `value` is the LAST pass; the first is reported beside it as
