@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 30
+#define MMF_ABI_VERSION 31
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -465,6 +465,13 @@ typedef struct MmfTrainNet {
 typedef struct MmfPfTrainArgs {
   int32_t T, N, M, d, n_meas, n_res_dyn, n_res_meas, logw_stride, precision;
   int32_t chunk_traj, n_splits, n_slices;
+  int32_t concurrent;        /* 1: small problems -- the measurement networks' backward chains and the dynamics recompute
+                                of a step run on private side streams (fork / join by events on `stream`), and the
+                                forward's measurement launches likewise; the scratch buffers stash / mask / dz / raw /
+                                d_tmp then hold n_meas + 1 consecutive sets (sized for max(NLd, NLm) layers and
+                                chunk_traj * M rows each) and d_raw (n_meas + 8) * chunk_traj * M floats.  Same kernels,
+                                same accumulation order: results are bit-identical to concurrent = 0.  Measured slower at
+                                32 x 30 x 16 (event fork / join costs more than 25 us kernels overlap): the host side leaves it off */
   MmfTrainNet dyn;
   MmfTrainNet meas[MMF_LOOP_MAX_MEAS];
   const float* dyn_bias;

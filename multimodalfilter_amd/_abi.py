@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 30
+ABI_VERSION = 31
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
@@ -77,7 +77,7 @@ class MmfTrainNet(Structure):
 class MmfPfTrainArgs(Structure):
     _fields_ = [("T", c_int32), ("N", c_int32), ("M", c_int32), ("d", c_int32), ("n_meas", c_int32),
                 ("n_res_dyn", c_int32), ("n_res_meas", c_int32), ("logw_stride", c_int32), ("precision", c_int32),
-                ("chunk_traj", c_int32), ("n_splits", c_int32), ("n_slices", c_int32),
+                ("chunk_traj", c_int32), ("n_splits", c_int32), ("n_slices", c_int32), ("concurrent", c_int32),
                 ("dyn", MmfTrainNet), ("meas", MmfTrainNet * LOOP_MAX_MEAS),
                 ("dyn_bias", _FP), ("meas_bias", _FP * LOOP_MAX_MEAS), ("meas_logw", _FP * LOOP_MAX_MEAS),
                 ("noise", _FP), ("scale_tril", _FP), ("g_estimates", _FP),

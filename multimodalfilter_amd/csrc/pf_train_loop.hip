@@ -84,6 +84,32 @@ __global__ __launch_bounds__(kThreads) void dyn_epilogue_bwd_kernel(const float*
 
 inline int blocks(size_t n) { return static_cast<int>((n + kThreads - 1) / kThreads); }
 
+// Small problems (the reference trains 32 x 30 particles): a network's kernels are a handful of workgroups each,
+// so the independent chains of a step -- one per measurement network, and the dynamics recompute -- run on
+// private side streams, forked from and joined into the caller's stream by events.
+struct SideStreams {
+  hipStream_t s[MMF_LOOP_MAX_MEAS + 1] = {};
+  hipEvent_t fork = nullptr, done[MMF_LOOP_MAX_MEAS + 1] = {};
+  bool ready = false;
+  int init() {
+    if (ready) return 0;
+    for (auto& x : s)
+      if (hipStreamCreateWithFlags(&x, hipStreamNonBlocking) != hipSuccess) return MMF_EINVAL;
+    if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return MMF_EINVAL;
+    for (auto& e : done)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return MMF_EINVAL;
+    ready = true;
+    return 0;
+  }
+};
+thread_local SideStreams g_side;
+
+#define MMF_HIP(call)                                      \
+  {                                                        \
+    hipError_t e_ = (call);                                \
+    if (e_ != hipSuccess) return static_cast<int>(e_);     \
+  }
+
 int check(const MmfPfTrainArgs* a) {
   if (!a) return MMF_EINVAL;
   if (a->T < 0 || a->N < 1 || a->M < 1 || a->n_meas < 1 || a->n_meas > MMF_LOOP_MAX_MEAS) return MMF_EINVAL;
@@ -104,18 +130,27 @@ extern "C" int mmf_pf_train_forward(const MmfPfTrainArgs* a, void* stream) {
   hipStream_t hs = static_cast<hipStream_t>(stream);
   const size_t row = static_cast<size_t>(a->N), R = row * a->M;
   const int K = a->n_meas;
+  const bool conc = a->concurrent && K > 1;
+  if (conc && (rc = g_side.init())) return rc;
   for (int t = 0; t < a->T; ++t) {
     const float* x = a->states + t * R * a->d;
     float* xn = a->states + (t + 1) * R * a->d;
     rc = mmf_pf_dynamics(a->dyn.packed, a->n_res_dyn, a->precision, x, a->dyn_bias + t * row * MMF_UNITS,
                          a->noise + t * R * a->d, a->scale_tril, xn, a->range_flag, a->N, a->M, a->d, stream);
     if (rc) return rc;
+    if (conc) MMF_HIP(hipEventRecord(g_side.fork, hs));
     float* ll = a->ll_steps + static_cast<size_t>(t) * K * R;  // (K, R): kept for the backward's softmax over modalities
     for (int k = 0; k < K; ++k) {
       const float* lw = a->meas_logw[k] ? a->meas_logw[k] + t * row * a->logw_stride : nullptr;
+      hipStream_t sk = (conc && k > 0) ? g_side.s[k] : hs;  // modality 0 stays on the caller's stream
+      if (sk != hs) MMF_HIP(hipStreamWaitEvent(sk, g_side.fork, 0));
       rc = mmf_pf_measure(a->meas[k].packed, a->n_res_meas, a->precision, xn, a->meas_bias[k] + t * row * MMF_UNITS, lw,
-                          a->logw_stride, ll + k * R, 0, a->range_flag, a->N, a->M, a->d, stream);
+                          a->logw_stride, ll + k * R, 0, a->range_flag, a->N, a->M, a->d, sk);
       if (rc) return rc;
+      if (sk != hs) {
+        MMF_HIP(hipEventRecord(g_side.done[k], sk));
+        MMF_HIP(hipStreamWaitEvent(hs, g_side.done[k], 0));
+      }
     }
     const float* loglik = ll;
     if (K > 1) {
@@ -140,6 +175,18 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
   const int N = a->N, M = a->M, d = a->d, K = a->n_meas, S = a->n_splits, SL = a->n_slices;
   const size_t row = static_cast<size_t>(N), R = row * M;
   const int NLd = 3 + 2 * a->n_res_dyn, NLm = 3 + 2 * a->n_res_meas;
+  const int NLmax = NLd > NLm ? NLd : NLm;
+  const bool conc = a->concurrent != 0;
+  if (conc && (rc = g_side.init())) return rc;
+  // scratch set s (concurrent: one per measurement network + one for the dynamics; else one for all)
+  const size_t Cmax = static_cast<size_t>(a->chunk_traj < N ? a->chunk_traj : N) * M;
+  const size_t set_act = static_cast<size_t>(NLmax + 1) * Cmax * MMF_UNITS, set_mask = static_cast<size_t>(NLmax + 1) * Cmax * 2;
+  auto stash_of = [&](int set) { return a->stash + (conc ? set * set_act : 0); };
+  auto dz_of = [&](int set) { return a->dz + (conc ? set * set_act : 0); };
+  auto mask_of = [&](int set) { return a->mask + (conc ? set * set_mask : 0); };
+  auto raw_of = [&](int set) { return a->raw + (conc ? set * Cmax * 8 : 0); };
+  auto tmp_of = [&](int set) { return a->d_tmp + (conc ? set * Cmax * d : 0); };
+  float* d_raw_dyn = a->d_raw + (conc ? static_cast<size_t>(K) * Cmax : 0);
   float* g_next = a->g_states_a;   // dL/d states[t+1] arriving from step t+1 (none at the last step)
   float* g_tot = a->g_states_b;
   float* g_lw = a->g_logw_a;       // dL/d logw[t+1] arriving from step t+1
@@ -171,49 +218,67 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
         combine_bwd_kernel<<<blocks(C), kThreads, 0, hs>>>(ll, d_a, a->d_raw, K, R, r0, C);
         MMF_CHECK_LAUNCH();
       }
+      if (conc) MMF_HIP(hipEventRecord(g_side.fork, hs));
       for (int k = 0; k < K; ++k) {
         const MmfTrainNet& net = a->meas[k];
         const float* d_out = K > 1 ? a->d_raw + k * C : d_a + r0;
+        hipStream_t sk = conc ? g_side.s[k] : hs;
+        if (conc) MMF_HIP(hipStreamWaitEvent(sk, g_side.fork, 0));
+        float *stash = stash_of(k), *dz = dz_of(k);
         rc = mmf_particle_net_train_forward(net.packed_f32, a->n_res_meas, 1, xn + r0 * d,
-                                            a->meas_bias[k] + (t * row + n0) * MMF_UNITS, a->stash, a->mask, a->raw, Nc, M, d, stream);
+                                            a->meas_bias[k] + (t * row + n0) * MMF_UNITS, stash, mask_of(k), raw_of(k), Nc, M, d, sk);
         if (rc) return rc;
-        rc = mmf_particle_net_train_backward(net.packed_t, net.head_w, a->n_res_meas, 1, a->mask, d_out, a->dz, a->d_tmp,
-                                             Ci, d, stream);
+        rc = mmf_particle_net_train_backward(net.packed_t, net.head_w, a->n_res_meas, 1, mask_of(k), d_out, dz, tmp_of(k),
+                                             Ci, d, sk);
         if (rc) return rc;
-        rc = mmf_particle_net_weight_grads_acc(a->dz, a->stash, net.pw, net.pb, NLm + 1, Ci, S, first_wgrad_meas[k] ? 0 : 1,
-                                               stream);
+        rc = mmf_particle_net_weight_grads_acc(dz, stash, net.pw, net.pb, NLm + 1, Ci, S, first_wgrad_meas[k] ? 0 : 1, sk);
         if (rc) return rc;
         first_wgrad_meas[k] = false;
-        rc = mmf_particle_net_small_grads(a->dz + static_cast<size_t>(NLm) * C * MMF_UNITS, a->dz + 2 * C * MMF_UNITS,
-                                          a->stash + static_cast<size_t>(NLm) * C * MMF_UNITS, xn + r0 * d, d_out,
+        rc = mmf_particle_net_small_grads(dz + static_cast<size_t>(NLm) * C * MMF_UNITS, dz + 2 * C * MMF_UNITS,
+                                          stash + static_cast<size_t>(NLm) * C * MMF_UNITS, xn + r0 * d, d_out,
                                           net.p_first + slot0 * MMF_UNITS * 4, net.p_head + slot0 * 4 * MMF_UNITS,
-                                          net.p_dout + slot0 * 4, net.p_traj + slot0 * MMF_UNITS, Nc, M, d, 1, SL, stream);
+                                          net.p_dout + slot0 * 4, net.p_traj + slot0 * MMF_UNITS, Nc, M, d, 1, SL, sk);
         if (rc) return rc;
-        add_kernel<<<blocks(C * d), kThreads, 0, hs>>>(g_tot + r0 * d, a->d_tmp, C * d);
-        MMF_CHECK_LAUNCH();
+        if (conc) {
+          MMF_HIP(hipEventRecord(g_side.done[k], sk));
+        } else {
+          add_kernel<<<blocks(C * d), kThreads, 0, hs>>>(g_tot + r0 * d, tmp_of(k), C * d);
+          MMF_CHECK_LAUNCH();
+        }
       }
       // ---- dynamics network: x' = x + dir sigmoid(gate) + L eps
       {
         const MmfTrainNet& net = a->dyn;
+        hipStream_t sd = conc ? g_side.s[K] : hs;  // the recompute needs nothing of this step's gradients
+        if (conc) MMF_HIP(hipStreamWaitEvent(sd, g_side.fork, 0));
+        float *stash = stash_of(K), *dz = dz_of(K);
         rc = mmf_particle_net_train_forward(net.packed_f32, a->n_res_dyn, 0, x + r0 * d,
-                                            a->dyn_bias + (t * row + n0) * MMF_UNITS, a->stash, a->mask, a->raw, Nc, M, d, stream);
+                                            a->dyn_bias + (t * row + n0) * MMF_UNITS, stash, mask_of(K), raw_of(K), Nc, M, d, sd);
         if (rc) return rc;
-        if (d == 2) dyn_epilogue_bwd_kernel<2><<<blocks(C), kThreads, 0, hs>>>(a->raw, g_tot + r0 * d, a->d_raw, C);
-        else dyn_epilogue_bwd_kernel<3><<<blocks(C), kThreads, 0, hs>>>(a->raw, g_tot + r0 * d, a->d_raw, C);
+        if (conc) {
+          MMF_HIP(hipEventRecord(g_side.done[K], sd));
+          for (int k = 0; k <= K; ++k) MMF_HIP(hipStreamWaitEvent(hs, g_side.done[k], 0));
+          for (int k = 0; k < K; ++k) {  // the same adds in the same order as the sequential path
+            add_kernel<<<blocks(C * d), kThreads, 0, hs>>>(g_tot + r0 * d, tmp_of(k), C * d);
+            MMF_CHECK_LAUNCH();
+          }
+        }
+        if (d == 2) dyn_epilogue_bwd_kernel<2><<<blocks(C), kThreads, 0, hs>>>(raw_of(K), g_tot + r0 * d, d_raw_dyn, C);
+        else dyn_epilogue_bwd_kernel<3><<<blocks(C), kThreads, 0, hs>>>(raw_of(K), g_tot + r0 * d, d_raw_dyn, C);
         MMF_CHECK_LAUNCH();
-        rc = mmf_particle_net_train_backward(net.packed_t, net.head_w, a->n_res_dyn, 0, a->mask, a->d_raw, a->dz, a->d_tmp,
+        rc = mmf_particle_net_train_backward(net.packed_t, net.head_w, a->n_res_dyn, 0, mask_of(K), d_raw_dyn, dz, tmp_of(K),
                                              Ci, d, stream);
         if (rc) return rc;
-        rc = mmf_particle_net_weight_grads_acc(a->dz, a->stash, net.pw, net.pb, NLd + 1, Ci, S, first_wgrad_dyn ? 0 : 1, stream);
+        rc = mmf_particle_net_weight_grads_acc(dz, stash, net.pw, net.pb, NLd + 1, Ci, S, first_wgrad_dyn ? 0 : 1, stream);
         if (rc) return rc;
         first_wgrad_dyn = false;
-        rc = mmf_particle_net_small_grads(a->dz + static_cast<size_t>(NLd) * C * MMF_UNITS, a->dz + 2 * C * MMF_UNITS,
-                                          a->stash + static_cast<size_t>(NLd) * C * MMF_UNITS, x + r0 * d, a->d_raw,
+        rc = mmf_particle_net_small_grads(dz + static_cast<size_t>(NLd) * C * MMF_UNITS, dz + 2 * C * MMF_UNITS,
+                                          stash + static_cast<size_t>(NLd) * C * MMF_UNITS, x + r0 * d, d_raw_dyn,
                                           net.p_first + slot0 * MMF_UNITS * 4, net.p_head + slot0 * 4 * MMF_UNITS,
                                           net.p_dout + slot0 * 4, net.p_traj + slot0 * MMF_UNITS, Nc, M, d, d + 1, SL, stream);
         if (rc) return rc;
         // dL/d states[t] = direct path + through the network
-        sum2_kernel<<<blocks(C * d), kThreads, 0, hs>>>(g_tot + r0 * d, a->d_tmp, g_next + r0 * d, C * d);
+        sum2_kernel<<<blocks(C * d), kThreads, 0, hs>>>(g_tot + r0 * d, tmp_of(K), g_next + r0 * d, C * d);
         MMF_CHECK_LAUNCH();
       }
     }

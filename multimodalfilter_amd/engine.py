@@ -440,6 +440,12 @@ def _assemble_param_grads(net: PackedParticleNet, params, dW, db, g_first, g_hea
 # buffers inside the 256 MiB Infinity Cache) 65.7, 65,536 56.1, 262,144 45.0 -- on-die hand-offs do not pay
 # for the small launches (150 KB of weights staged per workgroup for 4 tiles, half-empty grids)
 TRAIN_CHUNK_ROWS = int(os.environ.get("MMF_TRAIN_CHUNK_ROWS", "262144"))
+# MmfPfTrainArgs.concurrent: below this many rows (N * M) the independent chains of a training step (one per
+# measurement network + the dynamics recompute) run on side streams, forked / joined by events; results are
+# bit-identical (tests/test_gpu_training.py).  OFF by default -- measured at the reference's 32 x 30 x 16: 10.75 ms
+# per optimiser step against 10.22 on one stream: the ~10 event records / waits per time step cost more than
+# the overlap of kernels that are 25 us long buys.
+TRAIN_CONCURRENT_ROWS = int(os.environ.get("MMF_TRAIN_CONCURRENT_ROWS", "0"))
 
 
 class PfTrainLoopFunction(torch.autograd.Function):
@@ -479,6 +485,7 @@ class PfTrainLoopFunction(torch.autograd.Function):
         # forward pass in the engine's arithmetic mode (f16x3 by default: the inference kernels); the backward
         # recomputes the SAME particle sets' activations with exact fp32 products
         a.precision = dyn_net.precision_code()
+        a.concurrent = int(R <= TRAIN_CONCURRENT_ROWS)
         blobs = [dyn_net.blob(_abi.PREC_F32)] + [m.blob(_abi.PREC_F32) for m, _ in meas]
         fwd_blobs = [dyn_net.blob()] + [m.blob() for m, _ in meas]
         a.dyn.packed, a.dyn.packed_f32 = P(fwd_blobs[0]), P(blobs[0])
@@ -519,6 +526,8 @@ class PfTrainLoopFunction(torch.autograd.Function):
         a.T, a.N, a.M, a.d, a.n_meas = T, N, M, d, K
         a.n_res_dyn, a.n_res_meas, a.logw_stride, a.precision = dyn_net.n_res, meas[0][0].n_res, K_all, _abi.PREC_F32
         a.chunk_traj, a.n_splits, a.n_slices = chunk_traj, S, SL
+        a.concurrent = int(N * M <= TRAIN_CONCURRENT_ROWS)
+        sets = K + 1 if a.concurrent else 1  # private scratch per concurrently running network
         bufs = []
         head_ws, tblobs = [], []
         n_par = [len(n._sources()) for n in nets]
@@ -542,9 +551,9 @@ class PfTrainLoopFunction(torch.autograd.Function):
             if keep["beta"] is not None and col is not None:
                 a.meas_logw[k] = ctypes.c_void_p(keep["beta"].data_ptr() + 4 * col)
         g_est = g_est.to(torch.float32).contiguous()
-        scratch = dict(stash=E(NLmax + 1, C, U), mask=torch.empty((NLmax + 1, C, 2), dtype=torch.int32, device=dev),
-                       dz=E(NLmax + 1, C, U), raw=E(C, 8), d_raw=E(C, 8), ga=E(N, M, d), gb=E(N, M, d),
-                       la=E(N, M), lb=E(N, M), d_tmp=E(C, d), d_states0=E(N, M, d), d_logw0=E(N, M))
+        scratch = dict(stash=E(sets, NLmax + 1, C, U), mask=torch.empty((sets, NLmax + 1, C, 2), dtype=torch.int32, device=dev),
+                       dz=E(sets, NLmax + 1, C, U), raw=E(sets, C, 8), d_raw=E(K + 8, C), ga=E(N, M, d), gb=E(N, M, d),
+                       la=E(N, M), lb=E(N, M), d_tmp=E(sets, C, d), d_states0=E(N, M, d), d_logw0=E(N, M))
         a.dyn_bias, a.noise, a.scale_tril, a.g_estimates = P(keep["dyn_bias"]), P(keep["eps"]), P(keep["tril"]), P(g_est)
         a.states, a.logw, a.estimates = P(keep["states"]), P(keep["logw"]), P(keep["est"])
         a.loglik, a.ll_steps = P(keep["loglik"]), P(keep["ll_steps"])

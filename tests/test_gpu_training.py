@@ -768,3 +768,58 @@ def test_native_training_recursion_matches_stepwise(tname, cls, N, M, T, chunk_r
     # fp32-vs-fp32 tolerance (scripts/debug/train_loop_diff.py: 0 .. 1.5e-4 for most seeds and sizes, exactly 0
     # at T = 1, 1.3e-3 for one seed at T = 3 whatever the chunking or the model class)
     assert worst[0] < GRAD_TOL, worst
+
+
+@pytest.mark.parametrize("tname,cls,N,M,T,chunk_rows", [
+    ("door", "DoorCrossmodalParticleFilter", 32, 30, 6, 262144),  # the reference's training shape, one chunk
+    ("door", "DoorCrossmodalParticleFilter", 5, 300, 3, 600),     # ragged chunks: the scratch sets are sized for the largest
+    ("door", "DoorParticleFilter", 3, 100, 3, 100),               # one measurement network: only the dynamics recompute forks
+])
+def test_native_training_recursion_on_side_streams_is_bit_identical(tname, cls, N, M, T, chunk_rows):
+    """``MmfPfTrainArgs.concurrent`` (small problems: the measurement networks' backward chains and the dynamics
+    recompute of a step on private side streams, the forward's second measurement launch likewise): the same
+    kernels, the same accumulation order -- loss, estimates and EVERY parameter gradient equal the single-stream
+    run's bit for bit, twice in a row (a missing event wait shows as a race)."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine
+
+    dev = torch.device("cuda:0")
+    task = om.TASKS[tname]
+    d = task.state_dim
+    obs, ctrl, x0, target, g = _data(task, T, N, 41)
+    eps0 = torch.randn((N, M, d), generator=g)
+    eps = [torch.randn((N, M, d), generator=g) for _ in range(T)]
+    cov = (torch.eye(d) * 0.1)[None].expand(N, d, d)
+    torch.manual_seed(4)
+    f = mmf.model_types(tname)[cls]().to(dev).train()
+    f.num_particles = M
+    engine.set_training_backend("hip")
+    old_chunk, old_conc = engine.TRAIN_CHUNK_ROWS, engine.TRAIN_CONCURRENT_ROWS
+    engine.TRAIN_CHUNK_ROWS = chunk_rows
+    seen = []
+    real = mmf._abi.pf_train_backward
+    mmf._abi.pf_train_backward = lambda a, *rest: (seen.append(int(a.concurrent)), real(a, *rest))[1]
+    results = []
+    try:
+        for conc_rows in (0, 1 << 20, 1 << 20):
+            engine.TRAIN_CONCURRENT_ROWS = conc_rows
+            f.zero_grad(set_to_none=True)
+            f.noise = mmf.ReplayNoise([eps0] + eps, [])
+            f.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
+            pred = f.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
+            loss = torch.mean((pred - target.to(dev)) ** 2)
+            loss.backward()
+            torch.cuda.synchronize()
+            results.append((loss.detach().clone(), pred.detach().clone(),
+                            {n: p.grad.detach().clone() for n, p in f.named_parameters() if p.grad is not None}))
+    finally:
+        mmf._abi.pf_train_backward = real
+        engine.set_training_backend(None)
+        engine.TRAIN_CHUNK_ROWS, engine.TRAIN_CONCURRENT_ROWS = old_chunk, old_conc
+    assert seen == [0, 1, 1]
+    (l0, p0, g0) = results[0]
+    for l1, p1, g1 in results[1:]:
+        assert torch.equal(l0, l1) and torch.equal(p0, p1)
+        assert set(g0) == set(g1) and len(g0) > 20
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k
