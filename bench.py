@@ -741,8 +741,16 @@ def main():
         # allocator's first blocks of those sizes, the first event records of the kernel timer.  So the pre-roll
         # ends with ONE untimed rehearsal of exactly the timed sequence; the W warm-up steps the contract asks
         # for follow it, then the K timed steps.
-        def measure(sync_clock):
-            timer = None if args.no_kernel_timers else engine.KernelTimer(loop_stride=K if K < 64 else (K + 2) // 3)  # 3 sampled steps (1 for short passes)
+        def make_timer():  # its event pool costs ~10 ms of an idle GPU
+            return None if args.no_kernel_timers else engine.KernelTimer(loop_stride=K if K < 64 else (K + 2) // 3)  # 3 sampled steps (1 for short passes)
+
+        def warm_up():  # the W warm-up steps cover the whole path, including the evaluation statistic
+            if W > 0:
+                pred_w = run(traj_w, noise_w)
+                distributed.all_gather_rows(
+                    evaluation.per_trajectory_mse(pred_w, traj_w["states"][1:], start=min(30, W // 2)))
+
+        def measure(sync_clock, timer):
             engine.set_kernel_timer(timer)
             distributed.barrier()
             torch.cuda.synchronize()
@@ -756,18 +764,21 @@ def main():
             engine.set_kernel_timer(None)
             return (distributed.max_over_ranks(dt, device) if sync_clock else dt), timer, mse_all, pred
 
+        # both timers (event pools) first: from the pre-roll to the timed steps the GPU then only idles at the
+        # synchronisation points -- after an idle stretch the chip's clocks take ~30 ms of load to come back
+        # (measured per step inside one pass, bench_pass_timecourse.txt: dynamics kernel 205-230 us on the first
+        # steps after a synchronisation, 184 from step ~40 on; no such ramp between back-to-back passes)
+        rehearsal_timer, timer = make_timer(), make_timer()
         if W > 0 and args.preroll_seconds > 0:
             t_pre = time.perf_counter()
             while time.perf_counter() - t_pre < args.preroll_seconds:
                 run(traj, noise)  # back to back, no synchronisation: the GPU stays loaded while the host enqueues
-            measure(False)        # the rehearsal: untimed
+            warm_up()                        # the rehearsal: the W-step warm-up and the timed sequence, untimed
+            measure(False, rehearsal_timer)
         torch.cuda.synchronize()
-        if W > 0:  # the warm-up covers the whole path, including the evaluation statistic
-            pred_w = run(traj_w, noise_w)
-            distributed.all_gather_rows(
-                evaluation.per_trajectory_mse(pred_w, traj_w["states"][1:], start=min(30, W // 2)))
+        warm_up()
         torch.cuda.synchronize()
-        return measure(True)
+        return measure(True, timer)
 
     if os.environ.get("MMF_BENCH_TIMECOURSE"):
         # debug: the same K-step pass over and over, with idles / an f32 pass in between -- what the pass's speed
@@ -792,6 +803,19 @@ def main():
             ks = timer.summary() if timer else {}
             print(json.dumps({"t": round(time.perf_counter() - t_proc, 2), "what": step, "ms_per_step": 1e3 * dt / K,
                               "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in ks.items()}}), flush=True)
+        if os.environ.get("MMF_BENCH_TIMECOURSE_STEPS") and wl["kind"] == "pf":
+            # every step's dynamics / first-measurement kernel duration inside ONE pass (events on every step: slower)
+            timer = engine.KernelTimer(prealloc=(8 * K + 64) * int(os.environ["MMF_BENCH_TIMECOURSE_STEPS"]), loop_stride=1)
+            engine.set_kernel_timer(timer)
+            torch.cuda.synchronize()
+            reps = int(os.environ["MMF_BENCH_TIMECOURSE_STEPS"])
+            for _ in range(reps):  # back to back, no synchronisation in between
+                run(traj, noise)
+            torch.cuda.synchronize()
+            engine.set_kernel_timer(None)
+            for name in ("particle_net_dynamics", "image_encoder"):
+                ms = [s_.elapsed_time(e_) for s_, e_, _, _ in timer.records[name]]
+                print(json.dumps({"per_step_us": name, "passes": reps, "values": [round(1e3 * v, 1) for v in ms]}), flush=True)
         return
     # Order of the GPU work (one GPU): the headline pass, the comparison pass in exact-f32 mode, the error study
     # against fp64, one second of idle, and the headline pass AGAIN -- each pass does its own pre-roll and W

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--gap-ms", type=float, default=2.0)
     ap.add_argument("--top", type=int, default=6)
     ap.add_argument("--kernels", type=int, default=3, help="kernels listed per region")
+    ap.add_argument("--gaps", type=int, default=0, help="list the N largest idle gaps of each region (us, kernel before -> after)")
     args = ap.parse_args()
     rows = []
     with open(args.trace) as fh:
@@ -40,7 +41,17 @@ def main():
             k = n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:70]
             names[k] = names.get(k, 0) + (e - s)
         top = sorted(names.items(), key=lambda kv: -kv[1])[:args.kernels]
-        out.append({"span_ms": span / 1e6, "kernel_ms": busy / 1e6, "busy": busy / max(span, 1), "launches": len(reg),
+        gaps = []
+        if args.gaps:
+            end = reg[0][1]
+            prev = reg[0][2]
+            for s0, e0, n0 in reg[1:]:
+                if s0 > end:
+                    gaps.append((round((s0 - end) / 1e3, 1), round((s0 - reg[0][0]) / 1e6, 3), prev.split("(")[0][-40:], n0.split("(")[0][-40:]))
+                if e0 > end:
+                    end, prev = e0, n0
+            gaps.sort(reverse=True)
+        out.append({"gaps_us_at_ms_before_after": gaps[: args.gaps], "span_ms": span / 1e6, "kernel_ms": busy / 1e6, "busy": busy / max(span, 1), "launches": len(reg),
                     "mean_gap_us": (span - busy) / max(len(reg) - 1, 1) / 1e3,
                     "top": [(k, round(v / 1e6, 3)) for k, v in top]})
     out.sort(key=lambda r: -r["span_ms"])
