@@ -30,6 +30,14 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def _single() -> bool:
+    """True when there is nothing to exchange.  ``MMF_DIST_FORCE_COLLECTIVES=1`` sends a one-rank group through
+    the collectives anyway (the one-GPU box's RCCL test: RCCL refuses two ranks on one device)."""
+    if not dist.is_initialized():
+        return True
+    return dist.get_world_size() == 1 and os.environ.get("MMF_DIST_FORCE_COLLECTIVES") != "1"
+
+
 def shard_bounds(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous, balanced ownership of the trajectory axis (first ranks get the remainder)."""
     base, rem = divmod(n_total, world)
@@ -46,7 +54,7 @@ def shard_trajectories(traj: Dict[str, torch.Tensor], rank: int, world: int) -> 
 
 def all_gather_rows(x: torch.Tensor) -> torch.Tensor:
     """Concatenate per-rank ``(N_local, ...)`` tensors along dim 0 (ragged shards allowed)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return x
     world = dist.get_world_size()
     # gloo moves host memory; RCCL moves device memory over xGMI
@@ -63,7 +71,7 @@ def all_gather_rows(x: torch.Tensor) -> torch.Tensor:
 
 
 def max_over_ranks(value: float, device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return value
     comm_dev = device if dist.get_backend() == "nccl" else torch.device("cpu")
     t = torch.tensor([value], dtype=torch.float64, device=comm_dev)
@@ -72,7 +80,7 @@ def max_over_ranks(value: float, device) -> float:
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if not _single():
         dist.barrier()
 
 
@@ -84,7 +92,7 @@ def all_reduce_gradients(module: torch.nn.Module, average: bool = True) -> int:
     params = [p for p in module.parameters() if p.requires_grad]
     if not params:
         return 0
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return sum(p.numel() for p in params)
     for p in params:
         if p.grad is None:

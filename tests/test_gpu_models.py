@@ -609,3 +609,42 @@ def test_native_step_loop_as_hip_graph_equals_direct_launches():
         engine.LOOP_GRAPH = old
         torch.cuda.synchronize()
         _abi.load().mmf_loop_graphs_release()
+
+
+def test_rccl_executes_the_collectives_one_rank():
+    """The exchange steps of the multi-GPU layout (X1 all-gather of per-sequence errors, the max-over-ranks clock,
+    X2 the flat gradient all-reduce, the barrier) on the ``nccl`` (= RCCL) backend with DEVICE tensors.  This box
+    has one GPU and RCCL refuses two ranks on one device ("Duplicate GPU detected"), so the group has one rank
+    and ``MMF_DIST_FORCE_COLLECTIVES=1`` keeps the functions from short-circuiting: what is checked is that the
+    RCCL code path of each function runs and returns the right values; the two-rank semantics are covered by
+    the gloo tests (``tests/test_distributed_cpu.py``)."""
+    _need_gpu()
+    import subprocess
+    import sys
+
+    code = r"""
+import os, torch, torch.distributed as dist
+import multimodalfilter_amd as mmf
+from multimodalfilter_amd import distributed
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+assert dist.get_backend() == "nccl"
+x = torch.arange(12, dtype=torch.float32, device="cuda:0").reshape(4, 3)
+g = distributed.all_gather_rows(x)
+assert g.is_cuda and torch.equal(g, x)
+assert distributed.max_over_ranks(1.25, torch.device("cuda:0")) == 1.25
+distributed.barrier()
+lin = torch.nn.Linear(5, 3).cuda()
+lin(torch.ones(2, 5, device="cuda:0")).sum().backward()
+want = [p.grad.clone() for p in lin.parameters()]
+n = distributed.all_reduce_gradients(lin)
+assert n == 18 and all(torch.equal(p.grad, w) for p, w in zip(lin.parameters(), want))
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RCCL-OK")
+"""
+    env = dict(os.environ, MMF_DIST_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29741",
+               RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "RCCL-OK" in out.stdout, out.stderr[-2000:]
