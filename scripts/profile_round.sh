@@ -22,7 +22,10 @@ done
 # training (config 5 shape) and the reference-sized regimes: kernel stats + GPU-busy fraction of the timed regions
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_train -- python3 $R/scripts/bench_train.py --steps 3 --backends hip > /dev/null 2> $P/train.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_ref -- python3 $R/scripts/bench_reference_sizes.py --no-cpu --eval-repeats 1 --train-iters 3 > /dev/null 2> $P/ref.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_trainref -- python3 $R/scripts/bench_reference_sizes.py --only train --backends hip --no-cpu --train-iters 10 > /dev/null 2> $P/trainref.err
 cd $R
+cp $(find $P/stats_trainref -name "*kernel_stats.csv" | head -1) $OUT/train_refsize_kernel_stats.csv
+python scripts/gpu_busy.py $(find $P/stats_trainref -name "*kernel_trace.csv" | head -1) --gap-ms 1.0 --top 4 --kernels 12 > $OUT/train_refsize_gpu_busy.txt 2>&1
 python scripts/gpu_busy.py $(find $P/stats_ref -name "*kernel_trace.csv" | head -1) --top 8 --kernels 4 > $OUT/reference_sizes_gpu_busy.txt 2>&1
 python scripts/gpu_busy.py $(find $P/stats_ekf -name "*kernel_trace.csv" | head -1) --top 3 --kernels 12 > $OUT/door_ekf_gpu_busy.txt 2>&1
 python scripts/gpu_busy.py $(find $P/stats -name "*kernel_trace.csv" | head -1) --top 3 --kernels 8 > $OUT/door_pf_gpu_busy.txt 2>&1
@@ -37,6 +40,8 @@ python bench.py --noise philox $LEAN > $OUT/bench_door_pf_philox.json 2>> $OUT/b
 python bench.py --workload push_pf --no-reference-sizes > $OUT/bench_push_pf_n1.json 2>> $OUT/bench.err
 python bench.py --workload door_ekf > $OUT/bench_door_ekf_n1.json 2>> $OUT/bench.err
 python bench.py --workload door_ekf --steps 20 --warmup 5 $LEAN > $OUT/bench_driver_flags_door_ekf.json 2>> $OUT/bench.err
+MMF_BENCH_TIMECOURSE=p,p,p,s1,p,f,p,s5,p MMF_BENCH_TIMECOURSE_STEPS=3 python bench.py --steps 20 --warmup 5 2>> $OUT/bench.err | grep "^{" > $OUT/bench_pass_timecourse_now.txt
+python scripts/debug/rccl_probe.py 2>&1 | grep -E "^rank|^world|Duplicate GPU" | sort -u > $OUT/bench_rccl_probe.txt
 python scripts/bench_k4.py > $OUT/bench_k4.txt 2>> $OUT/bench.err
 python scripts/bench_k1.py > $OUT/bench_k1.txt 2>> $OUT/bench.err
 python bench.py --workload door_pf --particles 1024 $LEAN --no-f32-mode > $OUT/bench_c2_door_pf_n256_m1024.json 2>> $OUT/bench.err
