@@ -891,6 +891,8 @@ def main():
         r = {"kernel": k2_kernel_name(d, prec) + " (measurement network)", "bound": "mfma", "achieved": ach,
              "peak": MFMA_PEAK[prec], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK[prec],
              "traffic": pmc_traffic(k2_kernel_name(d, prec)) if default_shape else None}
+        if dom["launches"] and engine.MEASURE_SEQ:
+            r["launch"] = "one launch = the filter's two measurement networks back to back in every workgroup (mmf_pf_measure_seq)"
         if prec == "f16x3":
             r["note"] = ("achieved counts ALGORITHMIC fp32 FLOPs; the kernel executes 3 f16 MFMA "
                          "products per algorithmic product (executed-MFMA fraction = 3 x frac)")

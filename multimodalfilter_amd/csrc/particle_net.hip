@@ -483,14 +483,25 @@ struct NetArgs {
 };
 
 // blockIdx.y selects one of up to MMF_LOOP_MAX_MEAS independent problems of the same shape (the
-// sub-filters of a fused EKF evaluate their Jacobians in one launch); every other caller uses 1.
+// sub-filters of a fused EKF evaluate their Jacobians in one launch).  `seq` > 1 instead runs that many
+// problems ONE AFTER THE OTHER in every workgroup -- the modalities of a crossmodal particle filter, whose
+// second network combines its log-likelihood with the first's (logsumexp in the epilogue): the tile -> wave
+// mapping is the same in every pass, so a lane re-reads what it wrote itself, and the launch boundary
+// between the two networks (a drained chip, a launch gap) disappears.
 struct NetArgsMulti {
   NetArgs a[MMF_LOOP_MAX_MEAS];
+  int seq = 1;  // problems a workgroup runs back to back (blockIdx.y covers the rest): see mmf_pf_measure_seq
 };
 
 template <int D, int NRES, int KIND, int CT, int PREC, int WPS, bool PIPE = false>
 __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMulti multi) {
-  const NetArgs a = multi.a[blockIdx.y];
+#pragma unroll 1
+  for (int pass = 0; pass < multi.seq; ++pass) {
+  const NetArgs a = multi.a[blockIdx.y * multi.seq + pass];
+  if (pass) {
+    __threadfence();   // this lane's log-likelihoods of the previous pass, before it reads them back
+    __syncthreads();   // every wave is done with the previous network's weights in LDS
+  }
   static_assert(!PIPE || (CT == 2 && PREC == MMF_PREC_F16X3 && KIND != kJacobian), "pipelined halves: f16x3, 64-particle tiles");
   constexpr int kThreads = WPS * 256;           // WPS waves per SIMD, one workgroup per CU (LDS)
   constexpr int kWavesPerBlock = kThreads / MMF_WAVE;
@@ -817,6 +828,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
       }
     }
   }
+  }  // pass
 }
 
 template <int D, int NRES, int KIND, int PREC, int CT, int WPS, bool PIPE = false>
@@ -986,6 +998,26 @@ extern "C" int mmf_pf_measure(const float* packed, int n_res, int precision, con
   a.logw_stride = logw_stride; a.loglik = loglik; a.combine = combine; a.R = N * M; a.M = M;
   a.range_flag = range_flag;
   return launch<kMeasure>(a, d, n_res, precision, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mmf_pf_measure_seq(const float* const* packed, int n_res, int precision, const float* states,
+                                  const float* const* traj_bias, const float* const* modality_logw, int logw_stride,
+                                  float* loglik, int* range_flag, int K, int N, int M, int d, void* stream) {
+  if (!packed || !states || !traj_bias || !loglik) return MMF_EINVAL;
+  if (K < 1 || K > MMF_LOOP_MAX_MEAS || N < 0 || M < 1) return MMF_EINVAL;
+  if (static_cast<long long>(N) * M > 0x7fffffffLL / 8) return MMF_ETOOLARGE;
+  if (N == 0) return 0;
+  NetArgsMulti m{};
+  for (int k = 0; k < K; ++k) {
+    if (!packed[k] || !traj_bias[k]) return MMF_EINVAL;
+    NetArgs& a = m.a[k];
+    a.packed = packed[k]; a.states_in = states; a.traj_bias = traj_bias[k];
+    a.mod_logw = modality_logw ? modality_logw[k] : nullptr;
+    a.logw_stride = logw_stride; a.loglik = loglik; a.combine = k > 0; a.R = N * M; a.M = M;
+    a.range_flag = range_flag;
+  }
+  m.seq = K;
+  return launch_multi<kMeasure>(m, 1, d, n_res, precision, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mmf_dynamics_jacobian(const float* packed, int n_res, int precision, const float* states_in,

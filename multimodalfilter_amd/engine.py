@@ -138,6 +138,13 @@ def image_encoder_precision_code() -> int:
 # hipGraph replay of the native particle-filter step loop (A/B switch, off by default: at the reference's
 # evaluation size the launches enqueued from C already keep the GPU 93 % busy -- DESIGN.md, T3)
 LOOP_GRAPH = os.environ.get("MMF_LOOP_GRAPH", "0") not in ("", "0")
+# The modalities of a crossmodal particle filter as ONE launch per step (mmf_pf_measure_seq: every workgroup
+# runs the networks one after the other on its own tiles; bit-identical to one launch per modality --
+# tests/test_gpu_kernels.py, tests/test_gpu_models.py).  OFF by default: measured at 256 x 4096 the fused launch
+# takes 0.297 ms against 2 x 0.140 (step 0.589 vs 0.568 ms), at 32 x 300 the step 0.0611 vs 0.0591 ms -- the
+# workgroup-wide barrier between the two networks (every wave waits for the slowest before the weights are
+# re-staged) costs more than the launch boundary it removes.
+MEASURE_SEQ = os.environ.get("MMF_MEASURE_SEQ", "0") not in ("", "0")
 
 
 # Training is opt-in: nothing switches paths silently, and eval() always means the forward-only HIP

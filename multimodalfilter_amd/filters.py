@@ -334,9 +334,11 @@ class ParticleFilter(base.Filter):
                 a.indices_steps = ctypes.c_void_p(_abi.ptr(self.last_resample_indices, dtype=torch.int32))
         a.range_flag = ctypes.c_void_p(engine.range_flag(dev).data_ptr())
         a.use_graph = int(engine.LOOP_GRAPH)
+        fused_measure = engine.MEASURE_SEQ and len(nets) > 1
+        a.measure_seq = int(fused_measure)
         timer = engine.kernel_timer()
         events = None
-        names = ["particle_net_dynamics"] + ["particle_net_measure"] * len(nets) + ["pf_reweight_resample"]
+        names = ["particle_net_dynamics"] + ["particle_net_measure"] * (1 if fused_measure else len(nets)) + ["pf_reweight_resample"]
         stride = 1
         if timer is not None:
             stride = max(1, int(timer.loop_stride))
@@ -346,8 +348,9 @@ class ParticleFilter(base.Filter):
             R = N * M
             dflops = 2.0 * R * engine.particle_net_macs(d, dyn._net.n_res, dyn._net.n_out)
             work = [(dflops, R * 4.0 * 3 * d)]
-            for k, (net, _, _) in enumerate(nets):
-                work.append((2.0 * R * engine.particle_net_macs(d, net.n_res, net.n_out), R * 4.0 * (d + 1 + (k > 0))))
+            mwork = [(2.0 * R * engine.particle_net_macs(d, net.n_res, net.n_out), R * 4.0 * (d + 1 + (k > 0)))
+                     for k, (net, _, _) in enumerate(nets)]
+            work += [(sum(w[0] for w in mwork), sum(w[1] for w in mwork))] if fused_measure else mwork
             work.append((0.0, R * 4.0 * (2 + 2 * d)))
             timer.add_loop_records(names, work, events)
         self.particle_states = states_b if loc & 1 else states_a

@@ -710,3 +710,46 @@ def test_k2_full_size_cross_checks(task):
     for a, b in zip(out["f16x3"], out["f32"]):
         assert bool(torch.isfinite(a).all())
         assert _rel_err(a.cpu(), b.cpu()) < 1e-4
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"], indirect=True)
+@pytest.mark.parametrize("task", ["door", "push"])
+@pytest.mark.parametrize("N,M", [(1, 1), (3, 5), (4, 300), (2, 4096), (33, 4001), (256, 1024)])
+def test_k2_measurement_networks_in_one_launch_equal_one_launch_each(task, N, M, precision):
+    """``mmf_pf_measure_seq`` (every workgroup runs the crossmodal filter's measurement networks one after the
+    other on its own tiles, the second combining with what the first wrote) against one ``mmf_pf_measure``
+    launch per modality with combine = 0, 1: the fused log-likelihoods are the SAME BITS, in both arithmetic
+    modes, for ragged tile counts and for launches wider than the chip."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import _abi, engine
+
+    dev = _cuda()
+    spec = om.TASKS[task]
+    d = spec.state_dim
+    g = torch.Generator().manual_seed(N * 17 + M)
+    x = torch.randn((N, M, d), generator=g).to(dev)
+    obs = {"image": torch.randn((N, 32, 32), generator=g).clamp(-1, 1).to(dev),
+           "gripper_pos": torch.randn((N, 3), generator=g).to(dev),
+           "gripper_sensors": torch.randn((N, 7), generator=g).to(dev)}
+    torch.manual_seed(5)
+    models = mmf.door_models if task == "door" else mmf.push_models
+    f = getattr(models, ("Door" if task == "door" else "Push") + "CrossmodalParticleFilter")().to(dev).eval()
+    meas = f.measurement_model
+    with torch.no_grad():
+        ctx = meas.encode_observations(obs)
+        nets, stride = meas.fused_measurements(ctx)
+    assert len(nets) == 2 and stride == 2
+    prec = nets[0][0].precision_code()
+    flag = engine.range_flag(dev)
+    one_each = torch.full((N, M), float("nan"), device=dev)
+    for k, (net, bias, lw) in enumerate(nets):
+        _abi.pf_measure(net.blob(), net.n_res, prec, x, bias, lw, stride, one_each, k > 0, flag, N, M, d)
+    fused = torch.full((N, M), float("nan"), device=dev)
+    _abi.pf_measure_seq([n.blob() for n, _, _ in nets], nets[0][0].n_res, prec, x, [b for _, b, _ in nets],
+                        [lw for _, _, lw in nets], stride, fused, flag, N, M, d)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(one_each).all())
+    assert torch.equal(fused, one_each)
+    # and it is the measurement model's own answer
+    want = meas(states=x, observations=obs)
+    assert torch.equal(fused, want)
