@@ -806,9 +806,12 @@ def main():
         if os.environ.get("MMF_BENCH_TIMECOURSE_STEPS") and wl["kind"] == "pf":
             # every step's dynamics / first-measurement kernel duration inside ONE pass (events on every step: slower)
             timer = engine.KernelTimer(prealloc=(8 * K + 64) * int(os.environ["MMF_BENCH_TIMECOURSE_STEPS"]), loop_stride=1)
-            engine.set_kernel_timer(timer)
-            torch.cuda.synchronize()
             reps = int(os.environ["MMF_BENCH_TIMECOURSE_STEPS"])
+            for _ in range(3):  # load first: what is measured is the idle stretch that follows it
+                run(traj, noise)
+            torch.cuda.synchronize()
+            time.sleep(float(os.environ.get("MMF_BENCH_TIMECOURSE_IDLE_MS", "0")) * 1e-3)
+            engine.set_kernel_timer(timer)
             for _ in range(reps):  # back to back, no synchronisation in between
                 run(traj, noise)
             torch.cuda.synchronize()
