@@ -68,8 +68,10 @@ int mmf_version(void);
  *                              written (the survivors' weights are uniform by definition)
  *  indices_out (N, M_out) int32 ancestor indices, or null
  *  mode        0 none, 1 systematic, 2 multinomial
- * Limits: d <= 4; M, M_out <= 65536; mode 0 stages 4 B/particle in LDS (M <= 40000),
- *         modes 1/2 keep the 8-byte CDF there (M <= 20000); larger -> MMF_ETOOLARGE.
+ * Limits: d <= 4; M, M_out <= 65536; mode 0 stages 4 B/particle in LDS (M <= 40,800),
+ *         modes 1/2 keep the 8-byte CDF there (M <= 20,400: mmf_pf_reweight_resample_lds_bytes(M, mode)
+ *         <= 160 KiB); larger -> MMF_ETOOLARGE.  Plain systematic resampling of M, M_out <= 20,000 takes
+ *         the search-free kernel, everything else the CDF-search kernel.
  */
 int mmf_pf_reweight_resample(const float* loglik, const float* logw_in, const float* states_in,
                              const float* u, float* estimate, float* states_out,

@@ -79,3 +79,58 @@ def test_model_registry_and_state_dict_keys_match_oracle():
         for name, cls in mmf.model_types(task).items():
             assert cls.__name__ == name
             assert set(cls().state_dict()) == set(om.build(name).state_dict()), name
+
+
+def test_every_entry_point_rejects_null_arguments():
+    """Error behaviour of the boundary, uniformly: every ``int``-returning entry point called with null pointers
+    and zero sizes returns ``MMF_EINVAL`` (-1) before any HIP call (so this runs without a GPU) -- no crash, no
+    launch.  The reference raises ``AssertionError`` on bad shapes; the host side turns a non-zero
+    return into ``MmfError``."""
+    import ctypes
+
+    from multimodalfilter_amd import _abi
+
+    lib = _abi.load()
+    checked = 0
+    for name, (res, args) in _abi.SIGNATURES.items():
+        if res is not ctypes.c_int or not args:
+            continue
+        vals = [0 if a in (ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_size_t) else
+                (0.0 if a is ctypes.c_float else None) for a in args]
+        assert getattr(lib, name)(*vals) == -1, name
+        checked += 1
+    assert checked >= 35
+
+
+def test_size_limits_and_empty_batches_at_the_boundary():
+    """Sizes beyond what a kernel indexes -> ``MMF_ETOOLARGE`` (-2); unsupported ``d`` / precision / aliasing ->
+    ``MMF_EINVAL``; an EMPTY batch (N = 0 trajectories, R = 0 rows) is a successful no-op.  All decided on the
+    host before any HIP call: the pointers here are never dereferenced."""
+    import ctypes
+
+    from multimodalfilter_amd import _abi
+
+    lib = _abi.load()
+    bufs = [(ctypes.c_float * 16)() for _ in range(9)]
+    P = [ctypes.cast(b, ctypes.c_void_p) for b in bufs]
+    F32 = _abi.PREC_F32
+    EINVAL, ETOOLARGE = -1, -2
+    # too large
+    assert lib.mmf_pf_measure(P[0], 2, F32, P[1], P[2], None, 0, P[3], 0, None, 1 << 20, 1 << 12, 3, None) == ETOOLARGE
+    assert lib.mmf_pf_dynamics(P[0], 3, F32, P[1], P[2], P[3], P[4], P[5], None, 1 << 20, 1 << 12, 3, None) == ETOOLARGE
+    assert lib.mmf_dynamics_jacobian(P[0], 3, F32, P[1], P[2], P[3], P[4], None, 1 << 30, 3, None) == ETOOLARGE
+    # systematic resampling keeps an 8-byte CDF entry per particle in the 160 KiB LDS: 20,400 particles fit, 20,480 do not
+    rs = lambda M, mode, out: lib.mmf_pf_reweight_resample(P[0], P[1], P[2], P[3], P[4], out, P[6], None, 4, M, M, 3, mode, None)
+    assert lib.mmf_pf_reweight_resample_lds_bytes(20400, 1) <= 160 * 1024 < lib.mmf_pf_reweight_resample_lds_bytes(20480, 1)
+    assert rs(20480, 1, P[5]) == ETOOLARGE and rs(41000, 0, P[1]) == ETOOLARGE and rs(65537, 0, P[1]) == ETOOLARGE
+    assert rs(64, 1, P[2]) == EINVAL            # in-place gather
+    assert lib.mmf_pf_reweight_resample(P[0], P[1], P[2], P[3], P[4], P[5], P[6], None, 4, 64, 64, 5, 1, None) == EINVAL  # d > 4
+    # unsupported precision code / state dimension
+    assert lib.mmf_pf_measure(P[0], 2, 77, P[1], P[2], None, 0, P[3], 0, None, 4, 64, 3, None) == EINVAL
+    assert lib.mmf_pf_measure(P[0], 2, F32, P[1], P[2], None, 0, P[3], 0, None, 4, 64, 5, None) == EINVAL
+    # empty batches
+    assert lib.mmf_pf_measure(P[0], 2, F32, P[1], P[2], None, 0, P[3], 0, None, 0, 64, 3, None) == 0
+    assert lib.mmf_pf_dynamics(P[0], 3, F32, P[1], P[2], P[3], P[4], P[5], None, 0, 64, 3, None) == 0
+    assert lib.mmf_dynamics_jacobian(P[0], 3, F32, P[1], P[2], P[3], P[4], None, 0, 3, None) == 0
+    assert lib.mmf_image_encoder((ctypes.c_void_p * 1)(P[0]), 1, P[1], P[2], P[3], None, F32, 0, 0, None) == 0
+    assert lib.mmf_traj_program(P[0], 1, P[1], (ctypes.c_void_p * 8)(), 0, 1, 64, None) == 0
