@@ -76,6 +76,20 @@ def pmc_traffic(kernel_key: str):
     return None
 
 
+def pmc_traffic_k4_ekf():
+    """HBM bytes of ONE image-encoder launch sequence of the EKF bench (4096 images x 2 encoders), summed over
+    its five kernels, from the PMC passes of that very command (``profiles/r03/pmc_hbm_traffic_ekf.json``)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03", "pmc_hbm_traffic_ekf.json")) as fh:
+            k = json.load(fh)["kernels"]
+        total = 0.0
+        for prefix in ("stem_conv2a_kernel<false", "conv2b_conv3_kernel<false", "conv4_kernel", "fc_partial_f16x3_kernel", "fc_tail_kernel<false"):
+            total += [v for name, v in k.items() if name.startswith(prefix)][0]["hbm_bytes_corrected"]
+        return total
+    except (OSError, KeyError, ValueError, IndexError):
+        return None
+
+
 def pmc_traffic_k4_sequence(n_images: int, nets: int):
     """HBM bytes of ONE fused image-encoder launch sequence (stem+conv2a, conv2b+conv3, conv 16->8,
     linear partials + tail) from the committed K4 PMC passes (``scripts/bench_k4.py`` under
@@ -924,10 +938,10 @@ def main():
                                          "conv4_kernel, fc_partial_f16x3_kernel, fc_tail_kernel) per chunk of images",
                                "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK["f16x3"], "unit": "TFLOP/s",
                                "frac": ach / MFMA_PEAK["f16x3"],
-                               "traffic": pmc_traffic_k4_sequence(2048, 2) if (B == 1024 and args.workload == "door_ekf") else None,
+                               "traffic": pmc_traffic_k4_ekf() if (B == 1024 and args.workload == "door_ekf") else None,
                                "note": "ALGORITHMIC fp32 FLOPs (26.12 MMAC per image per encoder); every product is 3 f16 MFMA "
-                                       "products (executed-MFMA fraction = 3 x frac); traffic = one launch sequence over 2048 "
-                                       "images x 2 encoders: the image virtual sensor's and the weight model's (DESIGN.md K4)"}
+                                       "products (executed-MFMA fraction = 3 x frac); traffic = one launch sequence over 4096 "
+                                       "images x 2 encoders (the image virtual sensor's and the weight model's), PMC passes of this command"}
     if "roofline" not in out:
         out["roofline"] = None
 

@@ -872,7 +872,11 @@ def image_features_autograd(seq, images: torch.Tensor) -> torch.Tensor:
 
 _IMAGE_WORKSPACES = {}
 _MAX_NETS = 4
-_IMAGE_CHUNK = int(os.environ.get("MMF_IMAGE_CHUNK", "2048"))  # images per K4 launch sequence (workspace ~0.8 GB per encoder)
+# images per K4 launch sequence (workspace ~1.6 GB per encoder).  Measured round 3 on the EKF step (1024 trajectories,
+# three encoders) / the PF step: 512 images 0.482 / 0.612 ms, 1024 0.446 / 0.599, 2048 0.435 / 0.596, 4096 0.420 / 0.588,
+# 8192 .. 32768 no further gain: the persistent kernels' fill / drain per launch is what a chunk amortises; keeping
+# the intermediates inside the 256 MiB Infinity Cache (small chunks) buys nothing.
+_IMAGE_CHUNK = int(os.environ.get("MMF_IMAGE_CHUNK", "4096"))
 
 
 def _image_workspace(device, n_images: int, n_nets: int) -> torch.Tensor:

@@ -15,7 +15,7 @@ def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     reps = int(os.environ.get("REPS", "10"))
-    for n_img, nets in ((2048, 2), (1024, 3), (256, 2), (32, 3)):
+    for n_img, nets in ((4096, 2), (4096, 3), (2048, 2), (1024, 3), (256, 2), (32, 3)):
         encs = [layers.image_encoder(64).to(dev) for _ in range(nets)]
         img = (torch.randn((n_img, 32, 32), device=dev) * 0.5).clamp(-1, 1)
         outs = {}

@@ -82,7 +82,7 @@ def main(src, dst):
         if hits:
             shutil.copy(max(hits, key=os.path.getmtime), f"{dst}/door_{'pf_f32_mode' if tag == 'f32' else 'ekf'}_kernel_stats.csv")
     # HBM traffic of the variants (exact-f32 kernels, in-kernel philox noise): same reduction, own files
-    for tag in ("f32", "philox"):
+    for tag in ("f32", "philox", "ekf"):
         per_v = {}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             hits = glob.glob(f"{src}/pmc_{tag}_{counter}/**/*_counter_collection.csv", recursive=True)
@@ -101,7 +101,8 @@ def main(src, dst):
                                 "launches": len(c["FETCH_SIZE"])}
         if rows_v:
             with open(f"{dst}/pmc_hbm_traffic_{tag}.json", "w") as fh:
-                json.dump({"workload": f"door crossmodal PF, N=256, M=4096, variant {tag} (bench.py --{'precision f32' if tag == 'f32' else 'noise philox'})",
+                json.dump({"workload": "door crossmodal EKF, N=1024 (bench.py --workload door_ekf --steps 8 --warmup 0: two launch sequences of 4096 images x 2 encoders)" if tag == "ekf" else
+                                       f"door crossmodal PF, N=256, M=4096, variant {tag} (bench.py --{'precision f32' if tag == 'f32' else 'noise philox'})",
                            "unit": "KB per launch; hbm_bytes_corrected = (2 FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": rows_v}, fh, indent=1)
     k4 = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -534,8 +534,8 @@ def test_full_size_crossmodal_ekf_matches_oracle_on_a_shard():
     """BASELINE config 4's per-GPU shape: door crossmodal EKF, 1024 trajectories, 5 steps.  The
     native loop equals step-by-step evaluation bit for bit; with ``fix_weight_layout`` (the
     shard-invariant weight layout) trajectories are independent, so 24 of the 1024 -- the first 12 and
-    the LAST 12, i.e. the head and the tail of the image encoder's 2048-image launch chunks (image 2047 =
-    trajectory 1023 of step 1) -- must reproduce the CPU oracle run on those 24 alone: means and fused
+    the LAST 12, i.e. the head and the tail of the image encoder's 4096-image launch chunks (image 4095 =
+    trajectory 1023 of step 3) -- must reproduce the CPU oracle run on those 24 alone: means and fused
     covariances within 1e-4."""
     _need_gpu()
     import multimodalfilter_amd as mmf
