@@ -1052,11 +1052,14 @@ extern "C" int mmf_image_encoder(const float* const* packed, int n_nets, const f
     fa.out = bufA;
     if ((rc = launch_fused(fa, n_nets, 0, bf16, s))) return rc;
     fa.bin = bufA; fa.out = bufB;
+    fa.out_e = fuse_conv4() ? bufC : nullptr;  // conv 16->8 in the same kernel: D never reaches HBM
     if ((rc = launch_fused(fa, n_nets, 1, bf16, s))) return rc;
-    Conv4Args c4{};
-    for (int i = 0; i < n_nets; ++i) c4.packed[i] = packed[i];
-    c4.N = N; c4.din = reinterpret_cast<const unsigned char*>(bufB); c4.out = bufC;
-    if ((rc = launch_conv4(c4, n_nets, s))) return rc;
+    if (!fa.out_e) {
+      Conv4Args c4{};
+      for (int i = 0; i < n_nets; ++i) c4.packed[i] = packed[i];
+      c4.N = N; c4.din = reinterpret_cast<const unsigned char*>(bufB); c4.out = bufC;
+      if ((rc = launch_conv4(c4, n_nets, s))) return rc;
+    }
     bufB = bufC;  // the linear tail reads E
   } else if (precision == MMF_PREC_F16X3) {
     c.in = images; c.in_net_stride = 0; c.skip = nullptr; c.out = bufA; c.woff = L.w1; c.boff = L.b1;

@@ -4,6 +4,7 @@ algebra + fusion) and K2/K5 (per-particle networks, Jacobian) within 1e-4 relati
 oracle's fp32 torch restatement (the tolerance ``north_star`` states).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -753,3 +754,35 @@ def test_k2_measurement_networks_in_one_launch_equal_one_launch_each(task, N, M,
     # and it is the measurement model's own answer
     want = meas(states=x, observations=obs)
     assert torch.equal(fused, want)
+
+
+@pytest.mark.parametrize("image_precision", [None, "bf16"])
+@pytest.mark.parametrize("N,nets", [(1, 1), (37, 2), (300, 3), (1500, 2), (5000, 2)])
+def test_k4_conv4_inside_conv2b_conv3_is_bit_identical_to_the_conv4_kernel(N, nets, image_precision):
+    """Round 3: conv 16->8 runs in the Y waves of ``conv2b_conv3_kernel`` (D rows stay in an LDS ring, E leaves)
+    instead of as ``conv4_kernel`` (``MMF_K4_CONV4_KERNEL=1``).  Same MFMA sequence per output row, so the encoders'
+    features are the SAME BITS either way -- for one image, for workgroups that walk several images (ring slots
+    reused across image boundaries), for more images than a launch chunk, in both product modes; three repetitions
+    each (a ring hazard would show as a run-to-run difference)."""
+    from multimodalfilter_amd import engine, layers
+
+    dev = _cuda()
+    torch.manual_seed(N)
+    encs = [layers.image_encoder(64).to(dev) for _ in range(nets)]
+    img = (torch.randn((N, 32, 32), device=dev) * 0.5).clamp(-1, 1)
+    old_env = os.environ.get("MMF_K4_CONV4_KERNEL")
+    engine.set_image_encoder_precision(image_precision)
+    try:
+        os.environ["MMF_K4_CONV4_KERNEL"] = "1"
+        want = torch.stack(engine.encode_images(encs, img))
+        os.environ["MMF_K4_CONV4_KERNEL"] = "0"
+        for _ in range(3):
+            got = torch.stack(engine.encode_images(encs, img))
+            assert torch.equal(got, want)
+        assert bool(torch.isfinite(got).all()) and float(got.abs().max()) > 0
+    finally:
+        engine.set_image_encoder_precision(None)
+        if old_env is None:
+            os.environ.pop("MMF_K4_CONV4_KERNEL", None)
+        else:
+            os.environ["MMF_K4_CONV4_KERNEL"] = old_env
