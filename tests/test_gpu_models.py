@@ -683,3 +683,39 @@ def test_native_loop_with_one_measurement_launch_per_step_is_bit_identical(cls, 
     for a, b in zip(out[False], out[True]):
         assert torch.equal(a, b)
     assert bool(torch.isfinite(out[True][0]).all())
+
+
+@pytest.mark.parametrize("index", [0, 1])
+def test_likelihood_map_call_of_the_reference_notebook(index):
+    """The third caller of the path: ``scripts/door_task/vis_pf_likelihoods.ipynb`` cell 3 evaluates ONE
+    unimodal measurement model of the crossmodal particle filter (index 0 image, 1 proprioception / haptics) on a
+    239 x 239 grid of states around a trajectory's state -- N = 1, M = 57,121 "particles", far beyond anything the
+    filters use -- with one time step's observations.  Same call on the engine, against the CPU oracle: 1e-4."""
+    _need_gpu()
+    import multimodalfilter_amd as mmf
+
+    dev = torch.device("cuda:0")
+    span, resolution = 27 / 5.65, 0.02
+    grid = np.mgrid[-span / 2.0: span / 2.0: resolution, -span / 2.0: span / 2.0: resolution]
+    _, cols, rows = grid.shape
+    assert cols * rows == 57121
+    delta = np.concatenate((np.zeros((1, cols * rows, 1)), grid.T.reshape((1, cols * rows, 2))), axis=2)
+    g = torch.Generator().manual_seed(3)
+    center = torch.randn((1, 1, 3), generator=g)
+    states = (center + torch.from_numpy(delta)).to(torch.float32)
+    obs = {"image": torch.randn((1, 32, 32), generator=g).clamp(-1, 1),
+           "gripper_pos": torch.randn((1, 3), generator=g), "gripper_sensors": torch.randn((1, 7), generator=g)}
+    oracle = om.ParticleFilter(om.TASKS["door"], "crossmodal")
+    oracle.load_state_dict(om.seeded_state_dict(oracle, seed=4, gain=1.0))
+    oracle.eval()
+    f = mmf.door_models.DoorCrossmodalParticleFilter()
+    f.load_state_dict(oracle.state_dict())
+    f.to(dev).eval()
+    with torch.no_grad():
+        want = oracle.measurement_model.measurement_models[index](states=states, observations=obs)
+        got = f.measurement_model.measurement_models[index](states=states.to(dev), observations={k: v.to(dev) for k, v in obs.items()})
+    assert got.shape == want.shape == (1, 57121)
+    assert float((got.cpu() - want).abs().max()) < REL_TOL * max(1.0, float(want.abs().max()))
+    # the map the notebook plots: the same argmax cell, or a tie within the tolerance
+    top = int(want.argmax())
+    assert float(want[0, top] - want[0, int(got.cpu().argmax())]) < REL_TOL * max(1.0, float(want.abs().max()))
