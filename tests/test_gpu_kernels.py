@@ -786,3 +786,46 @@ def test_k4_conv4_inside_conv2b_conv3_is_bit_identical_to_the_conv4_kernel(N, ne
             os.environ.pop("MMF_K4_CONV4_KERNEL", None)
         else:
             os.environ["MMF_K4_CONV4_KERNEL"] = old_env
+
+
+@pytest.mark.parametrize("layer,what", [(0, "stem output (A / B planes)"), (2, "ResConv output (C rows, X waves)"),
+                                        (3, "conv 32->16 output (D rows, Y waves: the ring of the fused conv 16->8)"),
+                                        (5, "conv 16->8 output (E, split by the linear layer)")])
+def test_k4_f16x3_range_flag_reports_saturated_split(layer, what):
+    """Every place the fused image encoder splits an activation into two f16 halves tracks its range: an activation
+    beyond 65504 must raise the engine's range flag (``engine.check_range``), whichever layer produces it; the bf16
+    mode (fp32 exponent range) and the exact-f32 per-layer path never do."""
+    from multimodalfilter_amd import _abi, engine, layers
+
+    dev = _cuda()
+    torch.manual_seed(layer)
+    enc = layers.image_encoder(64)
+    with torch.no_grad():  # a bias of 1e5 on one output channel of the layer
+        target = enc[layer].block2 if layer == 2 else enc[layer]
+        target.bias[0] = 1.0e5
+    enc.to(dev)
+    img = (torch.randn((5, 32, 32), device=dev) * 0.5).clamp(-1, 1)
+    old = engine.DEFAULT_PRECISION
+    try:
+        engine.set_default_precision("f16x3")
+        engine.check_range(dev)  # clear
+        engine.encode_images([enc], img)
+        with pytest.raises(_abi.MmfError, match="f16x3 operand range"):
+            engine.check_range(dev)
+        # bf16 mode: the 32-channel planes are bf16 (fp32 exponent range), but conv 16->8 and the linear layer stay
+        # f16x3, so D and E are still split into f16 halves there
+        engine.set_image_encoder_precision("bf16")
+        engine.encode_images([enc], img)
+        if layer in (0, 2):
+            engine.check_range(dev)
+        else:
+            with pytest.raises(_abi.MmfError, match="f16x3 operand range"):
+                engine.check_range(dev)
+        engine.set_image_encoder_precision(None)
+        engine.set_default_precision("f32")
+        out = engine.encode_images([enc], img)[0]
+        engine.check_range(dev)
+        assert bool(torch.isfinite(out).all())
+    finally:
+        engine.set_image_encoder_precision(None)
+        engine.set_default_precision(old)
