@@ -147,6 +147,7 @@ def test_strict_k1_estimate_bit_exact(M):
 
 @pytest.mark.parametrize("cls,N,M,T", [("DoorCrossmodalParticleFilter", 32, 4096, 12),
                                        ("DoorCrossmodalParticleFilter", 256, 1024, 4),   # BASELINE config 2 at its own size
+                                       ("DoorCrossmodalParticleFilter", 256, 4096, 3),   # the headline shape itself: 3.1 M ancestors
                                        ("PushCrossmodalParticleFilter", 6, 300, 20),
                                        ("DoorUnimodalParticleFilter", 4, 1000, 8)])
 def test_strict_free_running_filter_bit_exact(f32_mode, cls, N, M, T):
