@@ -37,6 +37,32 @@ __device__ __forceinline__ unsigned dpp_u32(unsigned fill, unsigned v) {
   return static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(fill), static_cast<int>(v), CTRL, ROW_MASK, 0xf, false));
 }
 
+// Copy N4 float4 from global memory to LDS with THREADS threads, BATCH loads in flight per thread.  The plain
+// `for (i = tid; i < n; i += threads) dst[i] = src[i]` compiles to load -> wait -> store per iteration (hipcc does
+// not unroll it): 15-19 dependent L2 round trips, ~6 us, before a workgroup's first MFMA -- half the duration of
+// a per-particle-network launch at the reference's 32 x 300 size and ~4 % of one at 256 x 4096.  Every trip count
+// is a compile-time constant, so the staging registers never become an indexed (scratch) array.
+template <int N4, int THREADS, int BATCH = 8>
+__device__ __forceinline__ void stage_to_lds(const float4* __restrict__ src, float4* __restrict__ dst, int tid) {
+  constexpr int K = (N4 + THREADS - 1) / THREADS;
+#pragma unroll
+  for (int b = 0; b < K; b += BATCH) {
+    float4 t[BATCH];
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k)
+      if (b + k < K) {
+        const int i = tid + (b + k) * THREADS;
+        if ((b + k + 1) * THREADS <= N4 || i < N4) t[k] = src[i];
+      }
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k)
+      if (b + k < K) {
+        const int i = tid + (b + k) * THREADS;
+        if ((b + k + 1) * THREADS <= N4 || i < N4) dst[i] = t[k];
+      }
+  }
+}
+
 __device__ __forceinline__ float wave_max(float v) {
   v = fmaxf(v, dpp_f32<kDppXor1>(v, v));
   v = fmaxf(v, dpp_f32<kDppXor2>(v, v));

@@ -516,7 +516,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
   {
     const float4* src = reinterpret_cast<const float4*>(a.packed);
     float4* dst = reinterpret_cast<float4*>(lds);
-    for (int i = threadIdx.x; i < blob_floats(NRES) / 4; i += kThreads) dst[i] = src[i];
+    mmf::stage_to_lds<blob_floats(NRES) / 4, kThreads>(src, dst, threadIdx.x);
   }
   __syncthreads();
 
