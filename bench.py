@@ -14,6 +14,17 @@ per-sequence squared errors, ``multimodalfilter_amd/distributed.py``).
 Inputs (observations, controls, pre-drawn noise) are resident in HBM when the timed region
 starts; the timed region is ``forward_loop`` over exactly K steps, bracketed by barrier +
 ``torch.cuda.synchronize()``; the time is the max over ranks.  Rank 0 prints ONE JSON line.
+
+A particle filter's timed steps are steps ``B+W+1 .. B+W+K`` of ONE filter run over one trajectory:
+``B`` = ``BURN_IN`` untimed steps from the reference's initial belief (``states[0]``, ``0.1 I``:
+``eval_helpers.py:125-131``), then the W warm-up steps, then the K timed ones, the belief carried
+from one ``forward_loop`` call to the next -- so the timed steps are a filter that is TRACKING, with the
+measurement heads calibrated (``calibrate_to_band``) to hold ESS/M inside SURVEY.md 8d's [0.05, 0.5]
+there (the line reports the engine's own ESS/M over the timed steps: ``ess_over_m``).
+
+``configs`` (one GPU, default on): BASELINE.json's other configurations and the blackout workloads
+(``tasks/_door.py:181-197``) as bounded legs of the same run -- each with its value,
+ms per step, its dominant kernel's roofline fraction and one parity number against the oracle.
 """
 import argparse
 import json
@@ -48,6 +59,13 @@ WORKLOADS = {
                     desc="push crossmodal particle filter"),
     "door_ekf": dict(task="door", cls="DoorCrossmodalKalmanFilter", kind="ekf", batch=1024, particles=1,
                      desc="door crossmodal EKF"),
+    # SURVEY.md 8d's second run: image_blackout_ratio 0.4 (tasks/_door.py:181-197) through the filters that KNOW
+    # about blackouts (door_models/crossmodal_pf.py:99-104 via ...Seq5; door_models/crossmodal_kf.py:43-98)
+    "door_pf_blackout": dict(task="door", cls="DoorCrossmodalParticleFilterSeq5", kind="pf", batch=256, particles=4096,
+                             blackout=0.4, desc="door crossmodal particle filter (know_image_blackout), 40 % of the frames blacked out"),
+    "door_ekf_blackout": dict(task="door", cls="DoorCrossmodalKalmanFilter", kind="ekf", batch=1024, particles=1,
+                              blackout=0.4, ctor=dict(know_image_blackout=True),
+                              desc="door crossmodal EKF (know_image_blackout), 40 % of the frames blacked out"),
 }
 
 
@@ -59,11 +77,16 @@ def workload_desc(wl, batch, particles, total_batch, world, scaling) -> str:
     return f"{what}, batch {batch} trajectories per GPU x {world} GPU(s)"
 
 
+BURN_IN = 24  # untimed particle-filter steps ahead of the warm-up: the cloud contracts from the 0.1 I
+              # initial belief to its tracking width within ~8 steps (ESS/M 0.35 -> 0.9 under round 3's
+              # calibration at t = 0); the heads are calibrated to the TRACKING regime
+
+
 def pmc_traffic(kernel_key: str):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
     collected in separate runs of this same command; FETCH_SIZE doubled as the gfx950 note of
     MI355X_MICROARCH.md prescribes).  ``None`` when no profile of this workload is committed."""
-    for rnd in ("r03", "r02"):       # the newest committed round that profiled this kernel
+    for rnd in ("r04", "r03", "r02"):       # the newest committed round that profiled this kernel
         for fname in ("pmc_hbm_traffic.json", "pmc_hbm_traffic_f32.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, fname)) as fh:
@@ -80,7 +103,10 @@ def pmc_traffic_k4_ekf():
     """HBM bytes of ONE image-encoder launch sequence of the EKF bench (4096 images x 2 encoders), summed over
     its five kernels, from the PMC passes of that very command (``profiles/r03/pmc_hbm_traffic_ekf.json``)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03", "pmc_hbm_traffic_ekf.json")) as fh:
+        path = os.path.join(ROOT, "profiles", "r04", "pmc_hbm_traffic_ekf.json")
+        if not os.path.exists(path):
+            path = os.path.join(ROOT, "profiles", "r03", "pmc_hbm_traffic_ekf.json")
+        with open(path) as fh:
             k = json.load(fh)["kernels"]
         total, found = 0.0, 0
         for prefix in ("stem_conv2a_kernel<false", "conv2b_conv3_kernel<false", "conv4_kernel", "fc_partial_f16x3_kernel", "fc_tail_kernel<false"):
@@ -122,7 +148,7 @@ def build_filter(wl, device, seed=0):
     import multimodalfilter_amd as mmf
 
     torch.manual_seed(seed)
-    f = mmf.model_types(wl["task"])[wl["cls"]]()
+    f = mmf.model_types(wl["task"])[wl["cls"]](**wl.get("ctor", {}))
     f.to(device).eval()
     return f
 
@@ -134,7 +160,8 @@ def to_device(traj, device):
 def make_inputs(wl, steps, batch, seed, device, state_dim):
     from multimodalfilter_amd import synthetic
 
-    traj = synthetic.make_trajectories(state_dim=state_dim, T=steps, N=batch, seed=seed)
+    traj = synthetic.make_trajectories(state_dim=state_dim, T=steps, N=batch, seed=seed,
+                                       image_blackout_ratio=wl.get("blackout", 0.0))
     return traj, to_device(traj, device)
 
 
@@ -154,6 +181,110 @@ def run_pf(f, traj_dev, noise_dev, M, mode="systematic", traj_offset=0):
     us = us if torch.is_tensor(us) else torch.stack(list(us))
     f.noise = mmf.StackedNoise(eps0, eps, us)
     return evaluation.run_filter(f, traj_dev)
+
+
+class FilterRun:
+    """ONE filter run over ``traj`` (``(T+1, N, ...)`` device tensors, index 0 = the initial time step) cut into
+    consecutive ``forward_loop`` segments that share the belief: ``start()`` initialises it the reference's way
+    (``states[0]``, ``0.1 I``: ``eval_helpers.py:125-131``) and rewinds the noise, ``steps(t0, t1)`` filters time
+    steps ``t0+1 .. t1``.  ``noise``: ``("philox", seed)`` -- counter-based, generated inside the dynamics kernel --
+    or the pre-drawn blocks ``(eps0 (N, M, d), eps (T, N, M, d), u (T, N))`` (consumed in place)."""
+
+    def __init__(self, f, traj, noise=None, *, particles=None, traj_offset=0):
+        self.f, self.traj, self.noise, self.M, self.traj_offset = f, traj, noise, particles, traj_offset
+        self.obs = {k: traj[k] for k in ("image", "gripper_pos", "gripper_sensors")}
+
+    def start(self):
+        import multimodalfilter_amd as mmf
+
+        f, states = self.f, self.traj["states"]
+        N, d = states.shape[1:]
+        if self.M is not None:
+            f.num_particles, f.resample_mode = self.M, "systematic"
+            f.noise = (mmf.CounterNoise(self.noise[1], traj_offset=self.traj_offset) if self.noise[0] == "philox"
+                       else mmf.StackedNoise(*self.noise))
+        cov = (torch.eye(d, device=states.device) * 0.1)[None].expand(N, d, d)
+        with torch.no_grad():
+            f.initialize_beliefs(mean=states[0], covariance=cov)
+        return self
+
+    def steps(self, t0, t1):
+        with torch.no_grad():
+            return self.f.forward_loop(observations={k: v[t0 + 1:t1 + 1] for k, v in self.obs.items()},
+                                       controls=self.traj["controls"][t0 + 1:t1 + 1])
+
+
+def device_noise(T, N, M, d, seed, device):
+    """Pre-drawn noise blocks generated ON the device (pre-roll / calibration runs no oracle has to replay)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    return (torch.randn((N, M, d), generator=g, device=device), torch.randn((T, N, M, d), generator=g, device=device),
+            torch.rand((T, N), generator=g, device=device))
+
+
+def ess_over_m(loglik):
+    """``(T, N, M)`` log-likelihoods of steps that start from uniform weights (every step of a resampling
+    filter) -> ``(T, N)`` effective sample size as a fraction of M."""
+    w = torch.softmax(loglik.double(), dim=-1)
+    return (1.0 / (w * w).sum(-1) / loglik.shape[-1]).float()
+
+
+def engine_ess(run, segments):
+    """The engine's OWN ESS/M on the steps of ``run``: the same segments again, the native loop keeping every
+    step's log-likelihoods (``record_indices``; bit-identical to the unrecorded run) -> ``(T, N)`` per segment."""
+    f = run.f
+    rec, f.record_indices = f.record_indices, True
+    out = []
+    try:
+        run.start()
+        for t0, t1 in segments:
+            run.steps(t0, t1)
+            out.append(ess_over_m(f.last_log_likelihoods).cpu())
+    finally:
+        f.record_indices = rec
+        f.last_log_likelihoods = f.last_resample_indices = f.last_log_weights_in = None
+    return out
+
+
+def ess_summary(ess, lo=0.05, hi=0.5):
+    """``(T, N)`` -> the figures the line carries: per-step batch means (min / max / mean over the steps) and the
+    share of single (step, trajectory) cells inside SURVEY.md 8d's band."""
+    per_step = ess.mean(1)
+    return {"band": [lo, hi], "per_step_batch_mean_min": float(per_step.min()), "per_step_batch_mean_max": float(per_step.max()),
+            "mean": float(ess.mean()), "steps_with_batch_mean_in_band": int(((per_step >= lo) & (per_step <= hi)).sum()),
+            "steps": int(ess.shape[0]), "cells_in_band_fraction": float(((ess >= lo) & (ess <= hi)).float().mean())}
+
+
+def calibrate_to_band(f, wl, device, d, M, *, target=0.25, accept=(0.18, 0.34), iters=8, batch=32, steps=16, seed=909):
+    """Scale the measurement heads until the TRACKING filter holds ESS/M ~ ``target`` (non-degenerate
+    weights, ESS/M in [0.05, 0.5]; flat log-likelihoods make resampling the identity and flatter a benchmark,
+    peaked ones leave a handful of survivors).  Round 3 calibrated once on the initial belief; the cloud then
+    contracted and the weights went flat (ESS/M 0.35 -> 0.9).  Here the filter ITSELF is run -- ``BURN_IN`` steps
+    from the initial belief, then ``steps`` more -- and the head scale is moved by the log-normal rule
+    ``ESS/M = exp(-var(loglik))`` on the steady-state mean until that mean is inside ``accept``; sharper heads
+    narrow the cloud, hence the iteration.  Returns the trace ``[(scale factor applied, steady-state ESS/M)]``."""
+    from multimodalfilter_amd import synthetic
+
+    T = BURN_IN + steps
+    traj = to_device(synthetic.make_trajectories(state_dim=d, T=T, N=batch, seed=seed,
+                                                 image_blackout_ratio=wl.get("blackout", 0.0)), device)
+    run = FilterRun(f, traj, device_noise(T, batch, M, d, seed + 1, device), particles=M)
+    meas = f.measurement_model
+    heads = [m.shared_layers[4] for m in getattr(meas, "measurement_models", [meas])]
+    trace = []
+    for _ in range(iters):
+        ess = engine_ess(run, [(0, BURN_IN), (BURN_IN, T)])[1]
+        cur = float(ess.mean())
+        if accept[0] <= cur <= accept[1]:
+            trace.append((1.0, cur))
+            break
+        factor = (np.log(1.0 / target) / max(np.log(1.0 / min(cur, 0.98)), 1e-3)) ** 0.5
+        factor = float(min(max(factor, 1.0 / 3.0), 3.0))
+        with torch.no_grad():
+            for h in heads:
+                h.weight.mul_(factor)
+                h.bias.mul_(factor)
+        trace.append((factor, cur))
+    return trace
 
 
 CPU_THREADS = 16  # measured on the GPU box's host (2 x EPYC 9575F, 256 hw threads): the oracle
@@ -205,7 +336,7 @@ def oracle_pf_run(cls, state_dict, traj, eps0, eps, us, M, *, mode="systematic",
     return torch.stack(ests), dt, beliefs
 
 
-def teacher_forced_parity(engine_filter, traj, eps, us, beliefs, want, M, *, mode="systematic"):
+def teacher_forced_parity(engine_filter, traj, eps, us, beliefs, want, M, *, mode="systematic", start=0):
     """Engine against oracle with the recursion's chaos taken out: before EVERY step the engine's
     belief is overwritten with the belief the oracle held at that point, then one engine step
     runs on the same noise.  What remains is kernel arithmetic: the posterior mean of that step
@@ -231,6 +362,8 @@ def teacher_forced_parity(engine_filter, traj, eps, us, beliefs, want, M, *, mod
     errs, flips = [], []
     cert = {"unexplained": 0, "k1_inexact_on_own_weights": 0, "max_slack_used": 0.0, "max_hop": 0, "max_D_over_Q": 0.0}
     for t, (S, W, idx, _, _, lw_o) in enumerate(beliefs):
+        if t < start:  # the oracle's burn-in: the weight regime of the timed steps starts behind it
+            continue
         f.particle_states = S.to(dev).contiguous()
         f.particle_log_weights = W.to(dev).contiguous()
         f._spare_states = None
@@ -249,10 +382,11 @@ def teacher_forced_parity(engine_filter, traj, eps, us, beliefs, want, M, *, mod
             for k in ("max_slack_used", "max_hop", "max_D_over_Q"):
                 cert[k] = max(cert[k], c[k])
     f.record_indices = rec
-    return {"max_rel_err_posterior_mean_per_step": errs,
+    return {"steps": f"{start + 1} .. {len(beliefs)} of the oracle's run (the first {start} are its burn-in)",
+            "max_rel_err_posterior_mean_per_step": errs,
             "max_rel_err_posterior_mean": max(errs),
             "resample_index_mismatches_per_step": flips,
-            "resample_index_mismatch_fraction": sum(flips) / float(len(beliefs) * N * M),
+            "resample_index_mismatch_fraction": sum(flips) / float(len(errs) * N * M),
             "mismatch_certificate": cert,
             "oracle_ess_over_m_per_step": [round(b[3], 4) for b in beliefs]}
 
@@ -359,17 +493,20 @@ def reference_sized_regimes(device):
     return out
 
 
-def cpu_baseline_pf(wl, engine_filter, state_dim, cores, sample_batch=32, sample_steps=24, warm=1):
+def cpu_baseline_pf(wl, engine_filter, state_dim, cores, sample_batch=32, sample_steps=24, warm=1, burn=8):
     """The oracle (pure torch, fp32, CPU) on a bounded sample of the same workload, with the
     engine run on the identical sample (same weights, observations, noise) for parity:
-    teacher-forced (kernel arithmetic, the 1e-4 bar) and free-running (both filters left alone
-    for the whole horizon; resampling flips at CDF boundaries decorrelate a few particles)."""
-    from multimodalfilter_amd import synthetic
+    teacher-forced (kernel arithmetic, the 1e-4 bar; over the steps behind the oracle's first ``burn`` steps, i.e.
+    in the weight regime of the timed steps) in BOTH arithmetic modes against the TORCH oracle, the exact-fp32 mode
+    against its bit-exact twin, and free-running (both filters left alone for the whole horizon; resampling flips
+    at CDF boundaries decorrelate a few particles)."""
+    from multimodalfilter_amd import engine, synthetic
 
     M = wl["particles"]
     T = sample_steps + warm
     torch.set_num_threads(cores)
-    traj = synthetic.make_trajectories(state_dim=state_dim, T=T, N=sample_batch, seed=4242)
+    traj = synthetic.make_trajectories(state_dim=state_dim, T=T, N=sample_batch, seed=4242,
+                                       image_blackout_ratio=wl.get("blackout", 0.0))
     eps0, eps, us = synthetic.draw_filter_noise(T=T, N=sample_batch, M=M, state_dim=state_dim, seed=4243)
     sd = {k: v.detach().cpu() for k, v in engine_filter.state_dict().items()}
     want, dt, beliefs = oracle_pf_run(wl["cls"], sd, traj, eps0, eps, us, M, warm=warm)
@@ -381,9 +518,18 @@ def cpu_baseline_pf(wl, engine_filter, state_dim, cores, sample_batch=32, sample
     scale = max(1.0, float(want.abs().max()))
     rm_e = ((got - traj["states"][1:]) ** 2).mean((0, 1)).sqrt()
     rm_o = ((want - traj["states"][1:]) ** 2).mean((0, 1)).sqrt()
+    tf = teacher_forced_parity(engine_filter, traj, eps, us, beliefs, want, M, start=burn)
+    old = engine.DEFAULT_PRECISION
+    try:  # the exact-fp32 mode against the TORCH oracle (the thing the golden vectors pin), not only against its twin
+        engine.set_default_precision("f32")
+        tf32 = teacher_forced_parity(engine_filter, traj, eps, us, beliefs, want, M, start=burn)
+    finally:
+        engine.set_default_precision(old)
+    tf32.pop("oracle_ess_over_m_per_step", None)
     parity = {
         "strict_f32_free_running": strict_parity(wl["cls"], engine_filter, traj, eps0, eps, us, M),
-        "teacher_forced": teacher_forced_parity(engine_filter, traj, eps, us, beliefs, want, M),
+        "teacher_forced": tf,
+        "teacher_forced_f32": tf32,
         "free_running": {
             # both filters run the whole horizon on their own beliefs: a 1e-7 difference in a
             # log-likelihood occasionally moves a resampling position across a CDF boundary,
@@ -560,8 +706,9 @@ def cpu_baseline_ekf(wl, engine_filter, state_dim, cores, sample_batch=256, samp
 
     T = sample_steps + warm
     torch.set_num_threads(cores)
-    traj = synthetic.make_trajectories(state_dim=state_dim, T=T, N=sample_batch, seed=4242)
-    oracle = om.build(wl["cls"])
+    traj = synthetic.make_trajectories(state_dim=state_dim, T=T, N=sample_batch, seed=4242,
+                                       image_blackout_ratio=wl.get("blackout", 0.0))
+    oracle = om.build(wl["cls"], **wl.get("ctor", {}))
     oracle.load_state_dict({k: v.detach().cpu() for k, v in engine_filter.state_dict().items()})
     oracle.eval()
     obs = synthetic.observations_of(traj)
@@ -634,7 +781,7 @@ def launch_ranks(n_ranks: int, argv) -> int:
 
 def dry_run(args):
     """``MMF_BENCH_DRY=1``: the N-rank plumbing without the GPU work (CPU test of the launcher):
-    rendezvous, the same all-gather / max-over-ranks the real run uses, one JSON line from rank 0."""
+    rendezvous, the same shard bounds / all-gather / max-over-ranks the real run uses, one JSON line from rank 0."""
     from multimodalfilter_amd import distributed
 
     rank, world, local = distributed.init_from_env()
@@ -642,13 +789,283 @@ def dry_run(args):
         raise SystemExit(3)
     rows = distributed.all_gather_rows(torch.full((rank + 1, 2), float(rank)))
     slowest = distributed.max_over_ranks(float(rank), torch.device("cpu"))
+    wl = dict(WORKLOADS[args.workload])
+    out = {"dry_run": True, "n_gpus": world, "world_size_seen": world, "gathered_rows": int(rows.shape[0]),
+           "max_over_ranks": slowest, "steps": args.steps, "warmup": args.warmup, "workload": args.workload}
+    if args.global_batch:  # strong scaling (BASELINE config 4): every rank's shard of the global batch
+        lo, hi = distributed.shard_bounds(args.global_batch, rank, world)
+        spans = distributed.all_gather_rows(torch.tensor([[float(rank), float(lo), float(hi)]]))
+        out["shards"] = [[int(r), int(a), int(b)] for r, a, b in spans.tolist()]
+        out["scaling"], out["global_batch"] = "strong", args.global_batch
+    else:
+        out["scaling"], out["global_batch"] = "weak", (args.batch or wl["batch"]) * world
     distributed.barrier()
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "world_size_seen": world,
-                          "gathered_rows": int(rows.shape[0]), "max_over_ranks": slowest,
-                          "steps": args.steps, "warmup": args.warmup}), flush=True)
+        print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------ `configs` legs
+def _leg_parity_pf(wl, f, d, M, device, n=4, steps=2):
+    """One parity number for a particle-filter leg: the engine against the oracle on ``n`` trajectories x ``M``
+    particles, same weights / observations / pre-drawn noise, ``steps`` free-running steps from the initial belief.
+    The FIRST step's posterior means are kernel arithmetic only (no resampling lies in front of them)."""
+    from multimodalfilter_amd import synthetic
+
+    torch.set_num_threads(min(CPU_THREADS, os.cpu_count() or 1))
+    traj = synthetic.make_trajectories(state_dim=d, T=steps, N=n, seed=31337, image_blackout_ratio=wl.get("blackout", 0.0))
+    if wl.get("blackout", 0.0) > 0:
+        traj["image"][1, 0] = 0.0  # at least one blacked-out frame in the checked step
+    eps0, eps, us = synthetic.draw_filter_noise(T=steps, N=n, M=M, state_dim=d, seed=31338)
+    sd = {k: v.detach().cpu() for k, v in f.state_dict().items()}
+    want, _, _ = oracle_pf_run(wl["cls"], sd, traj, eps0, eps, us, M, keep_beliefs=False)
+    got = run_pf(f, to_device(traj, device), (eps0.to(device), [e.to(device) for e in eps], [u.to(device) for u in us]), M).cpu()
+    scale = max(1.0, float(want.abs().max()))
+    return {"max_rel_err_posterior_mean_step1_vs_oracle": float((got[0] - want[0]).abs().max()) / scale,
+            "sample": f"{n} trajectories x {M} particles, same weights / inputs / noise; CPU oracle"}
+
+
+def leg_pf(name, wl, *, K, W, device, share_state=None, seed=7000):
+    """A particle-filter configuration as one bounded leg: burn-in + W warm-up + K timed steps of one tracking filter
+    (counter-based process noise: no ``(T, N, M, d)`` tensor has to be drawn on the host), run twice -- the first run
+    pays the one-time host costs of its shapes -- and timed on the second."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine, evaluation, synthetic
+
+    t_leg = time.perf_counter()
+    spec = mmf.door_models._ns.task if wl["task"] == "door" else mmf.push_models._ns.task
+    d, B, M = spec.state_dim, wl["batch"], wl["particles"]
+    f = build_filter(wl, device)
+    synthetic.stabilise_dynamics(f)
+    f.num_particles = M
+    cal = None
+    if share_state is not None:
+        f.load_state_dict(share_state)  # the headline filter's calibrated weights (same architecture)
+    else:
+        cal = calibrate_to_band(f, wl, device, d, M)
+    T = BURN_IN + W + K
+    _, traj = make_inputs(wl, T, B, seed, device, d)
+    run = FilterRun(f, traj, ("philox", seed + 1), particles=M)
+    f.reserve(steps=K, batch=B, particles=M)
+    segs = [(0, BURN_IN), (BURN_IN, BURN_IN + W), (BURN_IN + W, T)]
+
+    def once(timer):
+        run.start()
+        run.steps(*segs[0])
+        if W > 0:
+            run.steps(*segs[1])
+        engine.set_kernel_timer(timer)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pred = run.steps(*segs[2])
+        mse = evaluation.per_trajectory_mse(pred, traj["states"][segs[2][0] + 1:T + 1], start=0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        engine.set_kernel_timer(None)
+        return dt, mse
+
+    once(None)
+    timer = engine.KernelTimer(loop_stride=K if K < 64 else (K + 2) // 3)
+    dt, mse = once(timer)
+    out = {"workload": workload_desc(wl, B, M, B, 1, "weak"), "filter": wl["cls"], "steps": K, "warmup": W, "burn_in": BURN_IN,
+           "value": B * M * K / dt, "unit": "particle-steps/s", "ms_per_step": 1e3 * dt / K, "process_noise": "philox",
+           "posterior_rmse_vs_truth": [float(x) for x in evaluation.raw_rmse(mse)]}
+    ks = timer.summary()
+    dom = ks.get("particle_net_measure")
+    if dom:
+        ach = dom["flops_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e12
+        prec = engine.DEFAULT_PRECISION
+        out["roofline"] = {"kernel": "particle_net_kernel (measurement network)", "bound": "mfma", "achieved": ach,
+                           "peak": MFMA_PEAK[prec], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK[prec], "avg_us": 1e3 * dom["avg_ms"]}
+    k1 = ks.get("pf_reweight_resample")
+    if k1:
+        gbs = k1["bytes_per_launch"] / (k1["avg_ms"] * 1e-3) / 1e9
+        out["roofline_k1"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                              "avg_us": 1e3 * k1["avg_ms"]}
+    # the engine's own weights on the timed steps of (up to) its first 32 trajectories: counter-based noise keeps
+    # a trajectory's draws the same whatever batch it sits in
+    nb = min(B, 32)
+    sub = FilterRun(f, {k: v[:, :nb].contiguous() for k, v in traj.items()}, ("philox", seed + 1), particles=M)
+    out["ess_over_m"] = ess_summary(engine_ess(sub, segs)[2])
+    if cal is not None:
+        out["head_calibration_trace"] = [[round(a, 3), round(b, 4)] for a, b in cal]
+    out["parity"] = _leg_parity_pf(wl, f, d, M, device)
+    out["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
+    del run, sub, traj
+    return out, f
+
+
+def leg_ekf(name, wl, *, K, W, device, seed=7100, cpu_batch=64, cpu_steps=4, plain_ms=None):
+    """An EKF configuration as one bounded leg (config 4's per-GPU share; its blackout twin): W warm-up + K timed
+    steps of one filter run, image encoders inside the timed region, with the K4 launch sequence's roofline and a
+    bounded CPU-oracle sample for the baseline and the parity number."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine, evaluation, synthetic
+
+    t_leg = time.perf_counter()
+    d, B = 3, wl["batch"]
+    f = build_filter(wl, device)
+    synthetic.stabilise_dynamics(f)
+    T = W + K
+    _, traj = make_inputs(wl, T, B, seed, device, d)
+    run = FilterRun(f, traj)
+
+    def once(timer):
+        run.start()
+        if W > 0:
+            run.steps(0, W)
+        engine.set_kernel_timer(timer)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pred = run.steps(W, T)
+        mse = evaluation.per_trajectory_mse(pred, traj["states"][W + 1:T + 1], start=0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        engine.set_kernel_timer(None)
+        return dt, mse
+
+    once(None)
+    timer = engine.KernelTimer()
+    dt, mse = once(timer)
+    out = {"workload": workload_desc(wl, B, 1, B, 1, "weak"), "filter": wl["cls"], "steps": K, "warmup": W,
+           "value": B * K / dt, "unit": "trajectory-steps/s", "ms_per_step": 1e3 * dt / K,
+           "posterior_rmse_vs_truth": [float(x) for x in evaluation.raw_rmse(mse)]}
+    if wl.get("blackout", 0.0) > 0:
+        dark = (traj["image"][W + 1:T + 1].abs().sum((-1, -2)) < 1e-8)
+        out["blacked_out_frames_fraction"] = float(dark.float().mean())
+        out["native_loop"] = "mmf_ekf_forward_loop; the batch-global branch of door_models/crossmodal_kf.py:59-62 is a per-step device flag"
+        if plain_ms:
+            out["ms_per_step_over_plain_ekf"] = out["ms_per_step"] / plain_ms
+    dom = timer.summary().get("image_encoder")
+    if dom:
+        ach = dom["flops_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "image encoder launch sequence (K4) per chunk of images", "bound": "mfma", "achieved": ach,
+                           "peak": MFMA_PEAK["f16x3"], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK["f16x3"], "avg_us": 1e3 * dom["avg_ms"]}
+    cores = min(CPU_THREADS, os.cpu_count() or 1)
+    base, parity = cpu_baseline_ekf(wl, f, d, cores, sample_batch=cpu_batch, sample_steps=cpu_steps)
+    out["cpu_baseline"] = base
+    out["parity"] = {"max_rel_err_posterior_mean_vs_oracle": parity["max_rel_err_posterior_mean"],
+                     "sample": f"{cpu_batch} trajectories x {cpu_steps + 1} steps, same weights / inputs; CPU oracle"}
+    out["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
+    del run, traj
+    return out
+
+
+def leg_train(device, *, iters=4):
+    """BASELINE config 5's per-GPU shape: push unimodal particle filter, 8192 particles, batch 32 (N x M = 2^18),
+    subsequences of 16 steps, train mode (no resampling), bf16 image-encoder forward, forward + backward + SGD
+    through the native K6 recursion (``mmf_pf_train_forward`` / ``_backward``).  Parity: the loss and the gradients of
+    a 4 x 30 x 3 twin of the same step against the CPU oracle's autograd."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine, synthetic, train
+    from oracle import models as om
+    from oracle.tf.base import ReplayNoise as OReplay
+
+    t_leg = time.perf_counter()
+    d, N, M, L = 2, 32, 8192, 16
+    out = {"workload": f"push unimodal particle filter, train mode, {N} x {M} particles x {L}-step subsequences, forward + backward + SGD",
+           "filter": "PushUnimodalParticleFilter", "unit": "particle-steps/s (forward + backward)"}
+    engine.set_training_backend("hip")
+    engine.set_image_encoder_precision("bf16")
+    try:
+        torch.manual_seed(0)
+        f = mmf.push_models.PushUnimodalParticleFilter().to(device).train()
+        f.num_particles = M
+        batch = to_device(synthetic.make_trajectories(state_dim=d, T=L - 1, N=N, seed=11), device)
+        cov = torch.eye(d, device=device) * 0.1
+        opt = torch.optim.SGD(f.parameters(), lr=1e-4)
+        f.noise = mmf.NoiseSource(seed=5)
+        times = []
+        torch.cuda.reset_peak_memory_stats()
+        for _ in range(iters + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            train.train_filter_step(f, batch, opt, initial_covariance=cov, noise=f.noise)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        best = min(times[1:])
+        out.update({"ms_per_step": 1e3 * best, "value": N * M * (L - 1) / best, "peak_memory_GB": torch.cuda.max_memory_allocated() / 2 ** 30,
+                    "image_encoder_forward": "bf16 (BASELINE config 5)", "backend": "hip (K6)"})
+        del f, opt, batch
+        # parity twin (exact-fp32 image encoders: the oracle's arithmetic)
+        engine.set_image_encoder_precision(None)
+        n, m, T = 4, 30, 3
+        torch.manual_seed(1)
+        ft = mmf.push_models.PushUnimodalParticleFilter().to(device).train()
+        ft.num_particles = m
+        tw = synthetic.make_trajectories(state_dim=d, T=T, N=n, seed=12)
+        g = torch.Generator().manual_seed(13)
+        eps0 = torch.randn((n, m, d), generator=g)
+        eps = [torch.randn((n, m, d), generator=g) for _ in range(T)]
+        o = om.build("PushUnimodalParticleFilter")
+        o.load_state_dict({k: v.detach().cpu() for k, v in ft.state_dict().items()})
+        o.train()
+        o.num_particles = m
+        covc = (torch.eye(d) * 0.1)[None].expand(n, d, d)
+        obs = synthetic.observations_of(tw)
+
+        def loss_of(filt, dev):
+            mv = lambda t: t.to(dev)
+            filt.initialize_beliefs(mean=mv(tw["states"][0]), covariance=mv(covc))
+            pred = filt.forward_loop(observations={k: mv(v[1:]) for k, v in obs.items()}, controls=mv(tw["controls"][1:]))
+            return torch.mean((pred - mv(tw["states"][1:])) ** 2)
+
+        o.noise = OReplay([eps0] + eps, [])
+        lo = loss_of(o, "cpu")
+        lo.backward()
+        ft.noise = mmf.ReplayNoise([eps0.to(device)] + [e.to(device) for e in eps], [])
+        le = loss_of(ft, device)
+        le.backward()
+        worst = 0.0
+        po = dict(o.named_parameters())
+        for k, p in ft.named_parameters():
+            if p.grad is None or po[k].grad is None:
+                continue
+            worst = max(worst, float((p.grad.cpu() - po[k].grad).abs().max() / po[k].grad.abs().max().clamp_min(1e-12)))
+        out["parity"] = {"loss_rel_diff_vs_oracle": abs(float(le) - float(lo)) / max(abs(float(lo)), 1e-12),
+                         "max_grad_diff_over_tensor_max_vs_oracle": worst,
+                         "sample": f"{n} x {m} particles x {T} steps twin of the step, same weights / inputs / noise; CPU oracle autograd"}
+        del ft, o
+    finally:
+        engine.set_training_backend(None)
+        engine.set_image_encoder_precision(None)
+    out["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
+    torch.cuda.empty_cache()
+    return out
+
+
+def run_configs(args, device, headline_filter, d, K, W):
+    """BASELINE.json's other configurations and the blackout workloads, each a bounded leg (one GPU)."""
+    legs = {}
+    Kl = min(K, 32)  # legs are bounded: at most 32 timed steps each
+
+    def guarded(name, fn):
+        t0 = time.perf_counter()
+        try:
+            legs[name] = fn()
+        except Exception as e:  # a failing leg must not take the headline line with it
+            import traceback
+            legs[name] = {"error": f"{type(e).__name__}: {e}", "where": traceback.format_exc().splitlines()[-3:]}
+        torch.cuda.empty_cache()
+        return time.perf_counter() - t0
+
+    share = None
+    if args.workload == "door_pf":
+        share = {k: v.detach().clone() for k, v in headline_filter.state_dict().items()}
+    c2 = dict(WORKLOADS["door_pf"], batch=256, particles=1024)
+    guarded("C2_door_crossmodal_pf_256x1024", lambda: leg_pf("C2", c2, K=Kl, W=W, device=device, share_state=share)[0])
+    c3 = dict(WORKLOADS["push_pf"], batch=1024, particles=4096)
+    guarded("C3_push_crossmodal_pf_1024x4096", lambda: leg_pf("C3", c3, K=min(Kl, 16), W=min(W, 4), device=device)[0])
+    c4 = dict(WORKLOADS["door_ekf"], batch=1024)
+    guarded("C4_door_crossmodal_ekf_1024_per_gpu_share_of_8192", lambda: leg_ekf("C4", c4, K=Kl, W=W, device=device))
+    guarded("C5_push_unimodal_pf_train_32x8192x16", lambda: leg_train(device))
+    bp = dict(WORKLOADS["door_pf_blackout"])
+    guarded("blackout_0.4_door_crossmodal_pf_256x4096", lambda: leg_pf("blackout_pf", bp, K=Kl, W=W, device=device, share_state=share)[0])
+    plain = legs.get("C4_door_crossmodal_ekf_1024_per_gpu_share_of_8192", {}).get("ms_per_step")
+    be = dict(WORKLOADS["door_ekf_blackout"])
+    guarded("blackout_0.4_door_crossmodal_ekf_1024", lambda: leg_ekf("blackout_ekf", be, K=Kl, W=W, device=device, plain_ms=plain))
+    return legs
 
 
 def main():
@@ -672,8 +1089,12 @@ def main():
                          "counter-based, generated inside the dynamics kernel")
     ap.add_argument("--no-reference-sizes", action="store_true",
                     help="skip the two extra lines at the sizes the reference itself runs (32 x 300 eval, 32 x 30 x 16 training)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` legs (BASELINE.json's other configurations, the blackout workloads)")
+    ap.add_argument("--no-calibration", action="store_true",
+                    help="keep the randomly initialised measurement heads (flat weights; A/B only)")
     ap.add_argument("--preroll-seconds", type=float, default=0.5,
-                    help="untimed repetitions of the warm-up pass before the W warm-up steps (GPU clock ramp)")
+                    help="untimed repetitions of the whole sequence on OTHER inputs of the same shapes before the run that is timed (GPU clock ramp)")
     ap.add_argument("--global-batch", type=int, default=None,
                     help="STRONG scaling: this many trajectories in total, sharded over the ranks "
                          "(BASELINE config 4: --workload door_ekf --global-batch 8192)")
@@ -700,6 +1121,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the hot path")
+    t_start = time.perf_counter()
     rank, world, local = distributed.init_from_env()
     local_dev = local % torch.cuda.device_count()
     torch.cuda.set_device(local_dev)
@@ -717,147 +1139,103 @@ def main():
     K, W, B, M = args.steps, args.warmup, wl["batch"], wl["particles"]
     spec = mmf.door_models._ns.task if wl["task"] == "door" else mmf.push_models._ns.task
     d = spec.state_dim
+    pf = wl["kind"] == "pf"
+    burn = BURN_IN if pf else 0
+    T_all = burn + W + K
+    segs = [(0, burn), (burn, burn + W), (burn + W, T_all)]
+    # the evaluation statistic skips the first 30 steps of a sequence (eval_helpers.py:149-157)
+    mse_start = min(max(0, 30 - (burn + W)), K // 2)
 
     f = build_filter(wl, device)
     # untrained dynamics are expanding maps; keep any --steps the driver asks for finite
     # (same arithmetic per step; see synthetic.stabilise_dynamics)
     synthetic.stabilise_dynamics(f)
-    # rank-private trajectories (weak scaling): seed 20201025 + config id + rank
-    traj_w_cpu, traj_w = make_inputs(wl, max(W, 1), B, 20201025 + 1000 * rank + 1, device, d)  # unused when W == 0
-    traj_cpu, traj = make_inputs(wl, K, B, 20201025 + 1000 * rank + 2, device, d)
-
-    if wl["kind"] == "pf":
+    calibration = None
+    if pf:
         f.num_particles = M
-        # non-degenerate weights (ESS/M ~ 0.25): flat log-likelihoods would make resampling trivial
-        cal_states = traj["states"][0][:, None, :] + 0.3 * torch.randn((B, 256, d), device=device)
-        synthetic.calibrate_measurement_heads(
-            f, {k: traj[k][0] for k in ("image", "gripper_pos", "gripper_sensors")}, cal_states)
+        if not args.no_calibration:
+            # same weights on every rank: the calibration trajectory and noise do not depend on the rank
+            calibration = calibrate_to_band(f, wl, device, d, M)
+    # rank-private trajectories (weak scaling): seed 20201025 + config id + rank.  `traj` is the run that is timed,
+    # `traj_r` a second one of the same shapes for the pre-roll (never the timed inputs themselves)
+    traj_cpu, traj = make_inputs(wl, T_all, B, 20201025 + 1000 * rank + 2, device, d)
+    _, traj_r = make_inputs(wl, T_all, B, 20201025 + 1000 * rank + 1, device, d)
+    if pf:
         if args.noise == "philox":
             # counter-based noise generated inside the dynamics kernel (include/mmf_philox.h): no (T, N, M, d)
             # tensor exists; trajectories keep their global index, so any sharding draws the same numbers
-            noise_w, noise = ("philox", 77), ("philox", 78)
+            noise, noise_r = ("philox", 78), ("philox", 77)
         else:
-            noise_w = synthetic.draw_filter_noise(T=max(W, 1), N=B, M=M, state_dim=d, seed=77 + rank)
-            noise = synthetic.draw_filter_noise(T=K, N=B, M=M, state_dim=d, seed=78 + rank)
-            mv = lambda nz: (nz[0].to(device), torch.stack(nz[1]).to(device), torch.stack(nz[2]).to(device))
-            noise_w, noise = mv(noise_w), mv(noise)
+            nz = synthetic.draw_filter_noise(T=T_all, N=B, M=M, state_dim=d, seed=78 + rank)
+            noise = (nz[0].to(device), torch.stack(nz[1]).to(device), torch.stack(nz[2]).to(device))
+            noise_r = device_noise(T_all, B, M, d, 77 + rank, device)
         f.reserve(steps=K, batch=B, particles=M)  # memory planned before the warm-up
-        run = lambda tr, nz: run_pf(f, tr, nz, M, traj_offset=rank * B)
+        run = FilterRun(f, traj, noise, particles=M, traj_offset=rank * B)
+        run_r = FilterRun(f, traj_r, noise_r, particles=M, traj_offset=rank * B)
     else:
-        noise_w = noise = None
-        run = lambda tr, nz: evaluation.run_filter(f, tr)
+        run, run_r = FilterRun(f, traj), FilterRun(f, traj_r)
 
     def timed_pass():
-        """(pre-roll + one untimed rehearsal,) W untimed warm-up steps, then exactly K timed steps; returns
-        (seconds, timer, mse, prediction)."""
-        # Round 3, measured (profiles/r03/bench_pass_timecourse.txt, MMF_BENCH_TIMECOURSE): only the FIRST K-step
-        # pass of a process is slow -- 0.70 ms per step at the driver's flags against 0.645-0.66 for every later
-        # one, whatever lies in between (idle 1 / 5 / 10 s, 5 s of load, the f32 pass) and whatever the pre-roll
-        # (0 - 6 s); its kernels are not slower.  The ~1 ms is one-time host work inside the timed region: the code
-        # objects of the torch kernels the K-step statistic selects (the W-step warm-up has other shapes), the
-        # allocator's first blocks of those sizes, the first event records of the kernel timer.  So the pre-roll
-        # ends with ONE untimed rehearsal of exactly the timed sequence; the W warm-up steps the contract asks
-        # for follow it, then the K timed steps.
+        """Pre-roll on OTHER inputs, then ONE filter run: (burn-in,) W untimed warm-up steps, then exactly K timed
+        steps; returns (seconds, timer, mse, prediction)."""
+        # Round 3, measured (profiles/r03/bench_pass_timecourse.txt): after an idle stretch the chip takes ~30 ms of
+        # load to get back to its clocks, and only the FIRST pass of a process over a new loop length pays one-time
+        # host work (code objects of the torch kernels of the K-step statistic, the allocator's first blocks of those
+        # sizes, the first event records).  Round 4: the pre-roll repeats the whole sequence -- burn-in, warm-up, a
+        # K-step loop with its statistic -- on a SECOND trajectory / noise set of the same shapes (round 3 rehearsed
+        # the timed inputs themselves, which also left them in the Infinity Cache); the run that is timed follows
+        # back to back, and the GPU only idles at the synchronisation points the contract prescribes.
         def make_timer():  # its event pool costs ~10 ms of an idle GPU
             return None if args.no_kernel_timers else engine.KernelTimer(loop_stride=K if K < 64 else (K + 2) // 3)  # 3 sampled steps (1 for short passes)
 
-        def warm_up():  # the W warm-up steps cover the whole path, including the evaluation statistic
-            if W > 0:
-                pred_w = run(traj_w, noise_w)
-                distributed.all_gather_rows(
-                    evaluation.per_trajectory_mse(pred_w, traj_w["states"][1:], start=min(30, W // 2)))
-
-        def measure(sync_clock, timer):
+        def sequence(r, tr, timer, sync_clock):
+            r.start()
+            if burn:
+                r.steps(*segs[0])
+            if W > 0:  # the W warm-up steps cover the whole path, including the evaluation statistic
+                pred_w = r.steps(*segs[1])
+                distributed.all_gather_rows(evaluation.per_trajectory_mse(pred_w, tr["states"][segs[1][0] + 1:segs[1][1] + 1], start=0))
             engine.set_kernel_timer(timer)
-            distributed.barrier()
-            torch.cuda.synchronize()
+            if sync_clock:
+                distributed.barrier()
+                torch.cuda.synchronize()
             t0 = time.perf_counter()
-            pred = run(traj, noise)
-            mse_local = evaluation.per_trajectory_mse(pred, traj["states"][1:], start=min(30, K // 2))
+            pred = r.steps(*segs[2])
+            mse_local = evaluation.per_trajectory_mse(pred, tr["states"][segs[2][0] + 1:T_all + 1], start=mse_start)
             mse_all = distributed.all_gather_rows(mse_local)  # RCCL all-gather of per-sequence errors
-            torch.cuda.synchronize()
-            distributed.barrier()
+            if sync_clock:
+                torch.cuda.synchronize()
+                distributed.barrier()
             dt = time.perf_counter() - t0
             engine.set_kernel_timer(None)
             return (distributed.max_over_ranks(dt, device) if sync_clock else dt), timer, mse_all, pred
 
-        # both timers (event pools) first: from the pre-roll to the timed steps the GPU then only idles at the
-        # synchronisation points -- after an idle stretch the chip's clocks take ~30 ms of load to come back
-        # (measured per step inside one pass, bench_pass_timecourse.txt: dynamics kernel 205-230 us on the first
-        # steps after a synchronisation, 184 from step ~40 on; no such ramp between back-to-back passes)
         rehearsal_timer, timer = make_timer(), make_timer()
-        if W > 0 and args.preroll_seconds > 0:
+        if args.preroll_seconds > 0:
             t_pre = time.perf_counter()
-            while time.perf_counter() - t_pre < args.preroll_seconds:
-                run(traj, noise)  # back to back, no synchronisation: the GPU stays loaded while the host enqueues
-            warm_up()                        # the rehearsal: the W-step warm-up and the timed sequence, untimed
-            measure(False, rehearsal_timer)
-        torch.cuda.synchronize()
-        warm_up()
-        torch.cuda.synchronize()
-        return measure(True, timer)
+            first = True
+            while first or time.perf_counter() - t_pre < args.preroll_seconds:
+                sequence(run_r, traj_r, rehearsal_timer if first else None, False)  # back to back, no synchronisation
+                first = False
+        return sequence(run, traj, timer, True)
 
-    if os.environ.get("MMF_BENCH_TIMECOURSE"):
-        # debug: the same K-step pass over and over, with idles / an f32 pass in between -- what the pass's speed
-        # depends on (scripts/profile_round.sh does not run this)
-        t_proc = time.perf_counter()
-        plan = os.environ["MMF_BENCH_TIMECOURSE"].split(",")  # "p" pass, "s<sec>" sleep, "f" f32 pass, "b<sec>" busy
-        for step in plan:
-            if step[0] == "s":
-                torch.cuda.synchronize()
-                time.sleep(float(step[1:]))
-                continue
-            if step[0] == "b":
-                t_b = time.perf_counter()
-                while time.perf_counter() - t_b < float(step[1:]):
-                    run(traj, noise)
-                torch.cuda.synchronize()
-                continue
-            if step[0] == "f":
-                engine.set_default_precision("f32")
-            dt, timer, _, _ = timed_pass()
-            engine.set_default_precision(precision)
-            ks = timer.summary() if timer else {}
-            print(json.dumps({"t": round(time.perf_counter() - t_proc, 2), "what": step, "ms_per_step": 1e3 * dt / K,
-                              "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in ks.items()}}), flush=True)
-        if os.environ.get("MMF_BENCH_TIMECOURSE_STEPS") and wl["kind"] == "pf":
-            # every step's dynamics / first-measurement kernel duration inside ONE pass (events on every step: slower)
-            timer = engine.KernelTimer(prealloc=(8 * K + 64) * int(os.environ["MMF_BENCH_TIMECOURSE_STEPS"]), loop_stride=1)
-            reps = int(os.environ["MMF_BENCH_TIMECOURSE_STEPS"])
-            for _ in range(3):  # load first: what is measured is the idle stretch that follows it
-                run(traj, noise)
-            torch.cuda.synchronize()
-            time.sleep(float(os.environ.get("MMF_BENCH_TIMECOURSE_IDLE_MS", "0")) * 1e-3)
-            engine.set_kernel_timer(timer)
-            for _ in range(reps):  # back to back, no synchronisation in between
-                run(traj, noise)
-            torch.cuda.synchronize()
-            engine.set_kernel_timer(None)
-            for name in ("particle_net_dynamics", "image_encoder"):
-                ms = [s_.elapsed_time(e_) for s_, e_, _, _ in timer.records[name]]
-                print(json.dumps({"per_step_us": name, "passes": reps, "values": [round(1e3 * v, 1) for v in ms]}), flush=True)
-        return
     # Order of the GPU work (one GPU): the headline pass, the comparison pass in exact-f32 mode, the error study
-    # against fp64, one second of idle, and the headline pass AGAIN -- each pass does its own pre-roll and W
-    # warm-up steps and times exactly K.  `value` is the LAST pass; the first is reported beside it as
-    # `pass_order`.  Measured in round 3 at the driver's flags (20 steps): the pass that opens the process runs
-    # its kernels 10-15 % slower (dynamics 203 vs 181 us) whatever the pre-roll (0, 1, 3, 6 s: 0.70, 0.70, 0.69,
-    # 0.69 ms per step), the same pass after the f32 pass and the study 0.61-0.67; at 128 steps the two orders
-    # agree (0.6055 / 0.6054).  Round 2 ran the headline right behind the f32 pass without the idle second
-    # (0.683).  With more than one rank the extras are skipped and the single pass is the value.
+    # against fp64, one second of idle, and the headline pass AGAIN -- each pass does its own pre-roll, burn-in and W
+    # warm-up steps and times exactly K.  `value` is the LAST pass; the first is reported beside it as `pass_order`.
+    # With more than one rank the extras are skipped and the single pass is the value.
     lean = world > 1
     first = None
-    if not lean and (wl["kind"] == "pf" or not args.no_precision_study):
+    if not lean and (pf or not args.no_precision_study):
         first = timed_pass()[0]
     f32_pass = None
-    if wl["kind"] == "pf" and precision != "f32" and not args.no_f32_mode and not lean:
+    if pf and precision != "f32" and not args.no_f32_mode and not lean:
         engine.set_default_precision("f32")
         f32_pass = timed_pass()
         engine.set_default_precision(precision)
     # arithmetic error of each mode against fp64, at the benchmark's size (rank 0, no collective)
     study = None
     if rank == 0 and not args.no_precision_study and not lean:
-        if wl["kind"] == "pf":
+        if pf:
             study = precision_errors(wl, f, traj, B, M, raw_dynamics=build_filter(wl, device).dynamics_model)
         else:
             study = image_encoder_precision_errors(wl, f, traj)
@@ -871,21 +1249,21 @@ def main():
     elapsed, timer, mse_all, pred_main = timed_pass()
 
     total_batch = args.global_batch if args.global_batch else B * world
-    units_per_step = total_batch * M if wl["kind"] == "pf" else total_batch
+    units_per_step = total_batch * M if pf else total_batch
     value = units_per_step * K / elapsed
     rmse = evaluation.raw_rmse(mse_all)
 
     if rank != 0:
         return
     out = {
-        "metric": "filter steps/sec (batch x particles)" if wl["kind"] == "pf" else "filter steps/sec (trajectories)",
+        "metric": "filter steps/sec (batch x particles)" if pf else "filter steps/sec (trajectories)",
         "value": value,
-        "unit": "particle-steps/s" if wl["kind"] == "pf" else "trajectory-steps/s",
+        "unit": "particle-steps/s" if pf else "trajectory-steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32" if precision == "f32" else
                  ("f32 via f16x3 (operands split into 2 f16 halves exact to 2^-22, 3 f16 MFMA products "
-                  "per product, f32 accumulate)" if wl["kind"] == "pf" else
+                  "per product, f32 accumulate)" if pf else
                   "f32; image encoders and dynamics Jacobians f32 via f16x3 (operands split into 2 f16 halves exact to "
                   "2^-22, 3 f16 MFMA products per product, f32 accumulate)"),
         "data": "synthetic",
@@ -895,14 +1273,19 @@ def main():
                    "world_size_seen": world,
                    "parallelism": f"trajectory-sharded x{world}"},
         "posterior_rmse_vs_truth": [float(x) for x in rmse],
-        "preroll_seconds": args.preroll_seconds, "process_noise": args.noise if wl["kind"] == "pf" else None,
+        "sequence": {"burn_in_steps": burn, "warmup_steps": W, "timed_steps": K,
+                     "note": "ONE filter run per pass: belief initialised at states[0] / 0.1 I (eval_helpers.py:125-131), burn-in, "
+                             "W warm-up steps, then exactly K timed steps, the belief carried across the forward_loop calls"},
+        "preroll_seconds": args.preroll_seconds, "process_noise": args.noise if pf else None,
         "pass_order": None if first is None else {
             "headline_opening_the_process_ms_per_step": 1e3 * first / K,
             "headline_after_f32_pass_fp64_study_and_1s_idle_ms_per_step": 1e3 * elapsed / K,
-            "note": "value / ms_per_step are the LAST pass (pre-roll, W warm-up steps, then exactly K timed)"},
-        "traffic_source": "profiles/r03 (r02 where a kernel was not re-profiled): pmc_hbm_traffic*.json, pmc_k4_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+            "note": "value / ms_per_step are the LAST pass (pre-roll on other inputs, burn-in, W warm-up steps, then exactly K timed)"},
+        "traffic_source": "profiles/r04 (r03 / r02 where a kernel was not re-profiled): pmc_hbm_traffic*.json, pmc_k4_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                           "separate passes; bytes per launch = 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction)",
     }
+    if calibration is not None:
+        out["head_calibration_trace"] = [[round(a, 3), round(b, 4)] for a, b in calibration]
 
     def k2_roofline(ks, prec):
         dom = ks["particle_net_measure"]
@@ -922,7 +1305,7 @@ def main():
         ks = timer.summary()
         out["kernels"] = {k: {kk: (round(vv, 6) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                           for k, v in ks.items()}
-        if wl["kind"] == "pf" and "particle_net_measure" in ks:
+        if pf and "particle_net_measure" in ks:
             default_shape = (args.workload == "door_pf" and B == 256 and M == 4096)
             out["roofline"] = k2_roofline(ks, precision)
             k1 = ks.get("pf_reweight_resample")
@@ -932,7 +1315,7 @@ def main():
                                       "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": gbs / HBM_PEAK_GBS,
                                       "traffic": pmc_traffic("pf_resample_systematic_kernel") if default_shape else None}
-        if wl["kind"] != "pf" and "image_encoder" in ks:
+        if not pf and "image_encoder" in ks:
             # EKF steps are > 99 % image-encoder MACs: the K4 launch sequence
             # (stem + four 3x3 convolutions + linear tail) is the dominant "kernel"
             dom = ks["image_encoder"]
@@ -948,6 +1331,22 @@ def main():
     if "roofline" not in out:
         out["roofline"] = None
 
+    if pf:
+        # the ENGINE's own weights over the timed steps: the same run again, every step's log-likelihoods kept
+        # (bit-identical: same kernels, same inputs), on the first 64 trajectories' worth of memory at a time
+        nb = min(B, 64)
+        if args.noise == "philox":
+            sub_noise = noise
+        else:
+            sub_noise = (noise[0][:nb].contiguous(), noise[1][:, :nb].contiguous(), noise[2][:, :nb].contiguous())
+        sub = FilterRun(f, {k: v[:, :nb].contiguous() for k, v in traj.items()}, sub_noise, particles=M, traj_offset=rank * B)
+        ess = engine_ess(sub, segs)
+        out["ess_over_m"] = dict(ess_summary(ess[2]), trajectories=nb,
+                                 per_step_batch_mean=[round(float(x), 4) for x in ess[2].mean(1)][:160],
+                                 burn_in_per_step_batch_mean=[round(float(x), 4) for x in ess[0].mean(1)],
+                                 note="engine's own normalised weights on the timed steps (SURVEY.md 8d asks for ESS/M in [0.05, 0.5])")
+        del sub
+
     if f32_pass is not None:
         e32, t32, mse32, pred32 = f32_pass
         out["f32_mode"] = {"value": units_per_step * K / e32, "unit": out["unit"],
@@ -955,18 +1354,17 @@ def main():
                            "posterior_rmse_vs_truth": [float(x) for x in evaluation.raw_rmse(mse32)]}
         if t32 is not None:
             out["f32_mode"]["roofline"] = k2_roofline(t32.summary(), "f32")
-        # the two modes over the same K free-running steps (same inputs, same noise): posterior
+        # the two modes over the same free-running steps (same inputs, same noise): posterior
         # RMSE of each against the truth, and how far single estimates drift apart
-        start = min(30, K // 2)
         r16, r32 = rmse, evaluation.raw_rmse(mse32)
         out["mode_drift"] = {
             "steps": K, "rmse_f16x3": [float(x) for x in r16], "rmse_f32": [float(x) for x in r32],
             "rmse_rel_diff": float(max(abs(a - b) / b for a, b in zip(r16, r32))),
-            "max_abs_diff_posterior_mean_step1": float((pred_main[0] - pred32[0]).abs().max()),
+            "max_abs_diff_posterior_mean_first_timed_step": float((pred_main[0] - pred32[0]).abs().max()),
             "max_abs_diff_posterior_mean_all_steps": float((pred_main - pred32).abs().max()),
         }
 
-    if wl["kind"] == "pf" and study is not None:
+    if pf and study is not None:
         out["precision_vs_fp64"] = study
         worst = max(study["f16x3_over_f32_max_err"].values())
         ok = worst <= 2.0
@@ -986,7 +1384,7 @@ def main():
                             "(x = hi + lo to 2^-22), 3 f16 MFMA products per product, f32 accumulate; error vs fp64 "
                             f"within {worst:.2f}x of the exact-f32-product mode on every network (precision_vs_fp64)")
 
-    if wl["kind"] != "pf" and study is not None:
+    if not pf and study is not None:
         # the EKF's only non-f32 arithmetic is the image encoders' (K4 follows the engine's default mode)
         out["precision_vs_fp64"] = study
         worst = max(list(study["f16x3_over_f32_max_err"].values()) + list(study["jacobians"]["f16x3_over_f32_max_err"].values()))
@@ -999,12 +1397,17 @@ def main():
                             f"halves, 3 f16 MFMA products per product, f32 accumulate; error vs fp64 within {worst:.2f}x "
                             "of the exact-f32-product mode on every network, precision_vs_fp64)")
 
-    if world == 1 and wl["kind"] == "pf" and not args.no_reference_sizes:
+    del run_r, traj_r
+    if pf and args.noise != "philox":
+        del noise_r
+    torch.cuda.empty_cache()
+
+    if world == 1 and pf and not args.no_reference_sizes:
         out["reference_sized"] = reference_sized_regimes(device)
 
     if world == 1 and not args.no_cpu_baseline:
         cores = min(CPU_THREADS, os.cpu_count() or 1)
-        if wl["kind"] == "pf":
+        if pf:
             base, parity = cpu_baseline_pf(wl, f, d, cores)
         else:
             base, parity = cpu_baseline_ekf(wl, f, d, cores)
@@ -1013,6 +1416,12 @@ def main():
         out["speedup_vs_cpu_baseline"] = value / base["value"]
     else:
         out["cpu_baseline"] = None
+
+    if world == 1 and not args.no_configs:
+        t_cfg = time.perf_counter()
+        out["configs"] = run_configs(args, device, f, d, K, W)
+        out["configs"]["seconds"] = round(time.perf_counter() - t_cfg, 1)
+    out["bench_seconds"] = round(time.perf_counter() - t_start, 1)
     print(json.dumps(out), flush=True)
 
 

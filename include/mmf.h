@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 32
+#define MMF_ABI_VERSION 33
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -395,9 +395,21 @@ typedef struct MmfPfLoopArgs {
                              /* switch: measured slower than one launch per modality, the host leaves it off);    */
                              /* (bit-identical log-likelihoods); `events` then holds 2*3 entries per sampled  */
                              /* step: [dynamics, measure (all modalities), resample]                          */
+  float soft_alpha;          /* 0 or 1: plain resampling; 0 < alpha < 1 (resample_mode != 0): torchfilter's soft      */
+                             /* resampling (mmf_pf_reweight_resample_soft) -- the survivors carry importance weights, */
+                             /* so every step reads and writes the log-weights                                        */
+  int32_t estimate_argmax;   /* != 0: estimates = the particle with the largest pre-resampling weight                 */
+                             /* (mmf_pf_argmax_estimate; torchfilter's estimation_method = "argmax")                  */
+  float* estimate_scratch;   /* (N, d), needed with estimate_argmax: K1's weighted mean lands here instead            */
 } MmfPfLoopArgs;             /* host struct holding device pointers                           */
 
 int mmf_pf_forward_loop(const MmfPfLoopArgs* args /* host */, void* stream);
+
+/* estimation_method = "argmax" of torchfilter's ParticleFilter: per trajectory the particle with
+ * the largest pre-resampling log-weight logw_in + loglik (logw_in null: uniform), first index on ties (torch.argmax).
+ *   loglik (N, M), logw_in (N, M) | null, states (N, M, d) -> estimate (N, d)                                  */
+int mmf_pf_argmax_estimate(const float* loglik, const float* logw_in, const float* states, float* estimate,
+                           int N, int M, int d, void* stream);
 
 /* Counter-based process noise (include/mmf_philox.h: Philox4x32-10 + a fixed-order Box-Muller, a pure
  * function of (seed, step, global trajectory index, particle)): replaces the
@@ -594,6 +606,16 @@ int mmf_ekf_step(const float* A, const float* mu_pred, const float* q_tril, cons
                  float* mu_f, float* Sigma_f, int N, int d, int K, int fusion, int feedback,
                  void* stream);
 
+/* mmf_ekf_step whose write-back is gated by a DEVICE word: `feedback` applies only where *feedback_gate != 0
+ * (null = always).  Carries the reference's batch-global blackout test -- DoorCrossmodalKalmanFilter.forward
+ * takes the branch WITHOUT write-back as soon as any frame of the batch is blacked out
+ * (/root/reference/crossmodal/door_models/crossmodal_kf.py:59-62) -- into the
+ * native step loop without a host read per step. */
+int mmf_ekf_step_gated(const float* A, const float* mu_pred, const float* q_tril, const float* z,
+                       const float* r_tril, const float* fuse_w, float* mu, float* Sigma,
+                       float* mu_f, float* Sigma_f, int N, int d, int K, int fusion, int feedback,
+                       const int32_t* feedback_gate, void* stream);
+
 /* K6: reverse mode of mmf_ekf_step without fusion (fusion = 0; the fusions of the K sub-filters
  * are a handful of element-wise torch ops on (K, N, d) and keep their autograd form).  Inputs as
  * the forward call's, Sigma_in = the covariances BEFORE the step; g_mu (K, N, d) / g_Sigma
@@ -654,6 +676,9 @@ typedef struct MmfEkfLoopArgs {
   float* A;                  /* (K, N, d, d)  scratch                                           */
   float* Sigma_f;            /* (N, d, d)     fused covariance of the last step (fusion != 0)   */
   float* estimates;          /* (T, N, d) out: fused mean, or sub-filter 0's mean for fusion 0  */
+  const int32_t* feedback_gate; /* (T) device words or null: step t writes the fused belief back (feedback) only where
+                                gate[t] != 0 -- the reference's batch-global blackout branch
+                                (door_models/crossmodal_kf.py:59-62) decided on the device, no host read per step  */
 } MmfEkfLoopArgs;            /* host struct holding device pointers                            */
 
 int mmf_ekf_forward_loop(const MmfEkfLoopArgs* args /* host */, void* stream);

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 32
+ABI_VERSION = 33
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
@@ -66,7 +66,8 @@ class MmfPfLoopArgs(Structure):
                 ("final_location", POINTER(c_int32)), ("events", POINTER(c_void_p)),
                 ("event_stride", c_int32), ("loglik_steps", _FP), ("indices_steps", _FP),
                 ("noise_seed", ctypes.c_uint64), ("noise_step0", ctypes.c_uint32), ("noise_traj0", ctypes.c_uint32),
-                ("noise_mode", c_int32), ("use_graph", c_int32), ("measure_seq", c_int32)]
+                ("noise_mode", c_int32), ("use_graph", c_int32), ("measure_seq", c_int32),
+                ("soft_alpha", ctypes.c_float), ("estimate_argmax", c_int32), ("estimate_scratch", _FP)]
 
 
 class MmfTrainNet(Structure):
@@ -94,7 +95,7 @@ class MmfEkfLoopArgs(Structure):
                 ("dyn_packed", _FP * LOOP_MAX_MEAS), ("dyn_bias", _FP * LOOP_MAX_MEAS),
                 ("q_tril", _FP), ("z", _FP), ("r_tril", _FP), ("fuse_w", _FP),
                 ("mu", _FP), ("Sigma", _FP), ("mu_pred", _FP), ("A", _FP), ("Sigma_f", _FP),
-                ("estimates", _FP)]
+                ("estimates", _FP), ("feedback_gate", _FP)]
 
 
 class MmfImageEncoderDesc(Structure):
@@ -116,12 +117,14 @@ SIGNATURES = {
     "mmf_pf_measure_seq": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, c_int, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_dynamics_jacobian": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_ekf_step": (c_int, [_FP] * 10 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmf_ekf_step_gated": (c_int, [_FP] * 10 + [c_int, c_int, c_int, c_int, c_int, _FP, c_void_p]),
     "mmf_ekf_step_backward": (c_int, [_FP] * 13 + [c_int, c_int, c_int, c_void_p]),
     "mmf_ukf_sigma_points": (c_int, [_FP, _FP, ctypes.c_float, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_ukf_moments": (c_int, [_FP, ctypes.c_float, ctypes.c_float, ctypes.c_float, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_pf_reweight_backward": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_init_particles": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_forward_loop": (c_int, [POINTER(MmfPfLoopArgs), c_void_p]),
+    "mmf_pf_argmax_estimate": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_loop_graphs_release": (None, []),
     "mmf_pf_dynamics_philox": (c_int, [_FP, c_int, c_int, _FP, _FP, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
                                        _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
@@ -303,10 +306,25 @@ def dynamics_jacobian(packed, n_res, precision, states_in, traj_bias, states_out
                                             stream_of(states_in)), "mmf_dynamics_jacobian")
 
 
+def pf_argmax_estimate(loglik, logw_in, states, estimate):
+    N, M, d = states.shape
+    with _on(states):
+        _check(load().mmf_pf_argmax_estimate(ptr(loglik), ptr(logw_in), ptr(states), ptr(estimate), N, M, d,
+                                             stream_of(states)), "mmf_pf_argmax_estimate")
+
+
 def ekf_step(A, mu_pred, q_tril, z, r_tril, fuse_w, mu, Sigma, mu_f, Sigma_f, fusion: int,
-             feedback: int):
+             feedback: int, feedback_gate=None):
+    """``feedback_gate``: int32 device word; the write-back applies only where it is non-zero
+    (``mmf_ekf_step_gated``)."""
     K, N, d = mu_pred.shape
     with _on(mu_pred):
+        if feedback_gate is not None:
+            _check(load().mmf_ekf_step_gated(ptr(A), ptr(mu_pred), ptr(q_tril), ptr(z), ptr(r_tril),
+                                             ptr(fuse_w), ptr(mu), ptr(Sigma), ptr(mu_f), ptr(Sigma_f),
+                                             N, d, K, fusion, feedback, ptr(feedback_gate, dtype=torch.int32),
+                                             stream_of(mu_pred)), "mmf_ekf_step_gated")
+            return
         _check(load().mmf_ekf_step(ptr(A), ptr(mu_pred), ptr(q_tril), ptr(z), ptr(r_tril),
                                    ptr(fuse_w), ptr(mu), ptr(Sigma), ptr(mu_f), ptr(Sigma_f),
                                    N, d, K, fusion, feedback, stream_of(mu_pred)), "mmf_ekf_step")

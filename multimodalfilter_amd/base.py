@@ -110,6 +110,11 @@ class Filter(nn.Module, abc.ABC):
 
     def forward_loop(self, *, observations, controls) -> torch.Tensor:
         """``(T, N, ...)`` in, ``(T, N, d)`` out (``eval_helpers.py:139-146``)."""
+        from . import engine  # (engine imports this module's siblings)
+
+        return engine.checked_loop(Filter._forward_loop_steps)(self, observations=observations, controls=controls)
+
+    def _forward_loop_steps(self, *, observations, controls) -> torch.Tensor:
         T = tree_leading_shape(controls)[0]
         assert tree_leading_shape(observations)[0] == T
         out = [self(observations=tree_index(observations, t), controls=tree_index(controls, t))

@@ -282,6 +282,7 @@ class _FusedKalmanFilters(base.Filter, _EnabledModels):
         covs = torch.stack([f._belief_covariance for f in live])
         return means, covs
 
+    @engine.checked_step
     def forward(self, *, observations, controls):
         N, _ = controls.shape
         if use_autograd(self):
@@ -334,14 +335,14 @@ class _FusedKalmanFilters(base.Filter, _EnabledModels):
         self._loop_sensor_outputs = outs  # (T*N, ...) blocks, for the native step loop
         return encs
 
-    def _native_plan(self, encs, T, N):
-        """``(fusion, feedback, fuse_w (T, K, N, d) | None)`` for ``mmf_ekf_forward_loop``, or
-        ``None`` when this filter's step is not a plain K5 + K3 sequence."""
+    def _native_plan(self, encs, T, N, observations=None):
+        """``(fusion, feedback, fuse_w (T, K, N, d) | None[, feedback gate (T,) int32 | None])`` for
+        ``mmf_ekf_forward_loop``, or ``None`` when this filter's step is not a plain K5 + K3 sequence."""
         return None
 
-    def _native_loop(self, encs, ctrl_all, T, N):
+    def _native_loop(self, encs, ctrl_all, T, N, observations=None):
         """All ``T`` steps through ``mmf_ekf_forward_loop`` (one C call); ``None`` -> Python loop."""
-        plan = self._native_plan(encs, T, N)
+        plan = self._native_plan(encs, T, N, observations)
         live_idx = [i for i, on in enumerate(self._enabled_models) if on]
         live = [self.filter_models[i] for i in live_idx]
         if plan is None or T == 0 or len(live) > _abi.LOOP_MAX_MEAS:
@@ -351,7 +352,8 @@ class _FusedKalmanFilters(base.Filter, _EnabledModels):
             return None
         if any(ctrl_all[i] is None for i in live_idx) or len({m._net.n_res for m in dyns}) != 1:
             return None
-        fusion, feedback, fuse_w = plan
+        fusion, feedback, fuse_w = plan[:3]
+        gate = plan[3] if len(plan) > 3 else None  # (T,) int32 device words: step t writes back only where != 0
         outs = self._loop_sensor_outputs
         d, K = self.state_dim, len(live)
         dev = live[0]._belief_mean.device
@@ -380,6 +382,8 @@ class _FusedKalmanFilters(base.Filter, _EnabledModels):
             a.dyn_packed[k], a.dyn_bias[k] = P(blobs[k]), P(biases[k])
         a.q_tril, a.z, a.r_tril, a.fuse_w = P(q), P(z), P(r), P(fw)
         a.mu, a.Sigma, a.mu_pred, a.A, a.Sigma_f, a.estimates = P(mu), P(Sigma), P(mu_pred), P(A), P(Sigma_f), P(est)
+        if gate is not None:
+            a.feedback_gate = ctypes.c_void_p(_abi.ptr(gate, dtype=torch.int32))
         _abi.ekf_forward_loop(a, mu)
         for k, f in enumerate(live):
             f._belief_mean, f._belief_covariance = mu[k], Sigma[k]
@@ -396,7 +400,7 @@ class _FusedKalmanFilters(base.Filter, _EnabledModels):
             encs = self._encode_loop(observations, T, N)
             flat = tree_map(controls, lambda x: x.reshape((T * N,) + tuple(x.shape[2:])))
             ctrl_all = self._encode_controls(flat)
-            native = self._native_loop(encs, ctrl_all, T, N)
+            native = self._native_loop(encs, ctrl_all, T, N, observations)
             if native is not None:
                 return self._after_native_loop(*native)
             out = []
@@ -437,7 +441,7 @@ class CrossmodalKalmanFilter(_FusedKalmanFilters):
         assert w.shape == (np.sum(on), N, self.state_dim)
         return w
 
-    def _native_plan(self, encs, T, N):
+    def _native_plan(self, encs, T, N, observations=None):
         dev = self.filter_models[0]._belief_mean.device
         w = torch.stack([self._state_weights(e["weights"], N, dev) for e in encs])
         return 1, (1 if self.feedback == "belief" else 0), w
@@ -524,7 +528,7 @@ class UnimodalKalmanFilter(_FusedKalmanFilters):
         Sigma = torch.inverse(torch.sum(prec, dim=0) + 1e-9)
         return (Sigma @ torch.sum(prec @ means[..., None], dim=0)).squeeze(-1)
 
-    def _native_plan(self, encs, T, N):
+    def _native_plan(self, encs, T, N, observations=None):
         return (0 if np.sum(self._enabled_models) == 1 else 2), 0, None
 
     def _after_native_loop(self, estimates, Sigma_f):

@@ -117,9 +117,12 @@ __global__ __launch_bounds__(256) void ekf_step_kernel(
     const float* __restrict__ A, const float* __restrict__ mu_pred, const float* __restrict__ q_tril,
     const float* __restrict__ z, const float* __restrict__ r_tril, const float* __restrict__ fuse_w,
     float* __restrict__ mu, float* __restrict__ Sigma, float* __restrict__ mu_f,
-    float* __restrict__ Sigma_f, int N, int K, int fusion, int feedback) {
+    float* __restrict__ Sigma_f, int N, int K, int fusion, int feedback, const int32_t* __restrict__ feedback_gate) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
+  // a batch-global, data-dependent branch of the reference (door_models/crossmodal_kf.py:59-62: ANY blacked-out
+  // frame in the batch -> the branch that skips the write-back) as a device word: no host round trip per step
+  if (feedback_gate != nullptr && *feedback_gate == 0) feedback = 0;
 
   float mus[kMaxK][D];
   Mat<D> Ss[kMaxK];
@@ -476,10 +479,23 @@ extern "C" int mmf_fuse_virtual_sensors(const float* z, const float* tril, const
   return 0;
 }
 
+extern "C" int mmf_ekf_step_gated(const float* A, const float* mu_pred, const float* q_tril,
+                                  const float* z, const float* r_tril, const float* fuse_w, float* mu,
+                                  float* Sigma, float* mu_f, float* Sigma_f, int N, int d, int K,
+                                  int fusion, int feedback, const int32_t* feedback_gate, void* stream);
+
 extern "C" int mmf_ekf_step(const float* A, const float* mu_pred, const float* q_tril,
                             const float* z, const float* r_tril, const float* fuse_w, float* mu,
                             float* Sigma, float* mu_f, float* Sigma_f, int N, int d, int K,
                             int fusion, int feedback, void* stream) {
+  return mmf_ekf_step_gated(A, mu_pred, q_tril, z, r_tril, fuse_w, mu, Sigma, mu_f, Sigma_f, N, d, K, fusion, feedback,
+                            nullptr, stream);
+}
+
+extern "C" int mmf_ekf_step_gated(const float* A, const float* mu_pred, const float* q_tril,
+                                  const float* z, const float* r_tril, const float* fuse_w, float* mu,
+                                  float* Sigma, float* mu_f, float* Sigma_f, int N, int d, int K,
+                                  int fusion, int feedback, const int32_t* feedback_gate, void* stream) {
   if (!A || !mu_pred || !q_tril || !z || !r_tril || !mu || !Sigma) return MMF_EINVAL;
   if (N < 0 || d < 1 || d > MMF_MAX_STATE_DIM || K < 1 || K > kMaxK) return MMF_EINVAL;
   if (fusion < 0 || fusion > 2 || (fusion == 1 && !fuse_w)) return MMF_EINVAL;
@@ -490,7 +506,7 @@ extern "C" int mmf_ekf_step(const float* A, const float* mu_pred, const float* q
 #define MMF_K3(D)                                                                               \
   case D:                                                                                       \
     ekf_step_kernel<D><<<grid, block, 0, s>>>(A, mu_pred, q_tril, z, r_tril, fuse_w, mu, Sigma,  \
-                                              mu_f, Sigma_f, N, K, fusion, feedback);            \
+                                              mu_f, Sigma_f, N, K, fusion, feedback, feedback_gate); \
     break;
   switch (d) {
     MMF_K3(1) MMF_K3(2) MMF_K3(3) MMF_K3(4)

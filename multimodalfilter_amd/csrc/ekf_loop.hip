@@ -28,10 +28,10 @@ extern "C" int mmf_ekf_forward_loop(const MmfEkfLoopArgs* a, void* stream) {
       if (rc) return rc;
     }
     float* est = a->estimates + t * N * d;
-    const int rc = mmf_ekf_step(a->A, a->mu_pred, a->q_tril, a->z + t * K * N * d, a->r_tril + t * K * N * d * d,
-                                a->fuse_w ? a->fuse_w + t * K * N * d : nullptr, a->mu, a->Sigma,
-                                a->fusion ? est : nullptr, a->fusion ? a->Sigma_f : nullptr, a->N, a->d,
-                                a->K, a->fusion, a->feedback, stream);
+    const int rc = mmf_ekf_step_gated(a->A, a->mu_pred, a->q_tril, a->z + t * K * N * d, a->r_tril + t * K * N * d * d,
+                                      a->fuse_w ? a->fuse_w + t * K * N * d : nullptr, a->mu, a->Sigma,
+                                      a->fusion ? est : nullptr, a->fusion ? a->Sigma_f : nullptr, a->N, a->d,
+                                      a->K, a->fusion, a->feedback, a->feedback_gate ? a->feedback_gate + t : nullptr, stream);
     if (rc) return rc;
     if (a->fusion == 0) {  // a single (enabled) sub-filter: its corrected mean is the estimate
       const hipError_t e = hipMemcpyAsync(est, a->mu, N * d * sizeof(float), hipMemcpyDeviceToDevice, hs);

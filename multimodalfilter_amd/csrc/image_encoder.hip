@@ -1050,10 +1050,11 @@ extern "C" int mmf_image_encoder(const float* const* packed, int n_nets, const f
     for (int i = 0; i < n_nets; ++i) fa.packed[i] = packed[i];
     fa.images = images; fa.N = N; fa.range_flag = range_flag;
     fa.out = bufA;
-    if ((rc = launch_fused(fa, n_nets, 0, bf16, s))) return rc;
+    const FusedFlavour fl = fused_flavour();  // once per call: both launches and the conv4 decision below share it
+    if ((rc = launch_fused(fa, n_nets, 0, bf16, fl, s))) return rc;
     fa.bin = bufA; fa.out = bufB;
-    fa.out_e = fuse_conv4() ? bufC : nullptr;  // conv 16->8 in the same kernel: D never reaches HBM
-    if ((rc = launch_fused(fa, n_nets, 1, bf16, s))) return rc;
+    fa.out_e = fl.fuse_conv4 ? bufC : nullptr;  // conv 16->8 in the same kernel: D never reaches HBM
+    if ((rc = launch_fused(fa, n_nets, 1, bf16, fl, s))) return rc;
     if (!fa.out_e) {
       Conv4Args c4{};
       for (int i = 0; i < n_nets; ++i) c4.packed[i] = packed[i];

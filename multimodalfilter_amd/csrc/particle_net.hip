@@ -196,7 +196,22 @@ __device__ __forceinline__ float relu1(float v) {
   return __int_as_float(max(__float_as_int(v), 0));
 }
 
-template <int CT, bool JAC>
+// f16x3 layers: ReLU AND saturation at the largest f16 in ONE instruction (v_med3_f32; no canonicalisation is
+// emitted in front of the builtin).  An activation beyond the f16 range then splits into hi = 65504 (0x7BFF,
+// which the range tracking reports) and a finite residual instead of hi = +inf, lo = -inf, whose products are
+// NaN: the failure mode of the mode is a raised flag over FINITE outputs.  v_med3_f32 returns min3 when an
+// operand is NaN, i.e. it would swallow a NaN: the two ReLUs that see externally supplied numbers first (the
+// first layer on the particle states, the one after the join layer on the per-trajectory term) therefore stay
+// NaN-keeping (the first layer's inputs are tested directly, the ReLU after the join layer is relu_keepnan), so
+// that a NaN / inf input reaches the next operand split and raises the flag there (0x7C00 / 0x7E00 >= 0x7BFF),
+// and every later ReLU clamps whatever those produce.
+__device__ __forceinline__ float relu_sat(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, kF16SplitMax); }
+// ReLU that keeps a NaN of EITHER sign (relu1 turns a negative NaN into 0): compare + select, used once per network
+__device__ __forceinline__ float relu_keepnan(float v) { return v <= 0.f ? 0.f : v; }
+// signed operands (dynamics trunk entry, Jacobian tangents): saturate both ways; a NaN becomes -65504 (flagged)
+__device__ __forceinline__ float clamp_sat(float v) { return __builtin_amdgcn_fmed3f(v, -kF16SplitMax, kF16SplitMax); }
+
+template <int CT, bool JAC, bool SAT = false>
 __device__ __forceinline__ void relu(Act<CT>& a, bool primal) {
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -208,11 +223,23 @@ __device__ __forceinline__ void relu(Act<CT>& a, bool primal) {
         if (JAC) {
           // tangent columns follow the primal's mask (sub-gradient 0 at 0, as autograd)
           const float pv = quad_first(v);
-          a.v[t][c][r] = primal ? relu1(v) : (pv > 0.f ? v : 0.f);
+          const float keep = pv > 0.f ? v : 0.f;
+          a.v[t][c][r] = primal ? (SAT ? relu_sat(v) : relu1(v)) : (SAT ? clamp_sat(keep) : keep);
         } else {
-          a.v[t][c][r] = relu1(v);
+          a.v[t][c][r] = SAT ? relu_sat(v) : relu1(v);
         }
       }
+}
+
+// saturate a signed activation in place (f16x3: the one operand split that follows no ReLU)
+template <int CT>
+__device__ __forceinline__ void saturate(Act<CT>& a) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a.v[t][c][r] = clamp_sat(a.v[t][c][r]);
 }
 
 // y = relu(W2 relu(W1 x + b1) + b2 + x), in place in x, h as scratch (resblocks.Linear)
@@ -332,15 +359,16 @@ __device__ __forceinline__ void res_block_f16(const float* __restrict__ lds, int
                                               float neg_one, short2v& amax, bool primal = true) {
   const int h = lane >> 5;
   const float bs = (JAC && !primal) ? 0.f : 1.f;
+  if constexpr (SIGNED) saturate<CT>(x);  // no ReLU in front of this split: saturate the signed values themselves
   split_act<CT, SIGNED || JAC>(x, sp, neg_one, amax);
   add_bias<CT, false>(lds + off_bias(n_res) + l1 * kUnits, hbuf, h, bs);
   mfma_layer_f16<CT>(lds + off_layers() + l1 * kLayerFloats, sp, hbuf, lane);
-  relu<CT, JAC>(hbuf, primal);
+  relu<CT, JAC, true>(hbuf, primal);
   split_act<CT, JAC>(hbuf, sp, neg_one, amax);
   if constexpr (JAC) add_bias<CT, true>(lds + off_bias(n_res) + (l1 + 1) * kUnits, x, h, bs);
   else add_bias_packed<CT>(lds + off_bias(n_res) + (l1 + 1) * kUnits, x, h);
   mfma_layer_f16<CT>(lds + off_layers() + (l1 + 1) * kLayerFloats, sp, x, lane);
-  relu<CT, JAC>(x, primal);
+  relu<CT, JAC, true>(x, primal);
 }
 
 // ------------------------------------------------------------------ f16x3, pipelined halves
@@ -361,12 +389,20 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
-template <int C>
+template <int C, bool SAT = true>
 __device__ __forceinline__ void relu_half(Act<2>& a) {
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a.v[t][C][r] = relu1(a.v[t][C][r]);
+    for (int r = 0; r < 16; ++r) a.v[t][C][r] = SAT ? relu_sat(a.v[t][C][r]) : relu_keepnan(a.v[t][C][r]);
+}
+
+template <int C>
+__device__ __forceinline__ void saturate_half(Act<2>& a) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a.v[t][C][r] = clamp_sat(a.v[t][C][r]);
 }
 
 template <int C, bool SIGNED>
@@ -602,6 +638,16 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
 
     SplitAct<F16 ? CT : 0> SP;
     short2v amax = {0, 0};  // f16x3: largest hi halves handed to the MFMAs in this tile
+    if constexpr (F16) {
+      // a NaN / inf particle state: the first layer's exact-f32 MFMAs turn it into NaNs of either sign, and a
+      // negative NaN would pass the ReLU as 0 -- report the input itself (a handful of compares per tile)
+      bool bad = false;
+#pragma unroll
+      for (int s = 0; s < KS0; ++s)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) bad |= !(fabsf(bcur[s][c]) <= 3.0e38f);
+      if (bad) amax = short2v{0x7fff, 0x7fff};
+    }
     if constexpr (PIPE) {
       constexpr int NL = 3 + 2 * NRES;  // 64x64 layers: encoder block, join, NRES trunk blocks
       FragPair frag;                    // weight fragments of the next MFMA group, in flight
@@ -634,7 +680,9 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
             }
         } else if constexpr ((l - 3) % 2 == 0) {  // trunk block, first layer: X = b + W H
           constexpr bool kSigned = (l == 3 && KIND != kMeasure);  // no ReLU after the join (dynamics)
-          if constexpr (!kSigned) relu_half<C>(H);
+          // l == 3 consumes the per-trajectory term: its ReLU keeps a NaN / inf for the split to report (relu_sat)
+          if constexpr (kSigned) saturate_half<C>(H);
+          else relu_half<C, (l != 3)>(H);
           split_half<C, kSigned>(H, SP, neg_one, amax);
           bias_half<C, false>(bl, X, h);
         } else {                                  // trunk block, second layer: H += b + W relu(X)
@@ -695,7 +743,18 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
     } else {
       mfma_layer<CT>(lds + off_layers() + 2 * kLayerFloats, X, H, lane);
     }
-    if (KIND == kMeasure) relu<CT, JAC>(H, primal);
+    if (KIND == kMeasure) {
+      if constexpr (F16) {  // consumes the per-trajectory term: keep a NaN of either sign for the next split to report
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) H.v[t][c][r] = relu_keepnan(H.v[t][c][r]);
+      } else {
+        relu<CT, JAC>(H, primal);
+      }
+    }
 
     // ---- residual trunk: activations now live in H, X is scratch
 #pragma unroll
@@ -710,8 +769,10 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
 
     }
     if constexpr (F16) {
-      // an operand beyond the f16 range breaks the split (round-to-nearest: |x| >= 65520 gives hi = inf,
-      // lo = x - inf = -inf, so the MFMAs produce NaN until the caller's check_range raises): report it
+      // an operand beyond the f16 range cannot be split exactly: inner activations saturate at 65504 (relu_sat,
+      // hi = 0x7BFF), a non-finite state or per-trajectory term arrives as hi = inf / NaN (>= 0x7C00) and is
+      // clamped by the next relu_sat -- either way the tile's outputs stay finite and the flag says they are
+      // invalid (engine.check_range raises: per forward_loop, and per step for a bare forward())
       if (a.range_flag != nullptr && (amax[0] >= kF16Saturated || amax[1] >= kF16Saturated))
         atomicOr(a.range_flag, 1);
     }

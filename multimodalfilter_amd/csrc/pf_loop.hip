@@ -18,6 +18,8 @@ static int pf_enqueue_steps(const MmfPfLoopArgs* a, void* stream, bool with_even
       !a->logw_a || !a->logw_b || !a->loglik || !a->estimates)
     return MMF_EINVAL;
   if (a->resample_mode != 0 && !a->uniforms) return MMF_EINVAL;
+  const bool soft = a->resample_mode != 0 && a->soft_alpha > 0.f && a->soft_alpha < 1.f;
+  if (a->estimate_argmax && !a->estimate_scratch) return MMF_EINVAL;
   const size_t row = static_cast<size_t>(a->N);
   const size_t nm = row * a->M;
   float* cur = a->states_a;   // belief on entry
@@ -76,8 +78,22 @@ static int pf_enqueue_steps(const MmfPfLoopArgs* a, void* stream, bool with_even
       }
     }
     float* est = a->estimates + t * row * a->d;
+    if (a->estimate_argmax) {
+      // the particle with the largest pre-resampling weight; K1's weighted mean goes to the scratch.  In the plain
+      // resampling loop the incoming weights are uniform from the second step on (see below)
+      const bool uniform_in = a->resample_mode != 0 && !soft && t > 0;
+      rc = mmf_pf_argmax_estimate(ll, uniform_in ? nullptr : lw_cur, other, est, a->N, a->M, a->d, stream);
+      if (rc) return rc;
+      est = a->estimate_scratch;
+    }
     if ((rc = mark())) return rc;
-    if (a->resample_mode == 0) {
+    if (soft) {
+      // torchfilter's soft resampling: survivors carry importance weights, so the log-weights travel every step
+      const float* u = a->uniforms + t * (a->resample_mode == 1 ? row : nm);
+      rc = mmf_pf_reweight_resample_soft(ll, lw_cur, other, u, est, cur, lw_other, anc, a->N, a->M, a->M, a->d,
+                                         a->resample_mode, a->soft_alpha, stream);
+      if (rc) return rc;
+    } else if (a->resample_mode == 0) {
       rc = mmf_pf_reweight_resample(ll, lw_cur, other, nullptr, est, nullptr, lw_other, nullptr, a->N,
                                     a->M, a->M, a->d, 0, stream);
       if (rc) return rc;

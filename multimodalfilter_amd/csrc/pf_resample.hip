@@ -744,6 +744,61 @@ int launch_reweight_resample(const float* loglik, const float* logw_in, const fl
 }
 }  // namespace
 
+namespace {
+// estimation_method = "argmax": one workgroup per trajectory; value = logw_in + loglik (ONE fp32 add, as the
+// step-by-step path's torch expression), larger value wins, smaller index on ties (torch.argmax)
+template <int D>
+__global__ __launch_bounds__(256) void pf_argmax_estimate_kernel(const float* __restrict__ loglik,
+                                                                 const float* __restrict__ logw_in,
+                                                                 const float* __restrict__ states,
+                                                                 float* __restrict__ estimate, int M, float lw_uniform) {
+  __shared__ float best_v[256 / MMF_WAVE];
+  __shared__ int best_i[256 / MMF_WAVE];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float* ll = loglik + static_cast<size_t>(n) * M;
+  const float* lw = logw_in ? logw_in + static_cast<size_t>(n) * M : nullptr;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = tid; i < M; i += blockDim.x) {
+    const float v = (lw ? lw[i] : lw_uniform) + ll[i];
+    if (v > bv || (v == bv && i < bi) || bi == 0x7fffffff) { bv = v; bi = i; }
+  }
+  auto better = [](float v, int i, float w, int j) { return v > w || (v == w && i < j); };
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float ov = __shfl_xor(bv, off);
+    const int oi = __shfl_xor(bi, off);
+    if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+  if ((tid & (MMF_WAVE - 1)) == 0) { best_v[tid >> 6] = bv; best_i[tid >> 6] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < static_cast<int>(blockDim.x >> 6); ++w)
+      if (better(best_v[w], best_i[w], bv, bi)) { bv = best_v[w]; bi = best_i[w]; }
+    if (bi >= M) bi = 0;  // every value NaN: torch.argmax would pick a NaN's index; the filter is lost either way
+#pragma unroll
+    for (int c = 0; c < D; ++c) estimate[static_cast<size_t>(n) * D + c] = states[(static_cast<size_t>(n) * M + bi) * D + c];
+  }
+}
+}  // namespace
+
+extern "C" int mmf_pf_argmax_estimate(const float* loglik, const float* logw_in, const float* states, float* estimate,
+                                      int N, int M, int d, void* stream) {
+  if (!loglik || !states || !estimate) return MMF_EINVAL;
+  if (N < 0 || M < 1 || d < 1 || d > MMF_MAX_STATE_DIM) return MMF_EINVAL;
+  if (N == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float lw_uniform = static_cast<float>(-std::log(static_cast<double>(M)));
+  switch (d) {
+    case 1: pf_argmax_estimate_kernel<1><<<N, 256, 0, s>>>(loglik, logw_in, states, estimate, M, lw_uniform); break;
+    case 2: pf_argmax_estimate_kernel<2><<<N, 256, 0, s>>>(loglik, logw_in, states, estimate, M, lw_uniform); break;
+    case 3: pf_argmax_estimate_kernel<3><<<N, 256, 0, s>>>(loglik, logw_in, states, estimate, M, lw_uniform); break;
+    default: pf_argmax_estimate_kernel<4><<<N, 256, 0, s>>>(loglik, logw_in, states, estimate, M, lw_uniform); break;
+  }
+  MMF_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int mmf_pf_reweight_resample(const float* loglik, const float* logw_in,
                                         const float* states_in, const float* u, float* estimate,
                                         float* states_out, float* logw_out, int32_t* indices_out,

@@ -198,26 +198,46 @@ def check_range(device):
             "filter steps are invalid; set MMF_PRECISION=f32 / engine.set_default_precision('f32')")
 
 
-def checked_loop(fn):
-    """Decorator for ``forward_loop`` methods: the f16x3 range flag (raised by K2 / K4 launches whose
-    operands left the f16 range) is cleared on entry and checked on the way out, so a loop reports
-    its own launches -- one 4-byte device->host read per loop."""
+_CHECK_DEPTH = 0  # > 0 while a checked forward_loop / forward is running: inner calls leave the check to it
+
+
+def _checked(fn):
     import functools
 
     @functools.wraps(fn)
     def wrapper(self, *args, **kwargs):
+        global _CHECK_DEPTH
         dev = None
         for p in self.parameters():
             dev = p.device
             break
-        if dev is None or dev.type != "cuda":
+        if _CHECK_DEPTH > 0 or dev is None or dev.type != "cuda":
             return fn(self, *args, **kwargs)
         clear_range(dev)
-        out = fn(self, *args, **kwargs)
+        _CHECK_DEPTH += 1
+        try:
+            out = fn(self, *args, **kwargs)
+        finally:
+            _CHECK_DEPTH -= 1
         check_range(dev)
         return out
 
     return wrapper
+
+
+def checked_loop(fn):
+    """Decorator for ``forward_loop`` methods: the f16x3 range flag (raised by K2 / K4 launches whose
+    operands left the f16 range) is cleared on entry and checked on the way out, so a loop reports
+    its own launches -- one 4-byte device->host read per loop."""
+    return _checked(fn)
+
+
+def checked_step(fn):
+    """Decorator for a filter's ``forward``: a bare step (no ``forward_loop`` around it) checks the range
+    flag itself, so an out-of-range f16x3 operand raises at the step that produced it instead of handing
+    saturated numbers to the caller -- one 4-byte device->host read per step of a caller-driven loop;
+    steps inside a checked ``forward_loop`` (or inside another filter's step) leave the check to it."""
+    return _checked(fn)
 
 
 def clear_range(device):

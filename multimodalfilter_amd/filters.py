@@ -31,7 +31,7 @@ class ParticleFilter(base.Filter):
     ``resample=None`` resamples iff ``not self.training`` (upstream behaviour).
     ``soft_resample_alpha < 1`` (upstream option): ancestors are drawn from the
     mixture ``alpha w + (1 - alpha) / M`` and keep the importance weights ``w / mixture``
-    (``mmf_pf_reweight_resample_soft``; evaluated step by step, not by the native loop).
+    (``mmf_pf_reweight_resample_soft``; inside the native loop too: ``MmfPfLoopArgs.soft_alpha``).
     ``resample_mode``: ``"systematic"`` (low variance, one uniform per trajectory; what
     ``north_star`` asks for) or ``"multinomial"`` (upstream's distribution, one uniform per
     particle).  Both use the fixed-point CDF of ``csrc/pf_resample.hip``.
@@ -285,15 +285,13 @@ class ParticleFilter(base.Filter):
         if not self.use_native_loop:
             return None
         plan = meas.fused_measurements(obs_all)
-        if plan is None or self.estimation_method != "weighted_average" or T == 0:
+        if plan is None or T == 0:
             return None
         nets, stride = plan
         Nb, M, d = self.particle_states.shape
         do_resample = (not self.training) if self.resample is None else bool(self.resample)
         if Nb != N or self.num_particles != M or len(nets) > _abi.LOOP_MAX_MEAS:
             return None
-        if do_resample and self.soft_resample_alpha < 1.0:
-            return None  # the native loop resamples with the plain K1
         assert self._initialized, "Particle filter not initialized!"
         mode = _MODES[self.resample_mode] if do_resample else 0
         like = self.particle_states
@@ -334,6 +332,12 @@ class ParticleFilter(base.Filter):
                 a.indices_steps = ctypes.c_void_p(_abi.ptr(self.last_resample_indices, dtype=torch.int32))
         a.range_flag = ctypes.c_void_p(engine.range_flag(dev).data_ptr())
         a.use_graph = int(engine.LOOP_GRAPH)
+        if do_resample and self.soft_resample_alpha < 1.0:
+            a.soft_alpha = float(self.soft_resample_alpha)  # survivors carry importance weights (mmf_pf_reweight_resample_soft)
+        if self.estimation_method == "argmax":
+            est_scratch = torch.empty((N, d), dtype=torch.float32, device=dev)
+            keep.append(est_scratch)
+            a.estimate_argmax, a.estimate_scratch = 1, P(est_scratch)
         fused_measure = engine.MEASURE_SEQ and len(nets) > 1
         a.measure_seq = int(fused_measure)
         timer = engine.kernel_timer()
@@ -378,6 +382,11 @@ class ParticleFilter(base.Filter):
         nets, biases, beta, K_all = plan
         if len(nets) > _abi.LOOP_MAX_MEAS:
             return None
+        # the native recursion returns no gradient for the process-noise factor (the reference's models freeze Q)
+        # and takes ONE depth for all measurement networks: a trainable / state-dependent Q or networks of
+        # different depths keep the step-by-step autograd loop, which differentiates `eps @ scale_tril^T`
+        if dyn.scale_tril().requires_grad or len({net.n_res for net, _col in nets}) != 1:
+            return None
         eps, _ = self.noise.draw_steps(T, (N, M, d), None, like=self.particle_states)
         if isinstance(eps, CounterBlock):  # the training recursion reads its noise from a tensor
             blk = eps
@@ -395,11 +404,13 @@ class ParticleFilter(base.Filter):
         self._spare_states = None
         return est
 
+    @engine.checked_step
     def forward(self, *, observations, controls) -> torch.Tensor:
         if use_autograd(self):
             return self._step_autograd(observations, controls)
         return self._step(observations, controls)
 
+    @engine.checked_loop
     def forward_loop(self, *, observations, controls) -> torch.Tensor:
         """Sequential in ``t``.  Everything that does not depend on the belief (control and
         observation encoders, image CNNs, modality weights) is evaluated ahead of the
@@ -430,7 +441,6 @@ class ParticleFilter(base.Filter):
                     None if meas_all is None else {k: v[sl] for k, v in meas_all.items()}))
             return torch.stack(out, dim=0)
         obs_all = ctrl_all = None
-        engine.clear_range(self.particle_states.device if self.particle_states is not None else "cpu")
         with torch.no_grad():
             if hasattr(self.measurement_model, "forward_encoded"):
                 obs_all = self.measurement_model.encode_observations(tree_map(observations, flat))
@@ -438,7 +448,6 @@ class ParticleFilter(base.Filter):
                 ctrl_all = self.dynamics_model.encode_controls(tree_map(controls, flat))
             native = self._native_loop(obs_all, ctrl_all, T, N)
         if native is not None:
-            check_range(native.device)
             return native
         out = []
         for t in range(T):
@@ -447,9 +456,7 @@ class ParticleFilter(base.Filter):
                 tree_index(observations, t), tree_index(controls, t),
                 None if obs_all is None else {k: v[sl] for k, v in obs_all.items()},
                 None if ctrl_all is None else {k: v[sl] for k, v in ctrl_all.items()}))
-        result = torch.stack(out, dim=0)
-        check_range(result.device)  # f16x3 operand range (one 4-byte read per loop)
-        return result
+        return torch.stack(out, dim=0)
 
 
 class VirtualSensorExtendedKalmanFilter(base.Filter):
@@ -549,6 +556,7 @@ class VirtualSensorExtendedKalmanFilter(base.Filter):
         self._belief_covariance = (torch.eye(K.shape[-1], device=K.device) - K) @ Sp
         return self._belief_mean
 
+    @engine.checked_step
     def forward(self, *, observations, controls):
         if use_autograd(self):
             return self._step_autograd(observations, controls)

@@ -63,13 +63,25 @@ def lib():
             "H5Tget_native_type": (hid_t, [hid_t, c_int]), "H5Tclose": (c_int, [hid_t]),
             "H5Pcreate": (hid_t, [hid_t]), "H5Pset_chunk": (c_int, [hid_t, c_int, POINTER(c_ulonglong)]),
             "H5Pset_deflate": (c_int, [hid_t, c_uint]), "H5Pclose": (c_int, [hid_t]),
-            "H5Literate": (c_int, [hid_t, c_int, c_int, POINTER(c_ulonglong), c_void_p, c_void_p]),
+            "H5get_libversion": (c_int, [POINTER(c_uint), POINTER(c_uint), POINTER(c_uint)]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
         if L.H5open() < 0:
             raise ImportError("H5open failed")
+        maj, mnr, rel = c_uint(0), c_uint(0), c_uint(0)
+        L.H5get_libversion(ctypes.byref(maj), ctypes.byref(mnr), ctypes.byref(rel))
+        if (maj.value, mnr.value) < (1, 10):
+            # 1.8 has a 32-bit hid_t: every handle of this binding would be mis-sized
+            raise ImportError(f"libhdf5 {maj.value}.{mnr.value}.{rel.value}: this binding needs HDF5 >= 1.10 (64-bit hid_t); install h5py instead")
+        # HDF5 >= 1.12 turned H5Literate into a macro over H5Literate1 / H5Literate2: the library exports only those.
+        # H5Literate1 has the 1.10 signature (its callback gets the H5L_info1_t this binding ignores anyway)
+        it = getattr(L, "H5Literate", None) or getattr(L, "H5Literate1", None)
+        if it is None:
+            raise ImportError(f"libhdf5 {maj.value}.{mnr.value}.{rel.value} exports neither H5Literate nor H5Literate1")
+        it.restype, it.argtypes = c_int, [hid_t, c_int, c_int, POINTER(c_ulonglong), c_void_p, c_void_p]
+        L._mmf_iterate = it
         _lib = L
     return _lib
 
@@ -89,7 +101,7 @@ def _links(loc: int) -> List[str]:
         return 0
 
     idx = c_ulonglong(0)
-    if lib().H5Literate(loc, H5_INDEX_NAME, H5_ITER_INC, ctypes.byref(idx), ctypes.cast(_ITER_CB(cb), c_void_p), None) < 0:
+    if lib()._mmf_iterate(loc, H5_INDEX_NAME, H5_ITER_INC, ctypes.byref(idx), ctypes.cast(_ITER_CB(cb), c_void_p), None) < 0:
         raise OSError("H5Literate failed")
     return names
 
@@ -99,6 +111,7 @@ def _read_dataset(loc: int, name: str) -> np.ndarray:
     d = L.H5Dopen2(loc, name.encode(), 0)
     if d < 0:
         raise OSError(f"{name}: not a dataset")
+    space = ftype = mtype = -1
     try:
         space, ftype = L.H5Dget_space(d), L.H5Dget_type(d)
         nd = L.H5Sget_simple_extent_ndims(space)
@@ -116,9 +129,14 @@ def _read_dataset(loc: int, name: str) -> np.ndarray:
         out = np.empty(tuple(int(x) for x in dims[:nd]), dtype=dtype)
         if L.H5Dread(d, mtype, 0, 0, 0, out.ctypes.data_as(c_void_p)) < 0:
             raise OSError(f"{name}: H5Dread failed")
-        L.H5Tclose(mtype); L.H5Tclose(ftype); L.H5Sclose(space)
         return out
-    finally:
+    finally:  # every id, on the error paths too
+        if mtype >= 0:
+            L.H5Tclose(mtype)
+        if ftype >= 0:
+            L.H5Tclose(ftype)
+        if space >= 0:
+            L.H5Sclose(space)
         L.H5Dclose(d)
 
 

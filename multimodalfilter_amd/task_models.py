@@ -630,9 +630,43 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             self.weighted_covariances = Sigma
             return mu
 
-        def _native_plan(self, encs, T, N):
-            # the blackout branch is chosen per step by a batch-global test on the data (Q2)
-            return None if self.know_image_blackout else super()._native_plan(encs, T, N)
+        def _native_plan(self, encs, T, N, observations=None):
+            """With ``know_image_blackout`` the reference picks its branch per step by a BATCH-GLOBAL test on the
+            data (``door_models/crossmodal_kf.py:59-62``, Q2): no blacked-out frame in the batch (or a masked
+            modality) -> the base class's step; otherwise blackout weights and NO write-back.  Both are the same
+            K5 + K3 sequence: the blackout weights of a step without dark frames ARE the raw weights
+            (``0 * 1e-9 + 1 * w`` exactly), so the only thing the branch decides is the write-back -- a device
+            word per step that K3 reads (``MmfEkfLoopArgs.feedback_gate``); nothing is read back per step."""
+            plan = super()._native_plan(encs, T, N, observations)
+            on = self._enabled_models
+            if not self.know_image_blackout or observations is None or np.sum(on) < len(on):
+                return plan
+            fusion, feedback, w = plan
+            image = observations["image"]
+            dark = blackout_rows(image.reshape((T * N,) + tuple(image.shape[2:]))).view(T, N)
+            keep = (~dark).to(torch.float32)[:, None, :, None]
+            drk = dark.to(torch.float32)[:, None, :, None]
+            beta = torch.tensor([1e-9, 1.0 - 1e-9], dtype=torch.float32, device=w.device).view(1, 2, 1, 1)
+            w = drk * beta + keep * w                       # (T, 2, N, d): _blackout_weights for every step at once
+            self._loop_any_dark = dark.any(dim=1)           # (T,) bool, device: read ONCE after the loop (inert attributes)
+            gate = (~self._loop_any_dark).to(torch.int32).contiguous()
+            return fusion, feedback, w, gate
+
+        def _after_native_loop(self, estimates, Sigma_f):
+            any_dark = getattr(self, "_loop_any_dark", None)
+            self._loop_any_dark = None
+            if any_dark is None:
+                return super()._after_native_loop(estimates, Sigma_f)
+            # states_prev / states_covariance_prev are set by the base class's step only (inert: Q1); the blackout
+            # branch leaves them alone -- they keep what the last step WITHOUT a dark frame assigned
+            self.weighted_covariances = Sigma_f
+            plain = torch.nonzero(~any_dark).flatten()      # one device -> host read per loop, after it is enqueued
+            if plain.numel():
+                last = int(plain[-1])
+                for f in self.filter_models:
+                    f.states_prev = estimates[last]
+                    f.states_covariance_prev = Sigma_f if last == estimates.shape[0] - 1 else None
+            return estimates
 
         def _forward_encoded(self, observations, controls, enc, ctrl):
             if not self.know_image_blackout:

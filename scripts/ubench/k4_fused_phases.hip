@@ -48,9 +48,9 @@ int main(int argc, char** argv) {
     float tA = 0, tB = 0, tC = 0; const int reps = 5;
     for (int rep = 0; rep < reps + 2; ++rep) {
       hipEventRecord(ev[0]);
-      fa.out = bufA; launch_fused(fa, nets, 0, bf, nullptr);
+      fa.out = bufA; launch_fused(fa, nets, 0, bf, fused_flavour(), nullptr);
       hipEventRecord(ev[1]);
-      fa.bin = bufA; fa.out = bufB; launch_fused(fa, nets, 1, bf, nullptr);
+      fa.bin = bufA; fa.out = bufB; launch_fused(fa, nets, 1, bf, fused_flavour(), nullptr);
       hipEventRecord(ev[2]);
       c4.din = reinterpret_cast<const unsigned char*>(bufB); c4.out = bufC; launch_conv4(c4, nets, nullptr);
       hipEventRecord(ev[3]); hipDeviceSynchronize();

@@ -175,3 +175,97 @@ def test_bench_launcher_propagates_a_failing_rank():
     r = _run_bench({"MMF_BENCH_DRY": "fail1", "MMF_DIST_BACKEND": "gloo"}, "--gpus", "2")
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.timeout(600)
+def test_bench_eight_rank_preflight_strong_scaling_shards():
+    """The command the driver will run on an 8-GPU node for BASELINE config 4, rehearsed with 8 gloo ranks and no GPU
+    work (``MMF_BENCH_DRY``): ``launch_ranks`` spawns 8 children, they rendezvous, and the 8192 trajectories are cut
+    into 8 contiguous shards of 1024; the weak-scaling default reports 8 x 256.  (No scaling curve has been
+    measured on hardware: the pool gives this builder one GPU -- DESIGN.md section 6.)"""
+    import json
+
+    r = _run_bench({"MMF_BENCH_DRY": "1", "MMF_DIST_BACKEND": "gloo", "OMP_NUM_THREADS": "1"}, "--gpus", "8", "--steps", "4",
+                   "--warmup", "1", "--workload", "door_ekf", "--global-batch", "8192")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["world_size_seen"] == 8 and out["scaling"] == "strong"
+    assert out["gathered_rows"] == sum(range(1, 9)) and out["max_over_ranks"] == 7.0
+    shards = sorted(out["shards"])
+    assert [s[0] for s in shards] == list(range(8))
+    assert shards[0][1] == 0 and shards[-1][2] == 8192
+    assert all(a[2] == b[1] for a, b in zip(shards, shards[1:])) and all(s[2] - s[1] == 1024 for s in shards)
+    r = _run_bench({"MMF_BENCH_DRY": "1", "MMF_DIST_BACKEND": "gloo", "OMP_NUM_THREADS": "1"}, "--gpus", "8")
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "weak" and out["global_batch"] == 8 * 256 and out["workload"] == "door_pf"
+
+
+class _OracleCounterNoise:
+    """The oracle-side twin of ``multimodalfilter_amd.utils.CounterNoise``: every draw is a pure function of
+    (seed, step, GLOBAL trajectory index, particle), restated on the CPU by ``oracle.strict`` (bit for bit the
+    generator of ``include/mmf_philox.h``)."""
+
+    def __init__(self, seed, traj_offset=0):
+        self.seed, self.traj_offset, self.step_g, self.step_u = seed, traj_offset, 0, 0
+
+    def gaussian(self, shape, *, like=None):
+        from oracle import strict
+
+        N, M, d = shape
+        out = torch.from_numpy(strict.philox_normals(self.seed, self.step_g, N, M, d, traj0=self.traj_offset))
+        self.step_g += 1
+        return out
+
+    def uniform(self, shape, *, like=None):
+        from oracle import strict
+
+        out = torch.from_numpy(strict.philox_uniforms(self.seed, self.step_u, 1, shape[0], traj0=self.traj_offset))[0]
+        self.step_u += 1
+        return out
+
+
+def test_counter_noise_makes_an_eight_way_sharded_filter_equal_the_single_process_run():
+    """Weak / strong scaling shards the trajectory axis; with counter-based noise keyed by the GLOBAL trajectory
+    index (``CounterNoise(traj_offset=...)``) shard r of an 8-way run draws exactly what trajectories
+    ``[lo, hi)`` of the single-process run draw -- the draws themselves are compared bit for bit -- so the sharded
+    particle filter reproduces the unsharded one (CPU oracle as the per-rank filter: its torch GEMMs round
+    differently for different batch sizes, hence 1e-5 on the estimates; on the HIP engine, whose rows do not
+    depend on their batch position, ``tests/test_gpu_strict.py::test_counter_noise_*`` has a shard equal its
+    slice of the batch in every bit)."""
+    from oracle import models as om
+    from oracle import strict
+
+    if not strict.available():
+        pytest.skip("oracle/strict needs gcc")
+    torch.set_num_threads(2)
+    N, T, M, d, world = 11, 3, 24, 2, 8   # ragged: shards of 2 and 1 trajectories
+    traj = synthetic.make_trajectories(state_dim=d, T=T, N=N, seed=19)
+
+    def run(tr, offset):
+        f = om.build("PushUnimodalParticleFilter")
+        f.load_state_dict(om.seeded_state_dict(f, seed=5, gain=1.0))
+        f.eval()
+        f.num_particles = M
+        f.noise = _OracleCounterNoise(4711, traj_offset=offset)
+        n = tr["states"].shape[1]
+        cov = (torch.eye(d) * 0.1)[None].expand(n, d, d)
+        with torch.no_grad():
+            f.initialize_beliefs(mean=tr["states"][0], covariance=cov)
+            return f.forward_loop(observations={k: tr[k][1:] for k in ("image", "gripper_pos", "gripper_sensors")},
+                                  controls=tr["controls"][1:])
+
+    whole = run(traj, 0)
+    parts = []
+    for r in range(world):
+        lo, hi = distributed.shard_bounds(N, r, world)
+        parts.append(run(distributed.shard_trajectories(traj, r, world), lo))
+        # the shard's draws ARE the global run's draws for its trajectories: Gaussians of every step, resampling uniforms
+        for step in range(T + 1):
+            a = strict.philox_normals(4711, step, hi - lo, M, d, traj0=lo)
+            b = strict.philox_normals(4711, step, N, M, d, traj0=0)[lo:hi]
+            assert np.array_equal(a, b)
+        assert np.array_equal(strict.philox_uniforms(4711, 0, T, hi - lo, traj0=lo), strict.philox_uniforms(4711, 0, T, N, traj0=0)[:, lo:hi])
+    torch.testing.assert_close(torch.cat(parts, dim=1), whole, rtol=0, atol=1e-5)

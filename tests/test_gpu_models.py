@@ -264,11 +264,16 @@ def test_kalman_filters_track_oracle(tname, cls, okw):
         assert float((fe._belief_covariance.cpu() - fo._belief_covariance).abs().max()) / s < REL_TOL
 
 
-@pytest.mark.parametrize("resample,T", [(False, 3), (False, 4), (True, 1), (True, 4)])
-def test_native_step_loop_equals_stepwise(resample, T):
+@pytest.mark.parametrize("resample,T,alpha,method", [
+    (False, 3, 1.0, "weighted_average"), (False, 4, 1.0, "weighted_average"), (True, 1, 1.0, "weighted_average"),
+    (True, 4, 1.0, "weighted_average"),
+    # round 4: torchfilter's other two options run inside the native loop too (they kept the Python loop before)
+    (True, 4, 0.5, "weighted_average"), (True, 3, 0.7, "argmax"), (True, 4, 1.0, "argmax"), (False, 3, 1.0, "argmax")])
+def test_native_step_loop_equals_stepwise(resample, T, alpha, method):
     """``mmf_pf_forward_loop`` (C host loop) against T separate ``forward`` calls on the same
     pre-drawn randomness: estimates and the final belief are identical bits, whichever of the
-    ping-pong buffers the belief ends in (odd / even T, with and without resampling)."""
+    ping-pong buffers the belief ends in (odd / even T, with and without resampling; plain and soft
+    resampling; weighted-average and arg-max estimates)."""
     _need_gpu()
     import multimodalfilter_amd as mmf
 
@@ -284,18 +289,28 @@ def test_native_step_loop_equals_stepwise(resample, T):
     eps0 = torch.randn((N, M, d), generator=g).to(dev)
     eps = torch.randn((T, N, M, d), generator=g).to(dev)
     us = torch.rand((T, N), generator=g).to(dev)
+    from multimodalfilter_amd import _abi
+
     f = mmf.door_models.DoorCrossmodalParticleFilter().to(dev).eval()
     f.num_particles = M
     f.resample = resample
+    f.soft_resample_alpha, f.estimation_method = alpha, method
 
     f.noise = mmf.StackedNoise(eps0, eps, us)
     f.initialize_beliefs(mean=x0, covariance=cov)
     step = torch.stack([f(observations={k: v[t] for k, v in obs.items()}, controls=ctrl[t]) for t in range(T)])
     s_ref, w_ref = f.particle_states.clone(), f.particle_log_weights.clone()
 
-    f.noise = mmf.StackedNoise(eps0, eps, us)
-    f.initialize_beliefs(mean=x0, covariance=cov)
-    loop = f.forward_loop(observations=obs, controls=ctrl)
+    calls = []
+    real = _abi.pf_forward_loop
+    _abi.pf_forward_loop = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        f.noise = mmf.StackedNoise(eps0, eps, us)
+        f.initialize_beliefs(mean=x0, covariance=cov)
+        loop = f.forward_loop(observations=obs, controls=ctrl)
+    finally:
+        _abi.pf_forward_loop = real
+    assert calls, "the fused particle filter must take the native step loop"
     assert torch.equal(loop, step)
     assert torch.equal(f.particle_states, s_ref) and torch.equal(f.particle_log_weights, w_ref)
     # the belief stays usable for further single steps
@@ -311,10 +326,17 @@ def test_native_step_loop_equals_stepwise(resample, T):
     ("PushCrossmodalKalmanFilter", {}, True),
     ("DoorUnimodalKalmanFilter", {}, False),
     ("PushUnimodalKalmanFilter", {}, True),
+    # the blackout override (door_models/crossmodal_kf.py:43-98): the batch-global branch is a device word per step
+    ("DoorCrossmodalKalmanFilter", {"know_image_blackout": True}, False),
+    ("DoorCrossmodalKalmanFilter", {"know_image_blackout": True, "feedback": "belief"}, False),
+    ("PushCrossmodalKalmanFilter", {"know_image_blackout": True, "feedback": "belief", "fix_weight_layout": True}, False),
+    ("DoorCrossmodalKalmanFilter", {"know_image_blackout": True}, True),
 ])
 def test_native_ekf_loop_equals_stepwise(cls, kw, masked):
     """``mmf_ekf_forward_loop`` (C host loop over K5 + K3) against T separate ``forward``
-    calls: estimates, sub-filter beliefs and the fused covariance are identical bits."""
+    calls: estimates, sub-filter beliefs and the fused covariance are identical bits.  With
+    ``know_image_blackout`` the sequence mixes steps with and without blacked-out frames (steps 1 and 3 have
+    some, the others none), so both branches of the reference's batch-global test are taken inside one loop."""
     _need_gpu()
     import multimodalfilter_amd as mmf
     from multimodalfilter_amd import _abi
@@ -329,6 +351,10 @@ def test_native_ekf_loop_equals_stepwise(cls, kw, masked):
     ctrl = torch.randn((T, N, 7), generator=g).to(dev)
     x0 = torch.randn((N, d), generator=g).to(dev)
     cov = (torch.eye(d) * 0.1)[None].expand(N, d, d).to(dev)
+    if kw.get("know_image_blackout"):
+        obs["image"][1, 2] = 0.0
+        obs["image"][3, 0] = 0.0
+        obs["image"][3, 5] = 0.0
     f = mmf.model_types(tname)[cls](**kw).to(dev).eval()
     if masked:
         f.enabled_models = [False, True]

@@ -61,6 +61,55 @@ def _compare_grads(oracle, engine_model, loss_o, loss_e, min_checked=20):
     assert checked > min_checked
 
 
+def test_trainable_process_noise_gets_its_gradient(training_backend):
+    """the native training recursion (``PfTrainLoopFunction``) returns no gradient for the process-noise
+    factor, which is right for the reference's frozen Q only.  With ``Q_scale_tril_diag.requires_grad`` flipped the
+    filter must fall back to the step-by-step loop, and the gradient of Q equals the oracle's."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine
+
+    dev = torch.device("cuda:0")
+    task = om.TASKS["door"]
+    d, T, N, M = task.state_dim, 3, 4, 30
+    obs, ctrl, x0, target, g = _data(task, T, N, 23)
+    eps0 = torch.randn((N, M, d), generator=g)
+    eps = [torch.randn((N, M, d), generator=g) for _ in range(T)]
+    cov = (torch.eye(d) * 0.1)[None].expand(N, d, d)
+
+    oracle = om.ParticleFilter(task, "crossmodal")
+    oracle.load_state_dict(om.seeded_state_dict(oracle, seed=9, gain=1.0))
+    oracle.train()
+    oracle.num_particles = M
+    oracle.dynamics_model.Q_scale_tril_diag.requires_grad_(True)
+    oracle.noise = ReplayNoise([eps0] + eps, [])
+    oracle.initialize_beliefs(mean=x0, covariance=cov)
+    loss_o = torch.mean((oracle.forward_loop(observations=obs, controls=ctrl) - target) ** 2)
+    loss_o.backward()
+
+    eng = mmf.model_types("door")["DoorCrossmodalParticleFilter"]()
+    eng.load_state_dict(oracle.state_dict())
+    eng.to(dev).train()
+    eng.num_particles = M
+    eng.dynamics_model.Q_scale_tril_diag.requires_grad_(True)
+    eng.noise = mmf.ReplayNoise([eps0] + eps, [])
+    eng.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
+    loops = []
+    real_loop = engine.PfTrainLoopFunction.apply
+    engine.PfTrainLoopFunction.apply = lambda *a: (loops.append(1), real_loop(*a))[1]
+    try:
+        pred = eng.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
+    finally:
+        engine.PfTrainLoopFunction.apply = real_loop
+    assert not loops, "a trainable Q must not take the native recursion (it has no gradient for Q)"
+    loss_e = torch.mean((pred - target.to(dev)) ** 2)
+    loss_e.backward()
+    gq_o = oracle.dynamics_model.Q_scale_tril_diag.grad
+    gq_e = eng.dynamics_model.Q_scale_tril_diag.grad
+    assert gq_e is not None and float(gq_o.abs().max()) > 0
+    assert float((gq_e.cpu() - gq_o).abs().max()) / float(gq_o.abs().max()) < GRAD_TOL
+    assert abs(float(loss_e) - float(loss_o)) < 1e-4 * max(1.0, abs(float(loss_o)))
+
+
 @pytest.mark.parametrize("tname,cls,kind,N,M", [("door", "DoorCrossmodalParticleFilter", "crossmodal", 4, 30),
                                                 ("push", "PushUnimodalParticleFilter", "unimodal", 4, 30),
                                                 # config 5's particle count against the CPU oracle itself

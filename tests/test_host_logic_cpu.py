@@ -40,7 +40,7 @@ def test_stacked_noise_checks_shapes():
 def test_loop_argument_structs_match_the_header():
     """Field order / sizes of the host structs handed to the native step loops."""
     P, I = ctypes.sizeof(ctypes.c_void_p), 4
-    assert ctypes.sizeof(_abi.MmfEkfLoopArgs) == 8 * I + (2 * _abi.LOOP_MAX_MEAS + 11) * P
+    assert ctypes.sizeof(_abi.MmfEkfLoopArgs) == 8 * I + (2 * _abi.LOOP_MAX_MEAS + 12) * P  # + feedback_gate (ABI 33)
     pf = _abi.MmfPfLoopArgs
     assert pf.T.offset == 0 and pf.dyn_packed.offset == 10 * I
     assert pf.event_stride.offset + I <= ctypes.sizeof(pf)
