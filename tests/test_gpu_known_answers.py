@@ -431,7 +431,7 @@ def test_tracking_calibration_holds_the_ess_band(tracking_door_case):
     dev = _dev()
     B, K = bench.BURN_IN, 48
     print("calibration trace (factor, steady-state ESS/M):", c["trace"])
-    assert 0.18 <= c["trace"][-1][1] <= 0.34, c["trace"]
+    assert c["trace"][-1][0] == "all heads" and 0.2 <= c["trace"][-1][2] <= 0.31, c["trace"]
     traj = bench.to_device(synthetic.make_trajectories(state_dim=c["d"], T=B + K, N=c["N"], seed=1234), dev)
     run = bench.FilterRun(c["f"], traj, bench.device_noise(B + K, c["N"], c["M"], c["d"], 99, dev), particles=c["M"])
     burn_ess, ess = bench.engine_ess(run, [(0, B), (B, B + K)])
@@ -446,8 +446,13 @@ def test_tracking_calibration_holds_the_ess_band(tracking_door_case):
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 def test_tracking_regime_teacher_forced_certificate(tracking_door_case, precision):
     """The mismatch certificate RE-TAKEN in the weight regime the bench now times (ESS/M ~ 0.25 throughout, not the
-    0.9 round 3 drifted to: peaked weights put more resampling positions near CDF boundaries).  Teacher-forced on the
-    12 steps behind the oracle's burn-in: posterior means within 1e-4, every differing ancestor certified."""
+    0.9 round 3 drifted to).  Holding the band on a CONTRACTED cloud takes heads ~80x the random-init scale, so
+    log-likelihoods are O(10..100) and the last-ulp differences of two fp32 summation orders (engine vs torch oracle)
+    move the fixed-point weights by 1e-4 .. 3e-4 of their total (``max_D_over_Q``; round 3's flat regime: 2e-5) and
+    2e-3 .. 3e-3 of the ancestors across CDF boundaries (measured f32 2.7e-3; hops cross runs of zero-weight
+    particles, hence ``max_hop`` in the tens).  What is asserted: teacher-forced on the 12 steps behind the oracle's
+    burn-in the posterior means agree within 1e-4 (measured <= 2.6e-5), K1 is exact on its own input, and EVERY
+    differing ancestor lies inside its certificate band (zero unexplained)."""
     import bench
     from multimodalfilter_amd import engine
 
@@ -461,11 +466,11 @@ def test_tracking_regime_teacher_forced_certificate(tracking_door_case, precisio
     print(precision, r)
     assert len(r["max_rel_err_posterior_mean_per_step"]) == c["T"] - c["burn"]
     assert r["max_rel_err_posterior_mean"] < REL_TOL, r["max_rel_err_posterior_mean_per_step"]
-    assert r["resample_index_mismatch_fraction"] < 2e-3, r["resample_index_mismatches_per_step"]
+    assert r["resample_index_mismatch_fraction"] < 1e-2, r["resample_index_mismatches_per_step"]
     cert = r["mismatch_certificate"]
     assert cert["k1_inexact_on_own_weights"] == 0, cert
     assert cert["unexplained"] == 0, cert
-    assert cert["max_D_over_Q"] < 1e-4, cert
+    assert cert["max_D_over_Q"] < 1e-3, cert
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
