@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 33
+ABI_VERSION = 34
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
@@ -67,7 +67,8 @@ class MmfPfLoopArgs(Structure):
                 ("event_stride", c_int32), ("loglik_steps", _FP), ("indices_steps", _FP),
                 ("noise_seed", ctypes.c_uint64), ("noise_step0", ctypes.c_uint32), ("noise_traj0", ctypes.c_uint32),
                 ("noise_mode", c_int32), ("use_graph", c_int32), ("measure_seq", c_int32),
-                ("soft_alpha", ctypes.c_float), ("estimate_argmax", c_int32), ("estimate_scratch", _FP)]
+                ("soft_alpha", ctypes.c_float), ("estimate_argmax", c_int32), ("estimate_scratch", _FP),
+                ("persistent", c_int32), ("n_sync_words", c_int32), ("sync_words", _FP), ("ll_modal", _FP)]
 
 
 class MmfTrainNet(Structure):
@@ -125,6 +126,8 @@ SIGNATURES = {
     "mmf_pf_init_particles": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_forward_loop": (c_int, [POINTER(MmfPfLoopArgs), c_void_p]),
     "mmf_pf_argmax_estimate": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
+    "mmf_pf_persistent_plan": (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "mmf_pf_persistent_sync_words": (c_size_t, [c_int, c_int]),
     "mmf_loop_graphs_release": (None, []),
     "mmf_pf_dynamics_philox": (c_int, [_FP, c_int, c_int, _FP, _FP, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
                                        _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
@@ -304,6 +307,15 @@ def dynamics_jacobian(packed, n_res, precision, states_in, traj_bias, states_out
         _check(load().mmf_dynamics_jacobian(ptr(packed), n_res, precision, ptr(states_in), ptr(traj_bias),
                                             ptr(states_out), ptr(jac), ptr(range_flag, dtype=torch.int32), N, d,
                                             stream_of(states_in)), "mmf_dynamics_jacobian")
+
+
+def pf_persistent_plan(N: int, M: int, n_meas: int) -> int:
+    """Workgroups the persistent step loop would use for this problem; <= 0: not eligible (include/mmf.h)."""
+    return int(load().mmf_pf_persistent_plan(N, M, n_meas, None, None, None))
+
+
+def pf_persistent_sync_words(N: int, M: int) -> int:
+    return int(load().mmf_pf_persistent_sync_words(N, M))
 
 
 def pf_argmax_estimate(loglik, logw_in, states, estimate):

@@ -13,6 +13,10 @@
     if (_e != hipSuccess) return static_cast<int>(_e); \
   } while (0)
 
+// the persistent small-problem step loop (pf_persistent.inc, compiled with particle_net.hip); reached through
+// mmf_pf_forward_loop when MmfPfLoopArgs.persistent is set
+int mmf_internal_pf_persistent(const MmfPfLoopArgs* args, void* stream);
+
 namespace mmf {
 
 // ---- wave-wide reductions and scans on DPP (row / bank data paths of the VALU) instead of ds_bpermute:

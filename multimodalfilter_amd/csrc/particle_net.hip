@@ -23,6 +23,10 @@
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
 #include <utility>
 
 #include "mmf_common.h"
@@ -1118,3 +1122,4 @@ extern "C" int mmf_dynamics_jacobian_multi(const float* const* packed, int n_res
 }
 
 #include "particle_net_train.inc"
+#include "pf_persistent.inc"

@@ -172,6 +172,7 @@ int run_as_graph(hipStream_t hs, F&& enqueue) {
 }  // namespace
 
 extern "C" int mmf_pf_forward_loop(const MmfPfLoopArgs* a, void* stream) {
+  if (a && a->persistent) return mmf_internal_pf_persistent(a, stream);  // ONE launch for all T steps (small problems)
   if (a && a->use_graph && !a->events)
     return run_as_graph(static_cast<hipStream_t>(stream), [&](void* cs) { return pf_enqueue_steps(a, cs, false); });
   return pf_enqueue_steps(a, stream, true);

@@ -14,6 +14,7 @@
 #include <cmath>
 
 #include "mmf_common.h"
+#include "../../include/mmf_detmath.h"
 
 // Phase stamps for scripts/ubench/k1_phases.hip (compiled out of the library): thread 0 of every
 // workgroup stores s_memtime at phase boundaries into a buffer of its own.
@@ -31,18 +32,14 @@ __device__ unsigned long long g_k1_stamps[1024][8];
 #define K1_STAMP(i)
 #endif
 
+#include "pf_resample_systematic.inc"
+
 namespace {
 
-constexpr int kBlock = 1024;  // 16 waves; M = 4096 -> one float4 chunk per thread
-constexpr int kMaxWaves = kBlock / MMF_WAVE;
-constexpr int kFixBits = 24;
-
-struct Scratch {  // lives behind the slots in dynamic LDS
-  float red[kMaxWaves][MMF_MAX_STATE_DIM + 1];
-  unsigned long long wave_tot[kMaxWaves];
-  float bcast[MMF_MAX_STATE_DIM + 2];
-  unsigned wave_cnt[kMaxWaves];
-};
+constexpr int kBlock = mmf::kK1Block;  // 16 waves; M = 4096 -> one float4 chunk per thread
+constexpr int kMaxWaves = mmf::kK1MaxWaves;
+constexpr int kFixBits = mmf::kK1FixBits;
+using Scratch = mmf::K1Scratch;  // lives behind the slots in dynamic LDS
 
 // STAGE: the particle states are kept in LDS next to the CDF (M * 4D more bytes), so the gather
 // of the resampling step reads LDS instead of going back to L2 / HBM for rows this workgroup
@@ -391,260 +388,26 @@ __global__ __launch_bounds__(kBlock) void pf_reweight_resample_kernel(
 }
 
 
-// ---- plain systematic resampling WITHOUT a search (the bench's and the reference's evaluation mode).
-// Same fixed-point definition (oracle/resample.py), evaluated from the input side: particle i is the
-// ancestor of the outputs k with cdf_{i-1} <= p_k < cdf_i, and since p_k = (k Q + R) // M_out is
-// non-decreasing, #{k : p_k < cdf_i} = k_end(i) = ceil((cdf_i M_out - R) / Q) (0 when cdf_i M_out <= R,
-// at most M_out).  So:  marks[k_end(i)] += 1  (LDS atomics; particles whose k_end is M_out have no later
-// output to influence),  ancestor(k) = #{i : k_end(i) <= k} = inclusive prefix sum of marks  (one more block
-// scan, on DPP).  No dependent chain of LDS reads per output (the bisection / galloping search was a third
-// of the kernel, a constant ~73 of ~230 stamp units whatever M: scripts/ubench/k1_phases.hip), and a thread
-// needs only the CDF entries of its own four particles, which it still holds in registers.
+// ---- plain systematic resampling WITHOUT a search (the bench's and the reference's evaluation mode): the body is
+// mmf::resample_systematic_trajectory (pf_resample_systematic.inc, shared with the persistent small-problem loop)
 template <int D, bool STAGE>
 __global__ __launch_bounds__(kBlock) void pf_resample_systematic_kernel(
     const float* __restrict__ loglik, const float* __restrict__ logw_in, const float* __restrict__ states_in,
     const float* __restrict__ u, float* __restrict__ estimate, float* states_out, float* logw_out,
     int32_t* __restrict__ indices_out, int M, int M_out, float lw_uniform, float log_uniform) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const size_t slots_sz = (static_cast<size_t>(M) * 8 + 15) & ~static_cast<size_t>(15);
-  unsigned long long* cdf = reinterpret_cast<unsigned long long*>(smem);  // first the fp32 x_i, then the u64 CDF
-  Scratch& sc = *reinterpret_cast<Scratch*>(smem + slots_sz);
-  const size_t sc_sz = (sizeof(Scratch) + 15) & ~static_cast<size_t>(15);
-  unsigned* marks = reinterpret_cast<unsigned*>(smem + slots_sz + sc_sz);                       // [M_out + 4]
-  const size_t marks_sz = ((static_cast<size_t>(M_out) + 4) * 4 + 15) & ~static_cast<size_t>(15);
-  float* xs_lds = reinterpret_cast<float*>(smem + slots_sz + sc_sz + marks_sz);                 // STAGE: [M][D]
-
-  const int n = blockIdx.x, tid = threadIdx.x;
-  const int lane = tid & (MMF_WAVE - 1), wave = tid >> 6, nwaves = blockDim.x >> 6;
-  const int chunk = blockDim.x * 4;
-  const float* ll = loglik + static_cast<size_t>(n) * M;
-  const float* lw = logw_in ? logw_in + static_cast<size_t>(n) * M : nullptr;
-  const float* xs = states_in + static_cast<size_t>(n) * M * D;
-  const bool vec = (M & 3) == 0;
-  K1_STAMP(0);
-
-  // first chunk's states in flight before anything waits; marks cleared (ordered by pass 1's barriers)
-  float st0[4 * D];
-  {
-    const int i0 = tid * 4;
-    if (vec && i0 + 3 < M) {
-      const float4* p = reinterpret_cast<const float4*>(xs + static_cast<size_t>(i0) * D);
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        const float4 t = p[k];
-        st0[4 * k] = t.x; st0[4 * k + 1] = t.y; st0[4 * k + 2] = t.z; st0[4 * k + 3] = t.w;
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4 * D; ++k) st0[k] = (i0 * D + k < M * D) ? xs[static_cast<size_t>(i0) * D + k] : 0.f;
-    }
-  }
-  for (int k = tid; k < M_out + 4; k += blockDim.x) marks[k] = 0u;
-
-  // ---- pass 1: x_i = logw_i + loglik_i -> LDS, row max
-  float mx = -INFINITY;
-  for (int base = 0; base < M; base += chunk) {
-    const int i0 = base + tid * 4;
-    float v[4];
-    if (vec && i0 + 3 < M) {
-      const float4 a = *reinterpret_cast<const float4*>(ll + i0);
-      const float4 b = lw ? *reinterpret_cast<const float4*>(lw + i0) : make_float4(lw_uniform, lw_uniform, lw_uniform, lw_uniform);
-      v[0] = b.x + a.x; v[1] = b.y + a.y; v[2] = b.z + a.z; v[3] = b.w + a.w;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = (i0 + j < M) ? (lw ? lw[i0 + j] : lw_uniform) + ll[i0 + j] : -INFINITY;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (i0 + j < M) { reinterpret_cast<float*>(cdf + i0 + j)[0] = v[j]; mx = fmaxf(mx, v[j]); }
-  }
-  mx = mmf::wave_max(mx);
-  if (lane == 0) sc.red[wave][0] = mx;
-  __syncthreads();
-  mx = sc.red[0][0];
-  for (int w = 1; w < nwaves; ++w) mx = fmaxf(mx, sc.red[w][0]);
-  __syncthreads();
-  K1_STAMP(1);
-
-  // ---- pass 2: e_i, fixed-point q_i, float sums of the estimate, integer CDF (kept in LDS for multi-chunk rows)
-  float S = 0.f, acc[D];
-#pragma unroll
-  for (int c = 0; c < D; ++c) acc[c] = 0.f;
-  unsigned long long carry = 0;
-  unsigned long long own[4] = {0, 0, 0, 0};  // CDF of this thread's particles in the LAST chunk
-  unsigned long long own_prev = 0;           // ... and of the particle just before them
-  for (int base = 0; base < M; base += chunk) {
-    const int i0 = base + tid * 4;
-    float e[4];
-    unsigned long long q[4], tsum = 0;
-    float st[4 * D];
-    if (base == 0) {
-#pragma unroll
-      for (int k = 0; k < 4 * D; ++k) st[k] = st0[k];
-    } else if (vec && i0 + 3 < M) {
-      const float4* p = reinterpret_cast<const float4*>(xs + static_cast<size_t>(i0) * D);
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        const float4 t = p[k];
-        st[4 * k] = t.x; st[4 * k + 1] = t.y; st[4 * k + 2] = t.z; st[4 * k + 3] = t.w;
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4 * D; ++k) st[k] = (i0 * D + k < M * D) ? xs[static_cast<size_t>(i0) * D + k] : 0.f;
-    }
-    if (STAGE) {
-#pragma unroll
-      for (int k = 0; k < 4 * D; ++k)
-        if (i0 * D + k < M * D) xs_lds[i0 * D + k] = st[k];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const bool ok = i0 + j < M;
-      e[j] = ok ? mmf::detexp(reinterpret_cast<const float*>(cdf + i0 + j)[0] - mx) : 0.f;
-      q[j] = static_cast<unsigned long long>(floorf(e[j] * 16777216.0f));
-      tsum += q[j];
-      S += e[j];
-#pragma unroll
-      for (int c = 0; c < D; ++c) acc[c] = __builtin_fmaf(e[j], st[j * D + c], acc[c]);  // explicit: oracle/strict restates this chain
-    }
-    const unsigned long long incl = mmf::wave_inclusive_scan(tsum, lane);
-    if (lane == MMF_WAVE - 1) sc.wave_tot[wave] = incl;
-    const bool last_chunk = base + chunk >= M;
-    if (last_chunk) {  // the float sums of the estimate ride on the last chunk's barriers
-      const float Sw = mmf::wave_sum(S);
-      float aw[D];
-#pragma unroll
-      for (int c = 0; c < D; ++c) aw[c] = mmf::wave_sum(acc[c]);
-      if (lane == 0) {
-        sc.red[wave][0] = Sw;
-#pragma unroll
-        for (int c = 0; c < D; ++c) sc.red[wave][1 + c] = aw[c];
-      }
-    }
-    __syncthreads();
-    if (last_chunk && tid <= D) {
-      float t = 0.f;
-      for (int w = 0; w < nwaves; ++w) t += sc.red[w][tid];
-      sc.bcast[tid] = t;
-    }
-    unsigned long long before = carry, total = 0;
-    for (int w = 0; w < nwaves; ++w) {
-      const unsigned long long t = sc.wave_tot[w];
-      if (w < wave) before += t;
-      total += t;
-    }
-    unsigned long long run = before + incl - tsum;
-    own_prev = run;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      run += q[j];
-      own[j] = run;
-      if (!last_chunk && i0 + j < M) cdf[i0 + j] = run;  // earlier chunks wait in LDS for Q
-    }
-    carry += total;
-    __syncthreads();
-  }
-  K1_STAMP(2);
-  const unsigned long long Q = carry;  // every thread has added every chunk's total
-  S = sc.bcast[0];
-  if (tid < D) estimate[static_cast<size_t>(n) * D + tid] = sc.bcast[1 + tid] / S;
-
-  // ---- offspring boundaries: the first particle of every run of equal k_end announces itself,
-  // marks[k_end(i - 1)] = i  when  k_end(i - 1) < k_end(i)  -- one writer per entry, plain LDS stores
-  {
-    const unsigned long long U = static_cast<unsigned long long>(floorf(u[n] * 16777216.0f));
-    const unsigned long long R = (U * Q) >> kFixBits;
-    const float rq = 1.0f / static_cast<float>(Q);
-    const unsigned long long Mo = static_cast<unsigned long long>(M_out);
-    // k_end(c) = #{k >= 0 : k Q + R < c M_out} = ceil((c M_out - R) / Q), at most M_out <= 2^15: a float32
-    // quotient is within 1 of the floor (relative error 2^-22 on a value below 2^15); ONE u64 multiply corrects it
-    auto k_end = [&](unsigned long long cdf_i) -> unsigned {
-      const unsigned long long c = cdf_i * Mo;
-      if (c <= R) return 0u;
-      const unsigned long long num = c - R;
-      const float numf = static_cast<float>(static_cast<unsigned>(num >> 32)) * 4294967296.0f + static_cast<float>(static_cast<unsigned>(num));
-      long long fl = static_cast<long long>(numf * rq);
-      long long rem = static_cast<long long>(num) - fl * static_cast<long long>(Q);
-      if (rem < 0) { --fl; rem += static_cast<long long>(Q); }
-      if (rem >= static_cast<long long>(Q)) { ++fl; rem -= static_cast<long long>(Q); }
-      const unsigned long long ke = static_cast<unsigned long long>(fl) + (rem > 0 ? 1u : 0u);
-      return static_cast<unsigned>(ke < Mo ? ke : Mo);
-    };
-    for (int base = 0; base < M; base += chunk) {
-      const int i0 = base + tid * 4;
-      if (i0 >= M) continue;
-      const bool last_chunk = base + chunk >= M;
-      unsigned long long c[5];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) c[j + 1] = last_chunk ? own[j] : cdf[i0 + j < M ? i0 + j : M - 1];
-      // CDF just before this thread's first particle: its own running sum before q[0] (last chunk), LDS otherwise
-      c[0] = last_chunk ? own_prev : (i0 == 0 ? 0ull : cdf[i0 - 1]);
-      unsigned ke[5];
-#pragma unroll
-      for (int j = 0; j < 5; ++j) ke[j] = k_end(c[j]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (i0 + j < M && ke[j] < ke[j + 1] && ke[j] < static_cast<unsigned>(M_out)) marks[ke[j]] = static_cast<unsigned>(i0 + j);
-    }
-  }
-  __syncthreads();
-
-  // ---- ancestor(k) = the latest announcement at or before k = inclusive prefix MAX of marks; gather; store
-  float* so = states_out + static_cast<size_t>(n) * M_out * D;
-  float* lo = logw_out ? logw_out + static_cast<size_t>(n) * M_out : nullptr;
-  int32_t* io = indices_out ? indices_out + static_cast<size_t>(n) * M_out : nullptr;
-  const bool vec_out = (M_out & 3) == 0;
-  unsigned carry2 = 0;
-  for (int base = 0; base < M_out; base += chunk) {
-    const int k0 = base + tid * 4;
-    unsigned m[4] = {0u, 0u, 0u, 0u};
-    if (k0 < M_out) {
-      const uint4 t = *reinterpret_cast<const uint4*>(marks + k0);  // marks is padded by 4 zero entries
-      m[0] = t.x; m[1] = t.y; m[2] = t.z; m[3] = t.w;
-    }
-    m[1] = max(m[1], m[0]); m[2] = max(m[2], m[1]); m[3] = max(m[3], m[2]);
-    const unsigned incl = mmf::wave_inclusive_scan_max_u32(m[3]);
-    if (lane == MMF_WAVE - 1) sc.wave_cnt[wave] = incl;
-    __syncthreads();
-    unsigned before = carry2, total = carry2;
-    for (int w = 0; w < nwaves; ++w) {
-      const unsigned t = sc.wave_cnt[w];
-      if (w < wave) before = max(before, t);
-      total = max(total, t);
-    }
-    carry2 = total;
-    // everything announced before this thread's first output: previous waves / chunks and the lanes below
-    const unsigned below = max(before, mmf::dpp_u32<mmf::kDppWaveShr1>(0u, incl));
-    int idx[4];
-    float g[4 * D];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      idx[j] = static_cast<int>(max(below, m[j]));
-      const int src = (k0 + j < M_out) ? idx[j] : 0;
-#pragma unroll
-      for (int c = 0; c < D; ++c) g[j * D + c] = STAGE ? xs_lds[src * D + c] : xs[static_cast<size_t>(src) * D + c];
-    }
-    if (vec_out && k0 + 3 < M_out) {
-      float4* p = reinterpret_cast<float4*>(so + static_cast<size_t>(k0) * D);
-#pragma unroll
-      for (int k = 0; k < D; ++k) p[k] = make_float4(g[4 * k], g[4 * k + 1], g[4 * k + 2], g[4 * k + 3]);
-      if (lo) *reinterpret_cast<float4*>(lo + k0) = make_float4(log_uniform, log_uniform, log_uniform, log_uniform);
-      if (io) *reinterpret_cast<int4*>(io + k0) = make_int4(idx[0], idx[1], idx[2], idx[3]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = k0 + j;
-        if (k < M_out) {
-#pragma unroll
-          for (int c = 0; c < D; ++c) so[static_cast<size_t>(k) * D + c] = g[j * D + c];
-          if (lo) lo[k] = log_uniform;
-          if (io) io[k] = idx[j];
-        }
-      }
-    }
-    if (base + chunk < M_out) __syncthreads();  // wave_cnt is reused by the next chunk
-  }
-  K1_STAMP(3);
+  const int n = blockIdx.x;
+  mmf::K1Trajectory a{};
+  a.ll[0] = loglik + static_cast<size_t>(n) * M;
+  a.n_ll = 1;
+  a.lw = logw_in ? logw_in + static_cast<size_t>(n) * M : nullptr;
+  a.xs = states_in + static_cast<size_t>(n) * M * D;
+  a.u = u[n];
+  a.estimate = estimate + static_cast<size_t>(n) * D;
+  a.so = states_out + static_cast<size_t>(n) * M_out * D;
+  a.lo = logw_out ? logw_out + static_cast<size_t>(n) * M_out : nullptr;
+  a.io = indices_out ? indices_out + static_cast<size_t>(n) * M_out : nullptr;
+  mmf::resample_systematic_trajectory<D, STAGE, false, false>(smem, a, M, M_out, lw_uniform, log_uniform);
 }
 
 }  // namespace

@@ -145,6 +145,10 @@ LOOP_GRAPH = os.environ.get("MMF_LOOP_GRAPH", "0") not in ("", "0")
 # workgroup-wide barrier between the two networks (every wave waits for the slowest before the weights are
 # re-staged) costs more than the launch boundary it removes.
 MEASURE_SEQ = os.environ.get("MMF_MEASURE_SEQ", "0") not in ("", "0")
+# Small particle-filter loops (mmf_pf_persistent_plan > 0: e.g. the reference's 32 x 300 evaluation) as ONE persistent
+# launch per forward_loop: role-specialised workgroups keep one network's weights in LDS for all T steps and hand the
+# particles over through L2 (csrc/pf_persistent.inc); bit-identical to the launch-per-step loop.  "0": A/B, off.
+PF_PERSISTENT = os.environ.get("MMF_PF_PERSISTENT", "1") not in ("", "0")
 
 
 # Training is opt-in: nothing switches paths silently, and eval() always means the forward-only HIP
@@ -191,7 +195,14 @@ def check_range(device):
     """Raise if any f16x3 launch since the last check saturated its operand split (one
     4-byte device->host read; filters call it once per ``forward_loop`` / on demand)."""
     flag = _RANGE_FLAGS.get(str(device))
-    if flag is not None and int(flag.item()) != 0:
+    bits = 0 if flag is None else int(flag.item())
+    if bits & 4:
+        flag.zero_()
+        raise _abi.MmfError(
+            "the persistent particle-filter loop gave up waiting for a hand-off (a workgroup of its launch was not "
+            "resident -- is another process using this GPU?): results of this forward_loop are invalid; "
+            "MMF_PF_PERSISTENT=0 selects the launch-per-step loop")
+    if bits != 0:
         flag.zero_()
         raise _abi.MmfError(
             "an activation exceeded the f16x3 operand range (|x| >= 65504): results of the last "

@@ -318,6 +318,73 @@ def test_native_step_loop_equals_stepwise(resample, T, alpha, method):
     f(observations={k: v[0] for k, v in obs.items()}, controls=ctrl[0])
 
 
+@pytest.mark.parametrize("cls,N,M,T,precision,noise", [
+    ("DoorCrossmodalParticleFilter", 32, 300, 9, "f16x3", "tensor"),    # the reference's evaluation size (door_models/pf.py:24-27)
+    ("DoorCrossmodalParticleFilter", 32, 300, 6, "f32", "tensor"),      # the bit-reproducible mode
+    ("PushCrossmodalParticleFilter", 7, 300, 5, "f16x3", "philox"),     # d = 2, counter-based noise
+    ("DoorUnimodalParticleFilter", 3, 1000, 4, "f16x3", "tensor"),      # two modalities, no weight model
+    ("DoorParticleFilter", 5, 77, 5, "f16x3", "tensor"),                # ONE network; ragged tiles (77 = 2 x 32 + 13)
+    ("DoorCrossmodalParticleFilterSeq5", 6, 2048, 3, "f16x3", "philox"),  # the largest M; blacked-out frames (-inf modality weights)
+])
+def test_persistent_step_loop_equals_loop_of_launches(cls, N, M, T, precision, noise):
+    """``mmf_pf_forward_loop`` with ``MmfPfLoopArgs.persistent`` (ONE launch for all T steps: role-specialised
+    workgroups, hand-offs through L2 -- csrc/pf_persistent.inc) against the same loop as launches: estimates of every
+    step and the final belief are identical BITS, in both arithmetic modes, for both noise sources, from a
+    non-uniform incoming belief (the first call follows a step without resampling), and twice in a row (the
+    hand-off words are re-initialised per call)."""
+    _need_gpu()
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import _abi, engine, synthetic
+
+    dev = torch.device("cuda:0")
+    tname = "door" if cls.startswith("Door") else "push"
+    d = om.TASKS[tname].state_dim
+    old_prec, old_persist = engine.DEFAULT_PRECISION, engine.PF_PERSISTENT
+    engine.set_default_precision(precision)
+    try:
+        torch.manual_seed(3)
+        f = mmf.model_types(tname)[cls]().to(dev).eval()
+        f.num_particles = M
+        traj = {k: v.to(dev) for k, v in synthetic.make_trajectories(
+            state_dim=d, T=T + 1, N=N, seed=17, image_blackout_ratio=0.4 if cls.endswith("Seq5") else 0.0).items()}
+        obs = {k: traj[k][1:] for k in ("image", "gripper_pos", "gripper_sensors")}
+        ctrl = traj["controls"][1:]
+        cov = (torch.eye(d, device=dev) * 0.1)[None].expand(N, d, d)
+        g = torch.Generator(device=dev).manual_seed(5)
+        eps0 = torch.randn((N, M, d), generator=g, device=dev)
+        eps = torch.randn((T + 3, N, M, d), generator=g, device=dev)   # 1 + T + 2 steps are drawn below
+        us = torch.rand((T + 3, N), generator=g, device=dev)
+
+        def run(persistent):
+            engine.PF_PERSISTENT = persistent
+            taken = []
+            real = _abi.pf_forward_loop
+            _abi.pf_forward_loop = lambda a, *r, **k: (taken.append(int(a.persistent)), real(a, *r, **k))[1]
+            try:
+                f.noise = mmf.CounterNoise(99) if noise == "philox" else mmf.StackedNoise(eps0, eps, us)
+                f.initialize_beliefs(mean=traj["states"][0], covariance=cov)
+                # one step WITHOUT resampling first: the loop then starts from non-uniform log-weights
+                f.resample = False
+                first = f.forward_loop(observations={k: v[:1] for k, v in obs.items()}, controls=ctrl[:1])
+                f.resample = None
+                a = f.forward_loop(observations={k: v[1:] for k, v in obs.items()}, controls=ctrl[1:])
+                s1, w1 = f.particle_states.clone(), f.particle_log_weights.clone()
+                b = f.forward_loop(observations={k: v[1:3] for k, v in obs.items()}, controls=ctrl[1:3])  # again: even T
+                return taken, first, a, s1, w1, b, f.particle_states.clone(), f.particle_log_weights.clone()
+            finally:
+                _abi.pf_forward_loop = real
+
+        ref = run(False)
+        got = run(True)
+        assert ref[0] == [0, 0, 0] and got[0] == [0, 1, 1], (ref[0], got[0])  # (the no-resampling step keeps the launches)
+        for x, y in zip(ref[1:], got[1:]):
+            assert torch.equal(x, y)
+        assert bool(torch.isfinite(got[2]).all())
+    finally:
+        engine.set_default_precision(old_prec)
+        engine.PF_PERSISTENT = old_persist
+
+
 @pytest.mark.parametrize("cls,kw,masked", [
     ("DoorKalmanFilter", {}, False),
     ("PushKalmanFilter", {}, False),
