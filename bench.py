@@ -459,6 +459,28 @@ def strict_parity(cls, engine_filter, traj, eps0, eps, us, M):
             "checker_seconds": round(time.perf_counter() - t0, 1)}
 
 
+def belief_independent_ms(f, traj, repeats=3):
+    """Milliseconds of the part of a particle filter's ``forward_loop`` that does not depend on the belief -- the
+    image encoders (K4) and the per-trajectory encoders / weight model / hoisted join-layer halves (K7) of all
+    ``T*N`` rows, evaluated once ahead of the recursion (``filters.ParticleFilter.forward_loop``) -- so that a loop's
+    time splits into `encoders` and `recursion`."""
+    obs = {k: traj[k][1:] for k in ("image", "gripper_pos", "gripper_sensors")}
+    ctrl = traj["controls"][1:]
+    T, N = ctrl.shape[:2]
+    flat = lambda x: x.reshape((T * N,) + tuple(x.shape[2:]))
+    best = None
+    with torch.no_grad():
+        for _ in range(repeats + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            f.measurement_model.encode_observations({k: flat(v) for k, v in obs.items()})
+            f.dynamics_model.encode_controls(flat(ctrl))
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+    return 1e3 * best
+
+
 def reference_sized_regimes(device):
     """The sizes the REFERENCE runs (scripts/bench_reference_sizes.py has the CPU twins): evaluation of the door
     crossmodal PF at 32 trajectories x 300 particles (``door_models/pf.py:24-27``, ``eval_helpers.py:125-142``)
@@ -485,7 +507,15 @@ def reference_sized_regimes(device):
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     best = min(times[1:])
-    out["eval_32x300"] = {"steps": T, "ms_per_step": 1e3 * best / T, "particle_steps_per_s": N * M * T / best}
+    enc_ms = belief_independent_ms(f, traj)
+    from multimodalfilter_amd import _abi, engine as _eng
+    out["eval_32x300"] = {"steps": T, "ms_per_step": 1e3 * best / T, "particle_steps_per_s": N * M * T / best,
+                          "encoders_ms_per_step": enc_ms / T, "recursion_ms_per_step": (1e3 * best - enc_ms) / T,
+                          "recursion": ("ONE persistent launch for all steps (csrc/pf_persistent.inc): role-specialised workgroups, "
+                                        "tagged-granule hand-offs through L2" if _eng.PF_PERSISTENT and _abi.pf_persistent_plan(N, M, 2) > 0
+                                        else "four launches per step (mmf_pf_forward_loop)"),
+                          "note": "ms_per_step = whole forward_loop / steps: image + vector encoders of all T*N frames (K4, K7: encoders_ms_per_step) "
+                                  "ahead of the recursion, then the recursion"}
     # --- training
     N, M, L = 32, 30, 16
     ft = mmf.door_models.DoorCrossmodalParticleFilter().to(device).train()

@@ -404,10 +404,9 @@ typedef struct MmfPfLoopArgs {
   int32_t persistent;        /* != 0: the whole loop as ONE persistent launch (small problems: mmf_pf_persistent_plan > 0; */
                              /* plain systematic resampling, weighted-average estimates, no events / per-step records).    */
                              /* Same results, bit for bit, as the launch-per-step loop.                                    */
-  int32_t n_sync_words;      /* entries of sync_words (>= mmf_pf_persistent_sync_words(N, M))                             */
-  uint32_t* sync_words;      /* persistent: device words of the in-launch hand-offs (zeroed by the call), an allocation    */
-                             /* of their own                                                                               */
-  float* ll_modal;           /* persistent: (n_meas, N, M) scratch, each modality's own log-likelihoods                    */
+  int32_t n_sync_words;      /* 4-byte words of sync_words (>= mmf_pf_persistent_sync_words(N, M, d, n_meas))              */
+  uint32_t* sync_words;      /* persistent: device workspace of the in-launch hand-offs -- tagged 8-byte granules of the   */
+                             /* particle rows and log-likelihoods --, zeroed by the call; an allocation of its own         */
 } MmfPfLoopArgs;             /* host struct holding device pointers                           */
 
 int mmf_pf_forward_loop(const MmfPfLoopArgs* args /* host */, void* stream);
@@ -415,12 +414,12 @@ int mmf_pf_forward_loop(const MmfPfLoopArgs* args /* host */, void* stream);
 /* The persistent form of the step loop (MmfPfLoopArgs.persistent): at the sizes the reference itself runs (32
  * trajectories x 300 particles: door_models/pf.py:24-27, eval_helpers.py:125-142) a step is bound by the fixed cost
  * of its four launches; one launch whose workgroups keep ONE network's weights in LDS for all T steps and hand
- * particles over through L2 (per-trajectory flags, no grid barrier) removes it.
+ * particles over through L2 (tagged 8-byte granules: the data is the flag; no grid barrier) removes it.
  *   mmf_pf_persistent_plan: number of workgroups it would use (0: not eligible -- too many tiles per wave, or
  *   M > 2048; MMF_EINVAL: invalid sizes), and optionally the workgroups per network role, K1 workgroups and tiles
  *   per trajectory.                                                                                               */
 int mmf_pf_persistent_plan(int N, int M, int n_meas, int* G_out, int* GK_out, int* tiles_per_trajectory_out);
-size_t mmf_pf_persistent_sync_words(int N, int M);
+size_t mmf_pf_persistent_sync_words(int N, int M, int d, int n_meas);
 
 /* estimation_method = "argmax" of torchfilter's ParticleFilter: per trajectory the particle with
  * the largest pre-resampling log-weight logw_in + loglik (logw_in null: uniform), first index on ties (torch.argmax).

@@ -68,7 +68,7 @@ class MmfPfLoopArgs(Structure):
                 ("noise_seed", ctypes.c_uint64), ("noise_step0", ctypes.c_uint32), ("noise_traj0", ctypes.c_uint32),
                 ("noise_mode", c_int32), ("use_graph", c_int32), ("measure_seq", c_int32),
                 ("soft_alpha", ctypes.c_float), ("estimate_argmax", c_int32), ("estimate_scratch", _FP),
-                ("persistent", c_int32), ("n_sync_words", c_int32), ("sync_words", _FP), ("ll_modal", _FP)]
+                ("persistent", c_int32), ("n_sync_words", c_int32), ("sync_words", _FP)]
 
 
 class MmfTrainNet(Structure):
@@ -127,7 +127,7 @@ SIGNATURES = {
     "mmf_pf_forward_loop": (c_int, [POINTER(MmfPfLoopArgs), c_void_p]),
     "mmf_pf_argmax_estimate": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_persistent_plan": (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
-    "mmf_pf_persistent_sync_words": (c_size_t, [c_int, c_int]),
+    "mmf_pf_persistent_sync_words": (c_size_t, [c_int, c_int, c_int, c_int]),
     "mmf_loop_graphs_release": (None, []),
     "mmf_pf_dynamics_philox": (c_int, [_FP, c_int, c_int, _FP, _FP, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
                                        _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
@@ -314,8 +314,8 @@ def pf_persistent_plan(N: int, M: int, n_meas: int) -> int:
     return int(load().mmf_pf_persistent_plan(N, M, n_meas, None, None, None))
 
 
-def pf_persistent_sync_words(N: int, M: int) -> int:
-    return int(load().mmf_pf_persistent_sync_words(N, M))
+def pf_persistent_sync_words(N: int, M: int, d: int, n_meas: int) -> int:
+    return int(load().mmf_pf_persistent_sync_words(N, M, d, n_meas))
 
 
 def pf_argmax_estimate(loglik, logw_in, states, estimate):

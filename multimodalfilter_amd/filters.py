@@ -346,13 +346,11 @@ class ParticleFilter(base.Filter):
                 and dyn._net.n_res == 3 and all(net.n_res == 2 for net, _b, _l in nets)
                 and _abi.pf_persistent_plan(N, M, len(nets)) > 0):
             # small problem: ONE launch for all T steps (csrc/pf_persistent.inc); same bits as the loop of launches
-            n_words = _abi.pf_persistent_sync_words(N, M)
-            sync = torch.empty(n_words, dtype=torch.int32, device=dev)
-            ll_modal = torch.empty((len(nets), N, M), dtype=torch.float32, device=dev)
-            keep += [sync, ll_modal]
+            n_words = _abi.pf_persistent_sync_words(N, M, d, len(nets))
+            sync = torch.empty(n_words, dtype=torch.int32, device=dev)  # tagged granules of the hand-offs (zeroed by the call)
+            keep.append(sync)
             a.persistent, a.n_sync_words = 1, n_words
             a.sync_words = ctypes.c_void_p(_abi.ptr(sync, dtype=torch.int32))
-            a.ll_modal = P(ll_modal)
         events = None
         names = ["particle_net_dynamics"] + ["particle_net_measure"] * (1 if fused_measure else len(nets)) + ["pf_reweight_resample"]
         stride = 1
