@@ -502,6 +502,174 @@ __device__ __forceinline__ void pin_mfma_valu_interleave() {
 
 enum Kind { kDynamics = 0, kMeasure = 1, kJacobian = 2 };
 
+// ---- the 64x64 layers of one tile of 32*CT particles (f16x3), software-pipelined on ROW tiles.
+// res_block_f16 / mfma_layer_f16 (the unpipelined path) issue, per fragment group, two LDS reads, wait for them,
+// 3*CT dependent MFMAs -- and the ReLU / operand split of a layer's output only after all of its MFMAs: ~2,000 cycles
+// per layer for a lone wave at CT = 1 (768 of them MFMA), which IS a small filter's step time (pf_persistent.inc).
+// The column-half pipeline (PIPE) overlaps the two kinds of work perfectly but reads every weight fragment TWICE
+// (once per half, half a layer apart); this one keeps the column tiles in lock step -- one fragment read serves all
+// CT column tiles -- and pipelines on the output ROW tiles instead.
+// Same operations, same order PER ACCUMULATOR (k-steps ascending, hi*hi, hi*lo, lo*hi), so the same bits -- only
+// the interleaving changes:
+//  * output rows 0..31 (tile 0) feed k-steps 0, 1 of the next layer, rows 32..63 (tile 1) k-steps 2, 3: the
+//    fragment groups run (t0,s0) (t0,s1) (t1,s0) (t1,s1) | (t0,s2) (t0,s3) | (t1,s2) (t1,s3), so that tile 1 of the
+//    previous layer is post-processed (activation + split + range tracking: 72 VALU) under the first four groups,
+//    the next layer's accumulators are initialised under the next two, and tile 0 of this layer is post-processed
+//    under the last two (and a little after them);
+//  * weight fragments are requested TWO groups ahead, across layer boundaries;
+//  * the order is pinned with sched_group_barrier (as particle_net_kernel's PIPE variant does for column halves).
+constexpr int kGroupT[8] = {0, 0, 1, 1, 0, 0, 1, 1};
+constexpr int kGroupS[8] = {0, 1, 0, 1, 2, 3, 2, 3};
+
+enum SmallAct { kActReluSat = 0, kActReluKeepNan = 1, kActSaturate = 2, kActRelu1 = 3 };
+
+template <int CT, int T, int ACT>
+__device__ __forceinline__ void act_tile(Act<CT>& a) {
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = a.v[T][c][r];
+      a.v[T][c][r] = ACT == kActReluSat ? relu_sat(v) : ACT == kActReluKeepNan ? relu_keepnan(v) : ACT == kActSaturate ? clamp_sat(v) : relu1(v);
+    }
+}
+
+// rows of tile T -> k-steps 2T, 2T + 1 of the next layer's operand (split_act's arithmetic, one row tile)
+template <int CT, int T, bool SIGNED>
+__device__ __forceinline__ void split_tile(const Act<CT>& x, SplitAct<CT>& o, float neg_one, short2v& amax) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      u32x4 hh, ll;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        unsigned a, b;
+        split_pair(x.v[T][c][8 * u + 2 * p], x.v[T][c][8 * u + 2 * p + 1], neg_one, a, b);
+        hh[p] = a;
+        ll[p] = b;
+      }
+      constexpr unsigned kMask = SIGNED ? 0x7fff7fffu : 0xffffffffu;
+      const short2v m01 = __builtin_elementwise_max(__builtin_bit_cast(short2v, hh[0] & kMask), __builtin_bit_cast(short2v, hh[1] & kMask));
+      const short2v m23 = __builtin_elementwise_max(__builtin_bit_cast(short2v, hh[2] & kMask), __builtin_bit_cast(short2v, hh[3] & kMask));
+      amax = __builtin_elementwise_max(amax, __builtin_elementwise_max(m01, m23));
+      o.hi[2 * T + u][c] = __builtin_bit_cast(half8, hh);
+      o.lo[2 * T + u][c] = __builtin_bit_cast(half8, ll);
+    }
+  unsigned pin = __builtin_bit_cast(unsigned, amax);  // see split_act
+  asm volatile("" : "+v"(pin));
+  amax = __builtin_bit_cast(short2v, pin);
+}
+
+template <int CT, int G>
+__device__ __forceinline__ void mfma_group(const FragPair& f, const SplitAct<CT>& in, Act<CT>& acc) {
+  constexpr int t = kGroupT[G], s = kGroupS[G];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {  // ONE fragment pair serves every column tile
+    acc.v[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.hi, in.hi[s][c], acc.v[t][c], 0, 0, 0);
+    acc.v[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.hi, in.lo[s][c], acc.v[t][c], 0, 0, 0);
+    acc.v[t][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.lo, in.hi[s][c], acc.v[t][c], 0, 0, 0);
+  }
+}
+
+template <int CT, int GROUPS, int VPM>
+__device__ __forceinline__ void pin_small_region() {
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g) {
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the fragment pair of group + 2
+#pragma unroll
+    for (int m = 0; m < 3 * CT; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);  // VALU in its shadow
+    }
+  }
+}
+
+// On entry X holds the first layer's pre-activation (d -> 64, bias included); on exit H holds the trunk's output,
+// activated (what the head reads).  `join_init(acc)`: writes the per-trajectory term of the join layer.
+template <int CT, int NRES, int KIND, class JoinInit>
+__device__ __forceinline__ void rowpipe_net_f16(const float* __restrict__ lds, Act<CT>& X, Act<CT>& H, SplitAct<CT>& SP,
+                                                JoinInit&& join_init, int lane, float neg_one, short2v& amax) {
+  constexpr int NL = 3 + 2 * NRES;
+  const int h = lane >> 5;
+  const float* layers = lds + off_layers();
+  // fragments in flight: two groups ahead for a lone 32-particle tile (a group is 3 MFMAs = 96 cycles, an LDS read
+  // ~130), one group ahead with two column tiles (6 MFMAs per group; and the registers are needed elsewhere)
+  constexpr int AHEAD = CT == 1 ? 2 : 1;
+  FragPair fr[AHEAD + 1];
+  // which accumulator layer l writes, and what its OUTPUT goes through on its way into layer l + 1
+  auto out_is_h = [](int l) constexpr { return l == 0 || l == 2 || (l > 2 && (l - 3) % 2 == 1); };
+  asm volatile("" ::: "memory");  // keep the LDS fragment reads inside the caller's tile loop (see mfma_layer)
+  fr[0] = load_frag(layers, lane, kGroupT[0] * 4 + kGroupS[0]);
+  if constexpr (AHEAD == 2) fr[1] = load_frag(layers, lane, kGroupT[1] * 4 + kGroupS[1]);
+  // prologue: the first layer's ReLU (keeps a NaN state visible: see relu_sat), both tiles split, H = b_0
+  act_tile<CT, 0, kActRelu1>(X);
+  act_tile<CT, 1, kActRelu1>(X);
+  split_tile<CT, 0, false>(X, SP, neg_one, amax);
+  split_tile<CT, 1, false>(X, SP, neg_one, amax);
+  add_bias<CT, false>(lds + off_bias(NRES), H, h, 1.f);
+  __builtin_amdgcn_sched_barrier(0);
+
+  static_for<NL>([&](auto layer) {
+    constexpr int l = decltype(layer)::value;
+    Act<CT>& out = out_is_h(l) ? H : X;
+    // activation of layer l's output on its way into layer l + 1 (the final layer: the ReLU in front of the head)
+    constexpr bool to_join_out = (l + 1 == 3);  // the value that leaves the join layer
+    constexpr int act_next = (to_join_out && KIND == kMeasure) ? kActReluKeepNan : (to_join_out ? kActSaturate : kActReluSat);
+    constexpr bool signed_next = to_join_out && KIND != kMeasure;
+    // ... and of layer l - 1's output into this layer (its tile 1 is still pending when this layer starts)
+    constexpr bool from_join = (l == 3);
+    constexpr int act_in = (from_join && KIND == kMeasure) ? kActReluKeepNan : (from_join ? kActSaturate : kActReluSat);
+    constexpr bool signed_in = from_join && KIND != kMeasure;
+    auto step = [&](auto gi) {
+      constexpr int G = decltype(gi)::value;
+      constexpr int i = 8 * l + G;           // global fragment-group counter
+      if constexpr (i + AHEAD < 8 * NL) {
+        constexpr int l2 = (i + AHEAD) / 8, g2 = (i + AHEAD) % 8;
+        fr[(i + AHEAD) % (AHEAD + 1)] = load_frag(layers + l2 * kLayerFloats, lane, kGroupT[g2] * 4 + kGroupS[g2]);
+      }
+      mfma_group<CT, G>(fr[i % (AHEAD + 1)], SP, out);
+    };
+    using I = std::integral_constant<int, 0>;
+    // ---- region 1: groups 0..3 (k-steps 0, 1) || tile 1 of the previous layer -> k-steps 2, 3
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+    if constexpr (l > 0) {
+      Act<CT>& prev = out_is_h(l - 1) ? H : X;
+      act_tile<CT, 1, act_in>(prev);
+      split_tile<CT, 1, signed_in>(prev, SP, neg_one, amax);
+    }
+    pin_small_region<CT, 4, 6>();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- region 2: groups 4, 5 (tile 0 completes) || the next layer's accumulator: bias, skip + bias, or the
+    // per-trajectory term (join)
+    step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+    if constexpr (l + 1 < NL) {
+      constexpr int m = l + 1;
+      Act<CT>& nxt = out_is_h(m) ? H : X;
+      if constexpr (m == 2) {
+        join_init(nxt);
+      } else if constexpr (m == 1 || (m > 3 && (m - 3) % 2 == 1)) {
+        add_bias_packed<CT>(lds + off_bias(NRES) + m * kUnits, nxt, h);   // the block's skip + bias
+      } else {
+        add_bias<CT, false>(lds + off_bias(NRES) + m * kUnits, nxt, h, 1.f);
+      }
+    }
+    pin_small_region<CT, 2, 6>();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- region 3: groups 6, 7 (tile 1 completes) || tile 0 of this layer -> k-steps 0, 1 of the next
+    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+    act_tile<CT, 0, act_next>(out);
+    if constexpr (l + 1 < NL) split_tile<CT, 0, signed_next>(out, SP, neg_one, amax);
+    pin_small_region<CT, 2, 6>();
+    __builtin_amdgcn_sched_barrier(0);
+    (void)sizeof(I);
+  });
+  act_tile<CT, 1, kActReluSat>(H);  // tile 1 of the last layer (the last layer always writes H)
+}
+
+
+
 struct NetArgs {
   const float* packed;
   const float* states_in;   // (R, D)            [jacobian: (N, D)]
@@ -533,7 +701,7 @@ struct NetArgsMulti {
   int seq = 1;  // problems a workgroup runs back to back (blockIdx.y covers the rest): see mmf_pf_measure_seq
 };
 
-template <int D, int NRES, int KIND, int CT, int PREC, int WPS, bool PIPE = false>
+template <int D, int NRES, int KIND, int CT, int PREC, int WPS, bool PIPE = false, bool ROWPIPE = false>
 __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMulti multi) {
 #pragma unroll 1
   for (int pass = 0; pass < multi.seq; ++pass) {
@@ -543,6 +711,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
     __syncthreads();   // every wave is done with the previous network's weights in LDS
   }
   static_assert(!PIPE || (CT == 2 && PREC == MMF_PREC_F16X3 && KIND != kJacobian), "pipelined halves: f16x3, 64-particle tiles");
+  static_assert(!ROWPIPE || (!PIPE && PREC == MMF_PREC_F16X3 && KIND != kJacobian), "row-tile pipeline: f16x3");
   constexpr int kThreads = WPS * 256;           // WPS waves per SIMD, one workgroup per CU (LDS)
   constexpr int kWavesPerBlock = kThreads / MMF_WAVE;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -638,7 +807,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
           X.v[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, bcur[s][c], X.v[t][c], 0, 0, 0);
       }
     }
-    relu<CT, JAC>(X, primal);
+    if constexpr (!ROWPIPE) relu<CT, JAC>(X, primal);  // (the row-tile pipeline's prologue applies it)
 
     SplitAct<F16 ? CT : 0> SP;
     short2v amax = {0, 0};  // f16x3: largest hi halves handed to the MFMAs in this tile
@@ -723,6 +892,22 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
         __builtin_amdgcn_sched_barrier(0);
       });
       relu_half<1>(H);
+    } else if constexpr (ROWPIPE) {
+      // column tiles in lock step (one LDS read per weight fragment for all of them), pipelined on output ROW tiles
+      rowpipe_net_f16<CT, NRES, KIND>(lds, X, H, SP, [&](Act<CT>& acc) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int c = 0; c < CT; ++c) {
+            const float* tb = a.traj_bias + static_cast<size_t>(col_traj[c]) * kUnits + 32 * t + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 b = *reinterpret_cast<const f32x4*>(tb + 8 * g);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc.v[t][c][4 * g + e] = b[e];
+            }
+          }
+      }, lane, neg_one, amax);
     } else {
     // ---- encoder residual block (layers 0, 1)
     if constexpr (F16) res_block_f16<CT, false, JAC>(lds, NRES, 0, X, H, SP, lane, neg_one, amax, primal);
@@ -896,7 +1081,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
   }  // pass
 }
 
-template <int D, int NRES, int KIND, int PREC, int CT, int WPS, bool PIPE = false>
+template <int D, int NRES, int KIND, int PREC, int CT, int WPS, bool PIPE = false, bool ROWPIPE = false>
 int launch_variant(const NetArgsMulti& m, int count, hipStream_t s) {
   const NetArgs& a = m.a[0];
   const size_t lds = static_cast<size_t>(blob_floats(NRES)) * sizeof(float);
@@ -905,7 +1090,7 @@ int launch_variant(const NetArgsMulti& m, int count, hipStream_t s) {
   int grid = (ntiles + waves - 1) / waves;
   if (grid > 256) grid = 256;
   if (grid < 1) grid = 1;
-  auto k = particle_net_kernel<D, NRES, KIND, CT, PREC, WPS, PIPE>;
+  auto k = particle_net_kernel<D, NRES, KIND, CT, PREC, WPS, PIPE, ROWPIPE>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   if (e != hipSuccess) return static_cast<int>(e);
@@ -924,6 +1109,8 @@ int launch_ct(const NetArgsMulti& m, int count, hipStream_t s) {
     if (big && variant == 1) return launch_variant<D, NRES, KIND, PREC, 1, 3>(m, count, s);  // 32-particle tiles, 3 waves/SIMD
     if (big && variant == 2) return launch_variant<D, NRES, KIND, PREC, 1, 2>(m, count, s);
     if (big && variant == 3) return launch_variant<D, NRES, KIND, PREC, 2, 2, false>(m, count, s);  // unpipelined
+    if (big && variant == 4) return launch_variant<D, NRES, KIND, PREC, 2, 2, false, true>(m, count, s);  // row-tile pipeline: half the LDS fragment reads
+    if (!big && variant == 5) return launch_variant<D, NRES, KIND, PREC, 1, 2, false, true>(m, count, s);  // small problems, row-tile pipeline
     if (big) return launch_variant<D, NRES, KIND, PREC, 2, 2, true>(m, count, s);
   }
   if (big) return launch_variant<D, NRES, KIND, PREC, 2, 2>(m, count, s);
