@@ -47,10 +47,18 @@ PREC_CODE = {"f32": 0, "f16x3": 1}
 
 
 def k2_kernel_name(d: int, prec: str) -> str:
-    """<D, NRES, KIND=measure, CT=2 (64-particle tiles), PREC, WPS=2 waves/SIMD, PIPE (f16x3:
-    the two 32-particle halves run half a layer apart)>"""
-    pipe = "true" if prec == "f16x3" and os.environ.get("MMF_K2_VARIANT", "0") == "0" else "false"
-    return f"particle_net_kernel<{d}, 2, 1, 2, {PREC_CODE[prec]}, 2, {pipe}>"
+    """<D, NRES, KIND=measure, CT=2 (64-particle tiles), PREC, WPS=2 waves/SIMD, PIPE (f16x3: the two 32-particle
+    halves run half a layer apart), ROWPIPE (A/B: column tiles in lock step, pipelined on row tiles)>"""
+    variant = os.environ.get("MMF_K2_VARIANT", "0")
+    pipe = "true" if prec == "f16x3" and variant == "0" else "false"
+    rowpipe = "true" if prec == "f16x3" and variant == "4" else "false"
+    return f"particle_net_kernel<{d}, 2, 1, 2, {PREC_CODE[prec]}, 2, {pipe}, {rowpipe}>"
+
+
+def k2_kernel_key(d: int, prec: str) -> str:
+    """Prefix that finds the kernel in this round's AND earlier rounds' profile files (r01-r03 printed seven
+    template arguments)."""
+    return k2_kernel_name(d, prec).rsplit(",", 1)[0]
 
 WORKLOADS = {
     "door_pf": dict(task="door", cls="DoorCrossmodalParticleFilter", kind="pf", batch=256, particles=4096,
@@ -1340,7 +1348,7 @@ def main():
         default_shape = (args.workload == "door_pf" and B == 256 and M == 4096)
         r = {"kernel": k2_kernel_name(d, prec) + " (measurement network)", "bound": "mfma", "achieved": ach,
              "peak": MFMA_PEAK[prec], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK[prec],
-             "traffic": pmc_traffic(k2_kernel_name(d, prec)) if default_shape else None}
+             "traffic": pmc_traffic(k2_kernel_key(d, prec)) if default_shape else None}
         if dom["launches"] and engine.MEASURE_SEQ:
             r["launch"] = "one launch = the filter's two measurement networks back to back in every workgroup (mmf_pf_measure_seq)"
         if prec == "f16x3":

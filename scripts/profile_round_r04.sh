@@ -1,0 +1,85 @@
+# Round-4 profile (run on the GPU box): kernel-trace stats + HBM traffic counters of the default bench, the EKF / f32 /
+# philox variants, the reference-sized regimes (persistent loop on and off), K2's SQ counters (column-half and row-tile
+# pipelines), the K1 batch sweep, and the plain bench lines.
+#   bash scripts/profile_round_r04.sh [out-dir under gpurun_out/]
+#   then: python scripts/collect_profiles.py gpurun_out/<dir> profiles/r04 ; python scripts/profiles_summary.py profiles/r04
+# rocprofv3 writes under /tmp (a kernel trace of a long run is tens of MB; gpurun_out/ returns <= 64 MiB): only the
+# summaries (stats CSVs, this repo's kernels' trace / counter rows) are copied into $OUT.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/${1:-prof_r04}
+P=/tmp/mmf_prof
+rm -rf $P; mkdir -p $OUT $P
+HIPCC=/opt/rocm/bin/hipcc
+# micro-benchmarks the round quotes (binaries are git-ignored: build them here)
+$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -I$R/include -I$R/multimodalfilter_amd/csrc -o $R/scripts/ubench/k1_phases $R/scripts/ubench/k1_phases.hip > $OUT/ubench_build.log 2>&1
+$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -o $R/scripts/ubench/mfma_shape $R/scripts/ubench/mfma_shape.hip >> $OUT/ubench_build.log 2>&1
+cd /tmp && export TMPDIR=/tmp
+LEAN="--no-cpu-baseline --no-precision-study --no-reference-sizes --no-configs"
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -- python3 $R/bench.py --steps 32 --warmup 4 $LEAN --no-f32-mode > $OUT/bench_under_rocprof.json 2> $P/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_f32 -- python3 $R/bench.py --steps 32 --warmup 4 $LEAN --precision f32 > $OUT/bench_under_rocprof_f32.json 2> $P/stats_f32.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_ekf -- python3 $R/bench.py --workload door_ekf --steps 32 --warmup 4 $LEAN > $OUT/bench_under_rocprof_ekf.json 2> $P/stats_ekf.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_philox -- python3 $R/bench.py --steps 32 --warmup 4 $LEAN --no-f32-mode --noise philox > $OUT/bench_under_rocprof_philox.json 2> $P/stats_philox.err
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $P/pmc_$C -- python3 $R/bench.py --steps 4 --warmup 1 $LEAN --no-kernel-timers --no-f32-mode --preroll-seconds 0 > /dev/null 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $P/pmc_f32_$C -- python3 $R/bench.py --steps 4 --warmup 1 $LEAN --no-kernel-timers --precision f32 --preroll-seconds 0 > /dev/null 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $P/pmc_philox_$C -- python3 $R/bench.py --steps 4 --warmup 1 $LEAN --no-kernel-timers --no-f32-mode --noise philox --preroll-seconds 0 > /dev/null 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $P/pmc_ekf_$C -- python3 $R/bench.py --workload door_ekf --steps 8 --warmup 0 $LEAN --no-kernel-timers --preroll-seconds 0 > /dev/null 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $P/pmc_k4_$C -- python3 $R/scripts/bench_k4.py > /dev/null 2>&1
+done
+# reference-sized regimes: kernel stats + GPU-busy fraction, the persistent loop (default) and the loop of launches
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_ref -- python3 $R/scripts/bench_reference_sizes.py --only eval --no-cpu --eval-repeats 1 > /dev/null 2> $P/ref.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_train -- python3 $R/scripts/bench_train.py --steps 3 --backends hip > /dev/null 2> $P/train.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_trainref -- python3 $R/scripts/bench_reference_sizes.py --only train --backends hip --no-cpu --train-iters 10 > /dev/null 2> $P/trainref.err
+cd $R
+cp $(find $P/stats_ref -name "*kernel_stats.csv" | head -1) $OUT/reference_sizes_kernel_stats.csv
+cp $(find $P/stats_train -name "*kernel_stats.csv" | head -1) $OUT/train_kernel_stats.csv
+cp $(find $P/stats_trainref -name "*kernel_stats.csv" | head -1) $OUT/train_refsize_kernel_stats.csv
+cp $(find $P/stats_philox -name "*kernel_stats.csv" | head -1) $OUT/door_pf_philox_kernel_stats.csv
+python scripts/gpu_busy.py $(find $P/stats_ref -name "*kernel_trace.csv" | head -1) --top 8 --kernels 4 > $OUT/reference_sizes_gpu_busy.txt 2>&1
+python scripts/gpu_busy.py $(find $P/stats_ekf -name "*kernel_trace.csv" | head -1) --top 3 --kernels 12 > $OUT/door_ekf_gpu_busy.txt 2>&1
+python scripts/gpu_busy.py $(find $P/stats -name "*kernel_trace.csv" | head -1) --top 3 --kernels 8 > $OUT/door_pf_gpu_busy.txt 2>&1
+python scripts/collect_profiles.py $P $OUT/collected > $OUT/collect.log 2>&1
+# K2: SQ counters + effective clock of the shipped (column-half) pipeline and of the row-tile pipeline (half the LDS reads)
+bash scripts/pmc_k2_r04.sh variant0_column_half_pipeline > /dev/null 2>&1
+MMF_K2_VARIANT=4 bash scripts/pmc_k2_r04.sh variant4_row_tile_pipeline > /dev/null 2>&1
+python - > $OUT/pmc_k2_sq_counters.json <<'PY'
+import json
+out = {"what": "scripts/pmc_k2_r04.sh: SQ counters and effective clock (GRBM_GUI_ACTIVE / 8 / duration) of the K2 kernels of the default bench, "
+               "the shipped column-half pipeline (MMF_K2_VARIANT=0) and the row-tile pipeline (MMF_K2_VARIANT=4: one LDS read per weight fragment for both column tiles)"}
+for tag in ("variant0_column_half_pipeline", "variant4_row_tile_pipeline"):
+    try:
+        out[tag] = json.load(open(f"gpurun_out/pmc_k2_r04/{tag}.json"))["kernels"]
+    except OSError as e:
+        out[tag] = str(e)
+print(json.dumps(out, indent=1))
+PY
+bash scripts/debug/k2_rowpipe_ab.sh > $OUT/bench_k2_rowpipe_ab.txt 2>&1
+./scripts/ubench/mfma_shape > $OUT/ubench_mfma_shape.txt 2>&1
+# plain bench lines (un-profiled)
+python bench.py > $OUT/bench_door_pf_n1.json 2> $OUT/bench.err
+python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_flags_door_pf.json 2>> $OUT/bench.err
+python bench.py --noise philox $LEAN > $OUT/bench_door_pf_philox.json 2>> $OUT/bench.err
+python bench.py --workload push_pf --no-reference-sizes --no-configs > $OUT/bench_push_pf_n1.json 2>> $OUT/bench.err
+python bench.py --workload door_ekf --no-configs > $OUT/bench_door_ekf_n1.json 2>> $OUT/bench.err
+python bench.py --workload door_ekf --steps 20 --warmup 5 $LEAN > $OUT/bench_driver_flags_door_ekf.json 2>> $OUT/bench.err
+python bench.py --workload door_pf_blackout $LEAN --no-f32-mode > $OUT/bench_door_pf_blackout.json 2>> $OUT/bench.err
+python bench.py --workload door_ekf_blackout $LEAN > $OUT/bench_door_ekf_blackout.json 2>> $OUT/bench.err
+python bench.py --workload door_pf --batch 32 --steps 64 $LEAN --no-f32-mode > $OUT/bench_door_pf_n32_m4096.json 2>> $OUT/bench.err
+python bench.py --workload door_pf --batch 1024 --steps 32 $LEAN --no-f32-mode > $OUT/bench_door_pf_n1024_m4096.json 2>> $OUT/bench.err
+python bench.py --workload door_ekf --global-batch 8192 --steps 32 --warmup 4 $LEAN > $OUT/bench_c4_door_ekf_n8192_one_gpu.json 2>> $OUT/bench.err
+python bench.py --workload door_pf --steps 800 $LEAN --no-f32-mode > $OUT/bench_door_pf_800_steps.json 2>> $OUT/bench.err
+MMF_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 32 --warmup 8 2>> $OUT/bench.err | grep "^{" > $OUT/bench_gpus2_gloo_one_gpu.json
+python scripts/debug/rccl_probe.py 2>&1 | grep -E "^rank|^world|Duplicate GPU" | sort -u > $OUT/bench_rccl_probe.txt
+python scripts/bench_k4.py > $OUT/bench_k4.txt 2>> $OUT/bench.err
+python scripts/bench_k1.py > $OUT/bench_k1.txt 2>> $OUT/bench.err
+python scripts/bench_k1.py --batch-sweep > $OUT/bench_k1_dephase_ab.txt 2>> $OUT/bench.err
+# the sizes the reference itself runs: persistent loop (default) vs the loop of launches, with the stamps of one step
+python scripts/bench_reference_sizes.py > $OUT/bench_reference_sizes.txt 2>> $OUT/bench.err
+{ echo "# MMF_PF_PERSISTENT=1 (default)"; MMF_PERSIST_STAMPS=40 python scripts/bench_reference_sizes.py --only eval --no-cpu --eval-repeats 1 2>&1 | grep -v amdgpu.ids;
+  echo "# MMF_PF_PERSISTENT=0 (one launch per kernel and step)"; MMF_PF_PERSISTENT=0 python scripts/bench_reference_sizes.py --only eval --no-cpu 2>&1 | grep -v amdgpu.ids; } > $OUT/bench_persistent_loop_ab.txt
+python scripts/bench_train.py > $OUT/bench_train_push_unimodal_pf.json 2>> $OUT/bench.err
+python scripts/bench_train.py --backends hip --cnn-precision bf16 >> $OUT/bench_train_push_unimodal_pf.json 2>> $OUT/bench.err
+./scripts/ubench/k1_phases 256 4096 > $OUT/k1_phases.txt 2>&1; ./scripts/ubench/k1_phases 256 1024 >> $OUT/k1_phases.txt 2>&1; ./scripts/ubench/k1_phases 32 300 >> $OUT/k1_phases.txt 2>&1
+MMF_PRECISION=f32 python -m pytest tests -m gpu -q 2>&1 | grep -E '^E  |^FAILED|passed|failed' | tail -20 > $OUT/pytest_gpu_f32_mode.txt
+python -m pytest tests -m gpu -q 2>&1 | grep -E '^E  |^FAILED|passed|failed' | tail -20 > $OUT/pytest_gpu.txt
+du -sh $OUT
