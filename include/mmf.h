@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 34
+#define MMF_ABI_VERSION 35
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -542,6 +542,15 @@ typedef struct MmfPfTrainArgs {
   float* g_logw_b;
   float* d_tmp;
   int32_t* range_flag;
+  int32_t compact;           /* ABI 35.  1: the recompute buffers in half the bytes -- `stash` and `dz` are then f16 arrays of
+                                the SAME SHAPES (half the allocation), activations stored as f16 and the pre-activation
+                                gradients as f16 relative to their row's largest magnitude, kept in `dz_scale`; the
+                                weight-gradient products stay fp32 on the exact-fp32 MFMA.  The data path of the
+                                backward (d_states, the masks, the recursion's gradients) is untouched: only the
+                                parameter gradients see the rounding (2^-11 relative per stored element, measured
+                                <= 1e-3 of the gradient norm -- tests/test_gpu_training.py).  0: fp32 buffers (bit-identical
+                                to ABI 34) */
+  float* dz_scale;           /* compact: scratch (max(NLd, NLm) + 1, chunk_traj M) [x (n_meas + 1) sets if concurrent]; else unused */
 } MmfPfTrainArgs;
 
 int mmf_pf_train_forward(const MmfPfTrainArgs* args /* host */, void* stream);

@@ -181,8 +181,40 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
   // scratch set s (concurrent: one per measurement network + one for the dynamics; else one for all)
   const size_t Cmax = static_cast<size_t>(a->chunk_traj < N ? a->chunk_traj : N) * M;
   const size_t set_act = static_cast<size_t>(NLmax + 1) * Cmax * MMF_UNITS, set_mask = static_cast<size_t>(NLmax + 1) * Cmax * 2;
-  auto stash_of = [&](int set) { return a->stash + (conc ? set * set_act : 0); };
-  auto dz_of = [&](int set) { return a->dz + (conc ? set * set_act : 0); };
+  // compact: stash / dz are f16 arrays of the same shapes (element offsets are the same, bytes half) + row scales of dz
+  const bool cmp = a->compact != 0;
+  if (cmp && !a->dz_scale) return MMF_EINVAL;
+  const size_t esz = cmp ? 2 : 4;
+  auto stash_of = [&](int set) { return reinterpret_cast<char*>(a->stash) + (conc ? set * set_act : 0) * esz; };
+  auto dz_of = [&](int set) { return reinterpret_cast<char*>(a->dz) + (conc ? set * set_act : 0) * esz; };
+  auto scale_of = [&](int set) { return cmp ? a->dz_scale + (conc ? set * static_cast<size_t>(NLmax + 1) * Cmax : 0) : nullptr; };
+  auto net_fwd = [&](const MmfTrainNet& net, int n_res, int kind, const float* xs, const float* bias, char* stash, uint32_t* mask,
+                     float* raw, int Nc, hipStream_t s) {
+    return cmp ? mmf_internal_train_forward_h(net.packed_f32, n_res, kind, xs, bias, stash, mask, raw, Nc, M, d, s)
+               : mmf_particle_net_train_forward(net.packed_f32, n_res, kind, xs, bias, reinterpret_cast<float*>(stash), mask, raw, Nc, M, d, s);
+  };
+  auto net_bwd = [&](const MmfTrainNet& net, int n_res, int kind, const uint32_t* mask, const float* d_out, char* dz, float* sc,
+                     float* d_states, int Ci, hipStream_t s) {
+    return cmp ? mmf_internal_train_backward_h(net.packed_t, net.head_w, n_res, kind, mask, d_out, dz, sc, d_states, Ci, d, s)
+               : mmf_particle_net_train_backward(net.packed_t, net.head_w, n_res, kind, mask, d_out, reinterpret_cast<float*>(dz), d_states, Ci, d, s);
+  };
+  auto net_wgrads = [&](const MmfTrainNet& net, const char* dz, const float* sc, const char* stash, int n_layers, int Ci, int acc,
+                        hipStream_t s) {
+    return cmp ? mmf_internal_weight_grads_h(dz, sc, stash, net.pw, net.pb, n_layers, Ci, S, acc, s)
+               : mmf_particle_net_weight_grads_acc(reinterpret_cast<const float*>(dz), reinterpret_cast<const float*>(stash), net.pw,
+                                                   net.pb, n_layers, Ci, S, acc, s);
+  };
+  // the narrow reductions read dz of the first layer (slot NL) and of the join (slot 2), and the head's input (stash slot NL)
+  auto net_sgrads = [&](const MmfTrainNet& net, const char* dz, const float* sc, const char* stash, int NL, size_t C, const float* xs,
+                        const float* d_out, size_t slot0, int Nc, int n_out, hipStream_t s) {
+    const size_t oL = static_cast<size_t>(NL) * C * MMF_UNITS * esz, o2 = 2 * C * MMF_UNITS * esz;
+    float *pf = net.p_first + slot0 * MMF_UNITS * 4, *ph = net.p_head + slot0 * 4 * MMF_UNITS, *pd = net.p_dout + slot0 * 4,
+          *pt = net.p_traj + slot0 * MMF_UNITS;
+    return cmp ? mmf_internal_small_grads_h(dz + oL, sc + static_cast<size_t>(NL) * C, dz + o2, sc + 2 * C, stash + oL, xs, d_out, pf, ph,
+                                            pd, pt, Nc, M, d, n_out, SL, s)
+               : mmf_particle_net_small_grads(reinterpret_cast<const float*>(dz + oL), reinterpret_cast<const float*>(dz + o2),
+                                              reinterpret_cast<const float*>(stash + oL), xs, d_out, pf, ph, pd, pt, Nc, M, d, n_out, SL, s);
+  };
   auto mask_of = [&](int set) { return a->mask + (conc ? set * set_mask : 0); };
   auto raw_of = [&](int set) { return a->raw + (conc ? set * Cmax * 8 : 0); };
   auto tmp_of = [&](int set) { return a->d_tmp + (conc ? set * Cmax * d : 0); };
@@ -224,20 +256,16 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
         const float* d_out = K > 1 ? a->d_raw + k * C : d_a + r0;
         hipStream_t sk = conc ? g_side.s[k] : hs;
         if (conc) MMF_HIP(hipStreamWaitEvent(sk, g_side.fork, 0));
-        float *stash = stash_of(k), *dz = dz_of(k);
-        rc = mmf_particle_net_train_forward(net.packed_f32, a->n_res_meas, 1, xn + r0 * d,
-                                            a->meas_bias[k] + (t * row + n0) * MMF_UNITS, stash, mask_of(k), raw_of(k), Nc, M, d, sk);
+        char *stash = stash_of(k), *dz = dz_of(k);
+        float* sc = scale_of(k);
+        rc = net_fwd(net, a->n_res_meas, 1, xn + r0 * d, a->meas_bias[k] + (t * row + n0) * MMF_UNITS, stash, mask_of(k), raw_of(k), Nc, sk);
         if (rc) return rc;
-        rc = mmf_particle_net_train_backward(net.packed_t, net.head_w, a->n_res_meas, 1, mask_of(k), d_out, dz, tmp_of(k),
-                                             Ci, d, sk);
+        rc = net_bwd(net, a->n_res_meas, 1, mask_of(k), d_out, dz, sc, tmp_of(k), Ci, sk);
         if (rc) return rc;
-        rc = mmf_particle_net_weight_grads_acc(dz, stash, net.pw, net.pb, NLm + 1, Ci, S, first_wgrad_meas[k] ? 0 : 1, sk);
+        rc = net_wgrads(net, dz, sc, stash, NLm + 1, Ci, first_wgrad_meas[k] ? 0 : 1, sk);
         if (rc) return rc;
         first_wgrad_meas[k] = false;
-        rc = mmf_particle_net_small_grads(dz + static_cast<size_t>(NLm) * C * MMF_UNITS, dz + 2 * C * MMF_UNITS,
-                                          stash + static_cast<size_t>(NLm) * C * MMF_UNITS, xn + r0 * d, d_out,
-                                          net.p_first + slot0 * MMF_UNITS * 4, net.p_head + slot0 * 4 * MMF_UNITS,
-                                          net.p_dout + slot0 * 4, net.p_traj + slot0 * MMF_UNITS, Nc, M, d, 1, SL, sk);
+        rc = net_sgrads(net, dz, sc, stash, NLm, C, xn + r0 * d, d_out, slot0, Nc, 1, sk);
         if (rc) return rc;
         if (conc) {
           MMF_HIP(hipEventRecord(g_side.done[k], sk));
@@ -251,9 +279,9 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
         const MmfTrainNet& net = a->dyn;
         hipStream_t sd = conc ? g_side.s[K] : hs;  // the recompute needs nothing of this step's gradients
         if (conc) MMF_HIP(hipStreamWaitEvent(sd, g_side.fork, 0));
-        float *stash = stash_of(K), *dz = dz_of(K);
-        rc = mmf_particle_net_train_forward(net.packed_f32, a->n_res_dyn, 0, x + r0 * d,
-                                            a->dyn_bias + (t * row + n0) * MMF_UNITS, stash, mask_of(K), raw_of(K), Nc, M, d, sd);
+        char *stash = stash_of(K), *dz = dz_of(K);
+        float* sc = scale_of(K);
+        rc = net_fwd(net, a->n_res_dyn, 0, x + r0 * d, a->dyn_bias + (t * row + n0) * MMF_UNITS, stash, mask_of(K), raw_of(K), Nc, sd);
         if (rc) return rc;
         if (conc) {
           MMF_HIP(hipEventRecord(g_side.done[K], sd));
@@ -266,16 +294,12 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
         if (d == 2) dyn_epilogue_bwd_kernel<2><<<blocks(C), kThreads, 0, hs>>>(raw_of(K), g_tot + r0 * d, d_raw_dyn, C);
         else dyn_epilogue_bwd_kernel<3><<<blocks(C), kThreads, 0, hs>>>(raw_of(K), g_tot + r0 * d, d_raw_dyn, C);
         MMF_CHECK_LAUNCH();
-        rc = mmf_particle_net_train_backward(net.packed_t, net.head_w, a->n_res_dyn, 0, mask_of(K), d_raw_dyn, dz, tmp_of(K),
-                                             Ci, d, stream);
+        rc = net_bwd(net, a->n_res_dyn, 0, mask_of(K), d_raw_dyn, dz, sc, tmp_of(K), Ci, hs);
         if (rc) return rc;
-        rc = mmf_particle_net_weight_grads_acc(dz, stash, net.pw, net.pb, NLd + 1, Ci, S, first_wgrad_dyn ? 0 : 1, stream);
+        rc = net_wgrads(net, dz, sc, stash, NLd + 1, Ci, first_wgrad_dyn ? 0 : 1, hs);
         if (rc) return rc;
         first_wgrad_dyn = false;
-        rc = mmf_particle_net_small_grads(dz + static_cast<size_t>(NLd) * C * MMF_UNITS, dz + 2 * C * MMF_UNITS,
-                                          stash + static_cast<size_t>(NLd) * C * MMF_UNITS, x + r0 * d, d_raw_dyn,
-                                          net.p_first + slot0 * MMF_UNITS * 4, net.p_head + slot0 * 4 * MMF_UNITS,
-                                          net.p_dout + slot0 * 4, net.p_traj + slot0 * MMF_UNITS, Nc, M, d, d + 1, SL, stream);
+        rc = net_sgrads(net, dz, sc, stash, NLd, C, x + r0 * d, d_raw_dyn, slot0, Nc, d + 1, hs);
         if (rc) return rc;
         // dL/d states[t] = direct path + through the network
         sum2_kernel<<<blocks(C * d), kThreads, 0, hs>>>(g_tot + r0 * d, tmp_of(K), g_next + r0 * d, C * d);

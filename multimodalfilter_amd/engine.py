@@ -484,6 +484,12 @@ TRAIN_CHUNK_ROWS = int(os.environ.get("MMF_TRAIN_CHUNK_ROWS", "262144"))
 # per optimiser step against 10.22 on one stream: the ~10 event records / waits per time step cost more than
 # the overlap of kernels that are 25 us long buys.
 TRAIN_CONCURRENT_ROWS = int(os.environ.get("MMF_TRAIN_CONCURRENT_ROWS", "0"))
+# MmfPfTrainArgs.compact: the recompute buffers of the backward in half the bytes (activations as f16, pre-activation
+# gradients as f16 relative to their row's largest magnitude + one fp32 scale per row and layer).  They are the
+# recursion's HBM traffic (written once, read once by the weight-gradient pass).  Only the PARAMETER gradients see the
+# rounding (the backward's data path -- d_states, the recursion's gradients -- is computed in registers from fp32):
+# tests/test_gpu_training.py bounds it.  MMF_TRAIN_COMPACT_STASH=0 restores the fp32 buffers (bit-identical to round 3).
+TRAIN_COMPACT_STASH = os.environ.get("MMF_TRAIN_COMPACT_STASH", "1") != "0"
 
 
 class PfTrainLoopFunction(torch.autograd.Function):
@@ -589,13 +595,16 @@ class PfTrainLoopFunction(torch.autograd.Function):
             if keep["beta"] is not None and col is not None:
                 a.meas_logw[k] = ctypes.c_void_p(keep["beta"].data_ptr() + 4 * col)
         g_est = g_est.to(torch.float32).contiguous()
-        scratch = dict(stash=E(sets, NLmax + 1, C, U), mask=torch.empty((sets, NLmax + 1, C, 2), dtype=torch.int32, device=dev),
-                       dz=E(sets, NLmax + 1, C, U), raw=E(sets, C, 8), d_raw=E(K + 8, C), ga=E(N, M, d), gb=E(N, M, d),
+        a.compact = int(TRAIN_COMPACT_STASH)
+        A = (lambda *shape: torch.empty(shape, dtype=torch.float16, device=dev)) if a.compact else E
+        scratch = dict(stash=A(sets, NLmax + 1, C, U), mask=torch.empty((sets, NLmax + 1, C, 2), dtype=torch.int32, device=dev),
+                       dz=A(sets, NLmax + 1, C, U), dz_scale=E(sets, NLmax + 1, C) if a.compact else None, raw=E(sets, C, 8), d_raw=E(K + 8, C), ga=E(N, M, d), gb=E(N, M, d),
                        la=E(N, M), lb=E(N, M), d_tmp=E(sets, C, d), d_states0=E(N, M, d), d_logw0=E(N, M))
         a.dyn_bias, a.noise, a.scale_tril, a.g_estimates = P(keep["dyn_bias"]), P(keep["eps"]), P(keep["tril"]), P(g_est)
         a.states, a.logw, a.estimates = P(keep["states"]), P(keep["logw"]), P(keep["est"])
         a.loglik, a.ll_steps = P(keep["loglik"]), P(keep["ll_steps"])
         a.stash, a.mask, a.dz, a.raw, a.d_raw, a.d_tmp = (P(scratch[k]) for k in ("stash", "mask", "dz", "raw", "d_raw", "d_tmp"))
+        a.dz_scale = P(scratch["dz_scale"])
         a.g_states_a, a.g_states_b, a.g_logw_a, a.g_logw_b = P(scratch["ga"]), P(scratch["gb"]), P(scratch["la"]), P(scratch["lb"])
         a.d_states0, a.d_logw0 = P(scratch["d_states0"]), P(scratch["d_logw0"])
         _abi.pf_train_backward(a, g_est)
