@@ -22,7 +22,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats_philox -- pytho
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $P/pmc_$C -- python3 $R/bench.py --steps 4 --warmup 1 $LEAN --no-kernel-timers --no-f32-mode --preroll-seconds 0 > /dev/null 2>&1
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $P/pmc_f32_$C -- python3 $R/bench.py --steps 4 --warmup 1 $LEAN --no-kernel-timers --precision f32 --preroll-seconds 0 > /dev/null 2>&1
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $P/pmc_philox_$C -- python3 $R/bench.py --steps 4 --warmup 1 $LEAN --no-kernel-timers --no-f32-mode --noise philox --preroll-seconds 0 > /dev/null 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $P/pmc_philox_$C -- python3 $R/bench.py --steps 4 --warmup 1 $LEAN --no-kernel-timers --no-f32-mode --noise philox --no-calibration --preroll-seconds 0 > /dev/null 2>&1  # calibration segments draw from a noise tensor
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $P/pmc_ekf_$C -- python3 $R/bench.py --workload door_ekf --steps 8 --warmup 0 $LEAN --no-kernel-timers --preroll-seconds 0 > /dev/null 2>&1
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $P/pmc_k4_$C -- python3 $R/scripts/bench_k4.py > /dev/null 2>&1
 done
@@ -79,6 +79,8 @@ python scripts/bench_reference_sizes.py > $OUT/bench_reference_sizes.txt 2>> $OU
   echo "# MMF_PF_PERSISTENT=0 (one launch per kernel and step)"; MMF_PF_PERSISTENT=0 python scripts/bench_reference_sizes.py --only eval --no-cpu 2>&1 | grep -v amdgpu.ids; } > $OUT/bench_persistent_loop_ab.txt
 python scripts/bench_train.py > $OUT/bench_train_push_unimodal_pf.json 2>> $OUT/bench.err
 python scripts/bench_train.py --backends hip --cnn-precision bf16 >> $OUT/bench_train_push_unimodal_pf.json 2>> $OUT/bench.err
+{ echo "# MMF_TRAIN_COMPACT_STASH=1 (default: f16 recompute buffers, row-scaled dz)"; python scripts/bench_train.py --backends hip 2>&1 | grep "^{";
+  echo "# MMF_TRAIN_COMPACT_STASH=0 (fp32 recompute buffers: round 3)"; MMF_TRAIN_COMPACT_STASH=0 python scripts/bench_train.py --backends hip 2>&1 | grep "^{"; } > $OUT/bench_train_compact_ab.txt
 ./scripts/ubench/k1_phases 256 4096 > $OUT/k1_phases.txt 2>&1; ./scripts/ubench/k1_phases 256 1024 >> $OUT/k1_phases.txt 2>&1; ./scripts/ubench/k1_phases 32 300 >> $OUT/k1_phases.txt 2>&1
 MMF_PRECISION=f32 python -m pytest tests -m gpu -q 2>&1 | grep -E '^E  |^FAILED|passed|failed' | tail -20 > $OUT/pytest_gpu_f32_mode.txt
 python -m pytest tests -m gpu -q 2>&1 | grep -E '^E  |^FAILED|passed|failed' | tail -20 > $OUT/pytest_gpu.txt

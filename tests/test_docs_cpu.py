@@ -1,4 +1,4 @@
-"""DESIGN.md quotes measured numbers; the measurements live under ``profiles/r03`` (rocprofv3 CSVs, bench JSON
+"""DESIGN.md quotes measured numbers; the measurements live under ``profiles/r04`` (rocprofv3 CSVs, bench JSON
 lines, ``SUMMARY.md`` generated from them by ``scripts/profiles_summary.py``).  Round 2's verdict found three
 numbers in the docs that no committed file held.  These tests tie the headline figures of DESIGN.md section 5 to
 the committed files mechanically: a re-profile that is not followed by a doc update fails here."""
@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PROF = os.path.join(ROOT, "profiles", "r03")
+PROF = os.path.join(ROOT, "profiles", "r04")
 
 
 def _line(name):
@@ -42,19 +42,31 @@ def test_headline_numbers_in_design_are_the_committed_bench_lines():
     # the strict-mode parity the line carries
     strict = pf["parity_vs_oracle"]["strict_f32_free_running"]
     assert strict["differing_ancestors"] == 0 and strict["differing_estimate_values"] == 0 and strict["rmse_rel_diff"] == 0.0
+    # round 4: the weight regime the line was measured in, the certificate taken there, and every BASELINE config
+    ess = pf["ess_over_m"]
+    assert ess["steps_with_batch_mean_in_band"] == ess["steps"] == 128
+    assert 0.05 <= ess["per_step_batch_mean_min"] and ess["per_step_batch_mean_max"] <= 0.5
+    assert f"{ess['per_step_batch_mean_min']:.3f}" in text and f"{ess['per_step_batch_mean_max']:.3f}" in text
+    for key in ("teacher_forced", "teacher_forced_f32"):
+        cert = pf["parity_vs_oracle"][key]["mismatch_certificate"]
+        assert cert["unexplained"] == 0 and cert["k1_inexact_on_own_weights"] == 0, key
+        assert pf["parity_vs_oracle"][key]["max_rel_err_posterior_mean"] < 1e-4, key
+    assert {"C2", "C3", "C4", "C5"} <= {k[:2] for k in pf["configs"]} and sum(k.startswith("blackout") for k in pf["configs"]) == 2
+    c5 = next(v for k, v in pf["configs"].items() if k.startswith("C5"))
+    assert f"{c5['ms_per_step']:.1f}" in text, "C5 training step (configs of bench_door_pf_n1.json)"
 
 
 def test_kernel_durations_in_design_are_the_committed_rocprof_averages():
     text = _design()
-    for csv_name, prefix in (("door_pf_kernel_stats.csv", "particle_net_kernel<3, 2, 1, 2, 1, 2, true>"),
-                             ("door_pf_kernel_stats.csv", "particle_net_kernel<3, 3, 0, 2, 1, 2, true>"),
+    for csv_name, prefix in (("door_pf_kernel_stats.csv", "particle_net_kernel<3, 2, 1, 2, 1, 2, true, false>"),
+                             ("door_pf_kernel_stats.csv", "particle_net_kernel<3, 3, 0, 2, 1, 2, true, false>"),
                              ("door_pf_kernel_stats.csv", "pf_resample_systematic_kernel<3, true>"),
                              ("door_ekf_kernel_stats.csv", "conv2b_conv3_kernel<false, 2, true>"),
                              ("door_ekf_kernel_stats.csv", "stem_conv2a_kernel<false>")):
         us = _avg_us(csv_name, prefix)
         assert f"{us:.1f}" in text, f"{prefix}: {us:.1f} us ({csv_name}) is not what DESIGN.md quotes"
     # the roofline fraction follows from the measurement kernel's average: 6.067e10 FLOP per launch
-    us = _avg_us("door_pf_kernel_stats.csv", "particle_net_kernel<3, 2, 1, 2, 1, 2, true>")
+    us = _avg_us("door_pf_kernel_stats.csv", "particle_net_kernel<3, 2, 1, 2, 1, 2, true, false>")
     frac = 6.067e10 / (us * 1e-6) / 2.5e15
     assert f"{frac:.3f}" in text
 
@@ -62,7 +74,7 @@ def test_kernel_durations_in_design_are_the_committed_rocprof_averages():
 def test_summary_is_what_the_script_generates_from_the_committed_files():
     with open(os.path.join(PROF, "SUMMARY.md")) as fh:
         committed = fh.read()
-    out = subprocess.run([sys.executable, os.path.join("scripts", "profiles_summary.py"), os.path.join("profiles", "r03"), "--stdout"],
+    out = subprocess.run([sys.executable, os.path.join("scripts", "profiles_summary.py"), os.path.join("profiles", "r04"), "--stdout"],
                          capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-1000:]
     assert out.stdout.strip() == committed.strip()
