@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 35
+#define MMF_ABI_VERSION 36
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -544,13 +544,17 @@ typedef struct MmfPfTrainArgs {
   int32_t* range_flag;
   int32_t compact;           /* ABI 35.  1: the recompute buffers in half the bytes -- `stash` and `dz` are then f16 arrays of
                                 the SAME SHAPES (half the allocation), activations stored as f16 and the pre-activation
-                                gradients as f16 relative to their row's largest magnitude, kept in `dz_scale`; the
-                                weight-gradient products stay fp32 on the exact-fp32 MFMA.  The data path of the
+                                gradients as f16 relative to the largest magnitude of their 32-row tile, kept in `dz_scale`; the
+                                weight-gradient products of the f16 values are exact (f16 MFMA, fp32 accumulate).  The data path of the
                                 backward (d_states, the masks, the recursion's gradients) is untouched: only the
                                 parameter gradients see the rounding (2^-11 relative per stored element, measured
                                 <= 1e-3 of the gradient norm -- tests/test_gpu_training.py).  0: fp32 buffers (bit-identical
                                 to ABI 34) */
   float* dz_scale;           /* compact: scratch (max(NLd, NLm) + 1, chunk_traj M) [x (n_meas + 1) sets if concurrent]; else unused */
+  int32_t recompute_f16x3;   /* ABI 36.  backward, with compact = 1 and precision = MMF_PREC_F16X3: the recompute of a step's
+                                activations runs on `packed` (the forward pass's f16x3 blob) with the forward pass's own
+                                three-product arithmetic instead of exact fp32 products on `packed_f32`: the stash and the
+                                ReLU masks are then those of the forward pass that produced the loss.  0: exact fp32 */
 } MmfPfTrainArgs;
 
 int mmf_pf_train_forward(const MmfPfTrainArgs* args /* host */, void* stream);

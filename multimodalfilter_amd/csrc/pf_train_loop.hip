@@ -185,12 +185,15 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
   const bool cmp = a->compact != 0;
   if (cmp && !a->dz_scale) return MMF_EINVAL;
   const size_t esz = cmp ? 2 : 4;
+  const bool f16r = cmp && a->recompute_f16x3 != 0 && a->precision == MMF_PREC_F16X3;
   auto stash_of = [&](int set) { return reinterpret_cast<char*>(a->stash) + (conc ? set * set_act : 0) * esz; };
   auto dz_of = [&](int set) { return reinterpret_cast<char*>(a->dz) + (conc ? set * set_act : 0) * esz; };
   auto scale_of = [&](int set) { return cmp ? a->dz_scale + (conc ? set * static_cast<size_t>(NLmax + 1) * Cmax : 0) : nullptr; };
   auto net_fwd = [&](const MmfTrainNet& net, int n_res, int kind, const float* xs, const float* bias, char* stash, uint32_t* mask,
                      float* raw, int Nc, hipStream_t s) {
-    return cmp ? mmf_internal_train_forward_h(net.packed_f32, n_res, kind, xs, bias, stash, mask, raw, Nc, M, d, s)
+    // compact + recompute_f16x3: the recompute in the forward pass's own arithmetic, on the forward pass's blob
+    return cmp ? (f16r ? mmf_internal_train_forward_h(net.packed, MMF_PREC_F16X3, n_res, kind, xs, bias, stash, mask, raw, Nc, M, d, s)
+                       : mmf_internal_train_forward_h(net.packed_f32, MMF_PREC_F32, n_res, kind, xs, bias, stash, mask, raw, Nc, M, d, s))
                : mmf_particle_net_train_forward(net.packed_f32, n_res, kind, xs, bias, reinterpret_cast<float*>(stash), mask, raw, Nc, M, d, s);
   };
   auto net_bwd = [&](const MmfTrainNet& net, int n_res, int kind, const uint32_t* mask, const float* d_out, char* dz, float* sc,

@@ -485,11 +485,16 @@ TRAIN_CHUNK_ROWS = int(os.environ.get("MMF_TRAIN_CHUNK_ROWS", "262144"))
 # the overlap of kernels that are 25 us long buys.
 TRAIN_CONCURRENT_ROWS = int(os.environ.get("MMF_TRAIN_CONCURRENT_ROWS", "0"))
 # MmfPfTrainArgs.compact: the recompute buffers of the backward in half the bytes (activations as f16, pre-activation
-# gradients as f16 relative to their row's largest magnitude + one fp32 scale per row and layer).  They are the
+# gradients as f16 relative to the largest magnitude of their 32-row tile + one fp32 scale per row and layer).  They are the
 # recursion's HBM traffic (written once, read once by the weight-gradient pass).  Only the PARAMETER gradients see the
 # rounding (the backward's data path -- d_states, the recursion's gradients -- is computed in registers from fp32):
 # tests/test_gpu_training.py bounds it.  MMF_TRAIN_COMPACT_STASH=0 restores the fp32 buffers (bit-identical to round 3).
 TRAIN_COMPACT_STASH = os.environ.get("MMF_TRAIN_COMPACT_STASH", "1") != "0"
+# MmfPfTrainArgs.recompute_f16x3 (with the compact buffers, when the engine's mode is f16x3): the backward recomputes a
+# step's activations with the arithmetic the forward pass used (the inference kernels' three f16 products per product)
+# instead of exact fp32 products -- the stash and the ReLU masks are then the forward pass's own, at a fifth of the
+# exact-fp32 MFMA time.  MMF_TRAIN_RECOMPUTE_F16X3=0: exact fp32 recompute (round 3).
+TRAIN_RECOMPUTE_F16X3 = os.environ.get("MMF_TRAIN_RECOMPUTE_F16X3", "1") != "0"
 
 
 class PfTrainLoopFunction(torch.autograd.Function):
@@ -544,6 +549,7 @@ class PfTrainLoopFunction(torch.autograd.Function):
         a.range_flag = ctypes.c_void_p(range_flag(dev).data_ptr())
         _abi.pf_train_forward(a, states)
         ctx.nets, ctx.shape, ctx.keep, ctx.blobs = nets, (T, N, M, d), keep, blobs
+        ctx.fwd_blobs, ctx.fwd_precision = fwd_blobs, int(a.precision)
         ctx.save_for_backward(*[p.detach() for p in params])
         sT, lT = states[T], logw[T]
         ctx.mark_non_differentiable(sT, lT)
@@ -568,7 +574,11 @@ class PfTrainLoopFunction(torch.autograd.Function):
         P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
         a = _abi.MmfPfTrainArgs()
         a.T, a.N, a.M, a.d, a.n_meas = T, N, M, d, K
-        a.n_res_dyn, a.n_res_meas, a.logw_stride, a.precision = dyn_net.n_res, meas[0][0].n_res, K_all, _abi.PREC_F32
+        # recompute in the forward pass's own arithmetic (f16x3 blobs) or with exact fp32 products
+        f16r = TRAIN_COMPACT_STASH and TRAIN_RECOMPUTE_F16X3 and ctx.fwd_precision == _abi.PREC_F16X3
+        a.n_res_dyn, a.n_res_meas, a.logw_stride = dyn_net.n_res, meas[0][0].n_res, K_all
+        a.precision = _abi.PREC_F16X3 if f16r else _abi.PREC_F32
+        a.recompute_f16x3 = int(f16r)
         a.chunk_traj, a.n_splits, a.n_slices = chunk_traj, S, SL
         a.concurrent = int(N * M <= TRAIN_CONCURRENT_ROWS)
         sets = K + 1 if a.concurrent else 1  # private scratch per concurrently running network
@@ -586,7 +596,8 @@ class PfTrainLoopFunction(torch.autograd.Function):
             bufs.append(b)
             head_ws.append(params[offs[i + 1] - 2].to(torch.float32).contiguous())
             tblobs.append(_transposed_blob(net))
-            tn.packed = tn.packed_f32 = P(ctx.blobs[i])
+            tn.packed_f32 = P(ctx.blobs[i])
+            tn.packed = P(ctx.fwd_blobs[i]) if f16r else tn.packed_f32
             tn.packed_t, tn.head_w = P(tblobs[i]), P(head_ws[i])
             tn.pw, tn.pb, tn.p_first, tn.p_head, tn.p_dout, tn.p_traj = (P(b[k]) for k in ("pw", "pb", "p_first", "p_head", "p_dout", "p_traj"))
         for k in range(K):

@@ -832,7 +832,7 @@ def test_native_training_recursion_matches_stepwise(tname, cls, N, M, T, chunk_r
 ])
 def test_compact_recompute_buffers_change_only_the_rounding_of_parameter_gradients(tname, cls, N, M, T, chunk_rows):
     """``MmfPfTrainArgs.compact`` (round 4: the backward's recompute buffers as f16 -- activations directly, the
-    pre-activation gradients relative to their row's largest magnitude with one fp32 scale per row and layer): the
+    pre-activation gradients relative to the largest magnitude of their 32-row tile with one fp32 scale per row and layer): the
     forward recursion and the backward's DATA path (what flows to earlier steps) never read the buffers, so loss and
     estimates are bit-identical; every parameter gradient stays within 1e-3 of its tensor's scale (f16 keeps 2^-11
     per stored element and the products are summed over thousands of rows in fp32; observed <= 3e-4) -- and gradients
@@ -851,8 +851,9 @@ def test_compact_recompute_buffers_change_only_the_rounding_of_parameter_gradien
     f = mmf.model_types(tname)[cls]().to(dev).train()
     f.num_particles = M
     engine.set_training_backend("hip")
-    old_chunk, old_compact = engine.TRAIN_CHUNK_ROWS, engine.TRAIN_COMPACT_STASH
+    old_chunk, old_compact, old_f16r = engine.TRAIN_CHUNK_ROWS, engine.TRAIN_COMPACT_STASH, engine.TRAIN_RECOMPUTE_F16X3
     engine.TRAIN_CHUNK_ROWS = chunk_rows
+    engine.TRAIN_RECOMPUTE_F16X3 = False  # the buffers' FORMAT is what is compared: both sides recompute with exact fp32 products
     seen = []
     real = mmf._abi.pf_train_backward
     mmf._abi.pf_train_backward = lambda a, *rest: (seen.append(int(a.compact)), real(a, *rest))[1]
@@ -872,7 +873,7 @@ def test_compact_recompute_buffers_change_only_the_rounding_of_parameter_gradien
     finally:
         mmf._abi.pf_train_backward = real
         engine.set_training_backend(None)
-        engine.TRAIN_CHUNK_ROWS, engine.TRAIN_COMPACT_STASH = old_chunk, old_compact
+        engine.TRAIN_CHUNK_ROWS, engine.TRAIN_COMPACT_STASH, engine.TRAIN_RECOMPUTE_F16X3 = old_chunk, old_compact, old_f16r
     assert seen == [0, 1, 0, 1]
     for (l0, p0, g0), (l1, p1, g1) in ((results[0], results[1]), (results[2], results[3])):
         assert torch.equal(l0, l1) and torch.equal(p0, p1)
@@ -885,6 +886,67 @@ def test_compact_recompute_buffers_change_only_the_rounding_of_parameter_gradien
         # parameters the buffers never touch (the encoders' of the crossmodal weights / per-trajectory biases reach
         # the networks only through p_traj / p_dout, reduced from dz) differ by rounding too, never by a dropped term
         assert all(bool(torch.isfinite(v).all()) for v in g1.values())
+
+
+@pytest.mark.parametrize("tname,cls,N,M,T,chunk_rows", [
+    ("door", "DoorCrossmodalParticleFilter", 32, 30, 6, 262144),  # the reference's training shape
+    ("door", "DoorCrossmodalParticleFilter", 5, 300, 3, 600),     # ragged chunks
+    ("push", "PushUnimodalParticleFilter", 8, 512, 4, 2048),
+])
+def test_recompute_in_the_forward_arithmetic_tracks_the_exact_fp32_recompute(tname, cls, N, M, T, chunk_rows):
+    """``MmfPfTrainArgs.recompute_f16x3`` (round 4): with the engine in its default f16x3 mode the backward recomputes
+    each step's activations with the three-product f16 arithmetic the FORWARD pass used, on the forward pass's blob,
+    instead of exact fp32 products -- the activations and ReLU masks it differentiates through are then the ones that
+    produced the loss.  The forward pass is untouched (loss and estimates bit-identical); against the exact-fp32
+    recompute the gradients differ by the two arithmetics' 1e-6 on the activations plus the occasional ReLU whose
+    pre-activation lies between them: GRAD_TOL, the file's fp32-vs-fp32 tolerance (observed <= 1e-3)."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine
+
+    dev = torch.device("cuda:0")
+    task = om.TASKS[tname]
+    d = task.state_dim
+    obs, ctrl, x0, target, g = _data(task, T, N, 61)
+    eps0 = torch.randn((N, M, d), generator=g)
+    eps = [torch.randn((N, M, d), generator=g) for _ in range(T)]
+    cov = (torch.eye(d) * 0.1)[None].expand(N, d, d)
+    torch.manual_seed(6)
+    f = mmf.model_types(tname)[cls]().to(dev).train()
+    f.num_particles = M
+    engine.set_training_backend("hip")
+    old_chunk, old_f16r, old_prec = engine.TRAIN_CHUNK_ROWS, engine.TRAIN_RECOMPUTE_F16X3, engine.DEFAULT_PRECISION
+    engine.TRAIN_CHUNK_ROWS = chunk_rows
+    engine.set_default_precision("f16x3")
+    seen = []
+    real = mmf._abi.pf_train_backward
+    mmf._abi.pf_train_backward = lambda a, *rest: (seen.append((int(a.recompute_f16x3), int(a.precision))), real(a, *rest))[1]
+    results = []
+    try:
+        for f16r in (False, True):
+            engine.TRAIN_RECOMPUTE_F16X3 = f16r
+            f.zero_grad(set_to_none=True)
+            f.noise = mmf.ReplayNoise([eps0] + eps, [])
+            f.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
+            pred = f.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
+            loss = torch.mean((pred - target.to(dev)) ** 2)
+            loss.backward()
+            torch.cuda.synchronize()
+            results.append((loss.detach().clone(), pred.detach().clone(),
+                            {n: p.grad.detach().clone() for n, p in f.named_parameters() if p.grad is not None}))
+    finally:
+        mmf._abi.pf_train_backward = real
+        engine.set_training_backend(None)
+        engine.TRAIN_CHUNK_ROWS, engine.TRAIN_RECOMPUTE_F16X3 = old_chunk, old_f16r
+        engine.set_default_precision(old_prec)
+    assert seen == [(0, mmf._abi.PREC_F32), (1, mmf._abi.PREC_F16X3)]
+    (l0, p0, g0), (l1, p1, g1) = results
+    assert torch.equal(l0, l1) and torch.equal(p0, p1)
+    assert set(g0) == set(g1) and len(g0) > 20
+    top = max(float(v.abs().max()) for v in g0.values())
+    worst = max((float((g0[k] - g1[k]).abs().max()) / max(1e-3 * top, float(g0[k].abs().max())), k) for k in g0)
+    print("f16x3 vs exact-fp32 recompute, largest relative gradient difference:", worst)
+    assert worst[0] < GRAD_TOL, worst
+    assert all(bool(torch.isfinite(v).all()) for v in g1.values())
 
 
 @pytest.mark.parametrize("tname,cls,N,M,T,chunk_rows", [
