@@ -555,6 +555,11 @@ typedef struct MmfPfTrainArgs {
                                 activations runs on `packed` (the forward pass's f16x3 blob) with the forward pass's own
                                 three-product arithmetic instead of exact fp32 products on `packed_f32`: the stash and the
                                 ReLU masks are then those of the forward pass that produced the loss.  0: exact fp32 */
+  int32_t backward_f16x3;    /* ABI 36.  backward, with compact = 1: `packed_t` of every network is an MMF_PREC_F16X3 blob of
+                                the transposed layers and the backward data path multiplies on the f16 MFMA with three
+                                products per product; each layer's input tile (32 rows) is scaled by the power of two that
+                                brings its largest magnitude to [2^7, 2^8) and the result scaled back (exact: the backward
+                                is linear in the gradients).  0: exact fp32 products on an MMF_PREC_F32 blob */
 } MmfPfTrainArgs;
 
 int mmf_pf_train_forward(const MmfPfTrainArgs* args /* host */, void* stream);

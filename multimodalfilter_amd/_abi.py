@@ -86,7 +86,7 @@ class MmfPfTrainArgs(Structure):
                 ("states", _FP), ("logw", _FP), ("estimates", _FP), ("d_states0", _FP), ("d_logw0", _FP),
                 ("stash", _FP), ("mask", _FP), ("dz", _FP), ("raw", _FP), ("d_raw", _FP), ("loglik", _FP), ("ll_steps", _FP),
                 ("g_states_a", _FP), ("g_states_b", _FP), ("g_logw_a", _FP), ("g_logw_b", _FP), ("d_tmp", _FP),
-                ("range_flag", _FP), ("compact", c_int32), ("dz_scale", _FP), ("recompute_f16x3", c_int32)]
+                ("range_flag", _FP), ("compact", c_int32), ("dz_scale", _FP), ("recompute_f16x3", c_int32), ("backward_f16x3", c_int32)]
 
 
 class MmfEkfLoopArgs(Structure):

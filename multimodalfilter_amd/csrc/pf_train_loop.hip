@@ -186,6 +186,7 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
   if (cmp && !a->dz_scale) return MMF_EINVAL;
   const size_t esz = cmp ? 2 : 4;
   const bool f16r = cmp && a->recompute_f16x3 != 0 && a->precision == MMF_PREC_F16X3;
+  const bool f16b = cmp && a->backward_f16x3 != 0;
   auto stash_of = [&](int set) { return reinterpret_cast<char*>(a->stash) + (conc ? set * set_act : 0) * esz; };
   auto dz_of = [&](int set) { return reinterpret_cast<char*>(a->dz) + (conc ? set * set_act : 0) * esz; };
   auto scale_of = [&](int set) { return cmp ? a->dz_scale + (conc ? set * static_cast<size_t>(NLmax + 1) * Cmax : 0) : nullptr; };
@@ -198,7 +199,9 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
   };
   auto net_bwd = [&](const MmfTrainNet& net, int n_res, int kind, const uint32_t* mask, const float* d_out, char* dz, float* sc,
                      float* d_states, int Ci, hipStream_t s) {
-    return cmp ? mmf_internal_train_backward_h(net.packed_t, net.head_w, n_res, kind, mask, d_out, dz, sc, d_states, Ci, d, s)
+    // backward_f16x3: `packed_t` is then the f16x3 blob of the transposed layers
+    return cmp ? mmf_internal_train_backward_h(net.packed_t, f16b ? MMF_PREC_F16X3 : MMF_PREC_F32, net.head_w, n_res, kind, mask, d_out, dz, sc,
+                                               d_states, Ci, d, s)
                : mmf_particle_net_train_backward(net.packed_t, net.head_w, n_res, kind, mask, d_out, reinterpret_cast<float*>(dz), d_states, Ci, d, s);
   };
   auto net_wgrads = [&](const MmfTrainNet& net, const char* dz, const float* sc, const char* stash, int n_layers, int Ci, int acc,

@@ -325,12 +325,13 @@ class PackedParticleNet:
         return blob
 
 
-def _transposed_blob(net: PackedParticleNet) -> torch.Tensor:
+def _transposed_blob(net: PackedParticleNet, precision: int = _abi.PREC_F32) -> torch.Tensor:
     """Blob of the TRANSPOSED 64x64 layers (K6 backward data path: ``dx = W^T dz`` is a forward
-    layer with ``W^T``); cached like the forward blobs."""
+    layer with ``W^T``) in the given arithmetic's fragment order; cached like the forward blobs."""
     src = net._sources()
     stamp = tuple((t.data_ptr(), t._version, str(t.device)) for t in src)
-    cached = net._blobs.get("transposed")
+    key = "transposed" if precision == _abi.PREC_F32 else f"transposed_{precision}"
+    cached = net._blobs.get(key)
     if cached is not None and cached[0] == stamp:
         return cached[1]
     dev = src[0].device
@@ -354,8 +355,8 @@ def _transposed_blob(net: PackedParticleNet) -> torch.Tensor:
         d.w_res[i], d.b_res[i] = P(keep[5 + i]), P(zeros)
     d.w_head, d.b_head = P(keep[-3]), P(keep[-2])
     blob = torch.empty(_abi.particle_net_floats(net.n_res), dtype=torch.float32, device=dev)
-    _abi.pack_particle_net(d, blob, _abi.PREC_F32)
-    net._blobs["transposed"] = (stamp, blob)
+    _abi.pack_particle_net(d, blob, precision)
+    net._blobs[key] = (stamp, blob)
     return blob
 
 
@@ -495,6 +496,10 @@ TRAIN_COMPACT_STASH = os.environ.get("MMF_TRAIN_COMPACT_STASH", "1") != "0"
 # instead of exact fp32 products -- the stash and the ReLU masks are then the forward pass's own, at a fifth of the
 # exact-fp32 MFMA time.  MMF_TRAIN_RECOMPUTE_F16X3=0: exact fp32 recompute (round 3).
 TRAIN_RECOMPUTE_F16X3 = os.environ.get("MMF_TRAIN_RECOMPUTE_F16X3", "1") != "0"
+# MmfPfTrainArgs.backward_f16x3 (with the two above): the backward DATA path (transposed layers on gradients) on the
+# three-product f16 arithmetic too, every layer's input tile scaled by an exact power of two into the f16 range and
+# the result scaled back (the backward is linear in the gradients).  MMF_TRAIN_BACKWARD_F16X3=0: exact fp32 products.
+TRAIN_BACKWARD_F16X3 = os.environ.get("MMF_TRAIN_BACKWARD_F16X3", "1") != "0"
 
 
 class PfTrainLoopFunction(torch.autograd.Function):
@@ -579,6 +584,8 @@ class PfTrainLoopFunction(torch.autograd.Function):
         a.n_res_dyn, a.n_res_meas, a.logw_stride = dyn_net.n_res, meas[0][0].n_res, K_all
         a.precision = _abi.PREC_F16X3 if f16r else _abi.PREC_F32
         a.recompute_f16x3 = int(f16r)
+        f16b = bool(f16r and TRAIN_BACKWARD_F16X3)
+        a.backward_f16x3 = int(f16b)
         a.chunk_traj, a.n_splits, a.n_slices = chunk_traj, S, SL
         a.concurrent = int(N * M <= TRAIN_CONCURRENT_ROWS)
         sets = K + 1 if a.concurrent else 1  # private scratch per concurrently running network
@@ -595,7 +602,7 @@ class PfTrainLoopFunction(torch.autograd.Function):
                      p_dout=E(T, N * SL, 4), p_traj=E(T, N * SL, U))
             bufs.append(b)
             head_ws.append(params[offs[i + 1] - 2].to(torch.float32).contiguous())
-            tblobs.append(_transposed_blob(net))
+            tblobs.append(_transposed_blob(net, _abi.PREC_F16X3 if f16b else _abi.PREC_F32))
             tn.packed_f32 = P(ctx.blobs[i])
             tn.packed = P(ctx.fwd_blobs[i]) if f16r else tn.packed_f32
             tn.packed_t, tn.head_w = P(tblobs[i]), P(head_ws[i])

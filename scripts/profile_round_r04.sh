@@ -79,8 +79,9 @@ python scripts/bench_reference_sizes.py > $OUT/bench_reference_sizes.txt 2>> $OU
   echo "# MMF_PF_PERSISTENT=0 (one launch per kernel and step)"; MMF_PF_PERSISTENT=0 python scripts/bench_reference_sizes.py --only eval --no-cpu 2>&1 | grep -v amdgpu.ids; } > $OUT/bench_persistent_loop_ab.txt
 python scripts/bench_train.py > $OUT/bench_train_push_unimodal_pf.json 2>> $OUT/bench.err
 python scripts/bench_train.py --backends hip --cnn-precision bf16 >> $OUT/bench_train_push_unimodal_pf.json 2>> $OUT/bench.err
-{ echo "# default: f16 recompute buffers (tile-scaled dz), recompute in the forward pass's f16x3 arithmetic"; python scripts/bench_train.py --backends hip 2>&1 | grep "^{";
-  echo "# MMF_TRAIN_RECOMPUTE_F16X3=0 (f16 buffers, exact-fp32 recompute)"; MMF_TRAIN_RECOMPUTE_F16X3=0 python scripts/bench_train.py --backends hip 2>&1 | grep "^{";
+{ echo "# default: f16 recompute buffers (tile-scaled dz), recompute and backward data path in the forward pass's f16x3 arithmetic"; python scripts/bench_train.py --backends hip 2>&1 | grep "^{";
+  echo "# MMF_TRAIN_BACKWARD_F16X3=0 (f16 buffers, f16x3 recompute, exact-fp32 backward data path)"; MMF_TRAIN_BACKWARD_F16X3=0 python scripts/bench_train.py --backends hip 2>&1 | grep "^{";
+  echo "# MMF_TRAIN_RECOMPUTE_F16X3=0 (f16 buffers, exact-fp32 recompute and backward)"; MMF_TRAIN_RECOMPUTE_F16X3=0 python scripts/bench_train.py --backends hip 2>&1 | grep "^{";
   echo "# MMF_TRAIN_COMPACT_STASH=0 (fp32 recompute buffers, exact-fp32 recompute: round 3)"; MMF_TRAIN_COMPACT_STASH=0 python scripts/bench_train.py --backends hip 2>&1 | grep "^{";
   echo "# default again"; python scripts/bench_train.py --backends hip 2>&1 | grep "^{"; } > $OUT/bench_train_compact_ab.txt
 ./scripts/ubench/k1_phases 256 4096 > $OUT/k1_phases.txt 2>&1; ./scripts/ubench/k1_phases 256 1024 >> $OUT/k1_phases.txt 2>&1; ./scripts/ubench/k1_phases 32 300 >> $OUT/k1_phases.txt 2>&1

@@ -894,10 +894,11 @@ def test_compact_recompute_buffers_change_only_the_rounding_of_parameter_gradien
     ("push", "PushUnimodalParticleFilter", 8, 512, 4, 2048),
 ])
 def test_recompute_in_the_forward_arithmetic_tracks_the_exact_fp32_recompute(tname, cls, N, M, T, chunk_rows):
-    """``MmfPfTrainArgs.recompute_f16x3`` (round 4): with the engine in its default f16x3 mode the backward recomputes
-    each step's activations with the three-product f16 arithmetic the FORWARD pass used, on the forward pass's blob,
-    instead of exact fp32 products -- the activations and ReLU masks it differentiates through are then the ones that
-    produced the loss.  The forward pass is untouched (loss and estimates bit-identical); against the exact-fp32
+    """``MmfPfTrainArgs.recompute_f16x3`` + ``backward_f16x3`` (round 4): with the engine in its default f16x3 mode the
+    backward recomputes each step's activations with the three-product f16 arithmetic the FORWARD pass used, on the
+    forward pass's blob, instead of exact fp32 products -- the activations and ReLU masks it differentiates through are
+    then the ones that produced the loss -- and runs the transposed layers of the data path in the same arithmetic,
+    every layer's gradient tile scaled into the f16 range by an exact power of two and back.  The forward pass is untouched (loss and estimates bit-identical); against the exact-fp32
     recompute the gradients differ by the two arithmetics' 1e-6 on the activations plus the occasional ReLU whose
     pre-activation lies between them: GRAD_TOL, the file's fp32-vs-fp32 tolerance (observed <= 1e-3)."""
     import multimodalfilter_amd as mmf
@@ -919,7 +920,7 @@ def test_recompute_in_the_forward_arithmetic_tracks_the_exact_fp32_recompute(tna
     engine.set_default_precision("f16x3")
     seen = []
     real = mmf._abi.pf_train_backward
-    mmf._abi.pf_train_backward = lambda a, *rest: (seen.append((int(a.recompute_f16x3), int(a.precision))), real(a, *rest))[1]
+    mmf._abi.pf_train_backward = lambda a, *rest: (seen.append((int(a.recompute_f16x3), int(a.precision), int(a.backward_f16x3))), real(a, *rest))[1]
     results = []
     try:
         for f16r in (False, True):
@@ -938,7 +939,7 @@ def test_recompute_in_the_forward_arithmetic_tracks_the_exact_fp32_recompute(tna
         engine.set_training_backend(None)
         engine.TRAIN_CHUNK_ROWS, engine.TRAIN_RECOMPUTE_F16X3 = old_chunk, old_f16r
         engine.set_default_precision(old_prec)
-    assert seen == [(0, mmf._abi.PREC_F32), (1, mmf._abi.PREC_F16X3)]
+    assert seen == [(0, mmf._abi.PREC_F32, 0), (1, mmf._abi.PREC_F16X3, 1)]
     (l0, p0, g0), (l1, p1, g1) = results
     assert torch.equal(l0, l1) and torch.equal(p0, p1)
     assert set(g0) == set(g1) and len(g0) > 20
