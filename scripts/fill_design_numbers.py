@@ -101,6 +101,10 @@ def main(d, design, check):
         rows = [r for r in csv.DictReader(fh) if "particle_net_train_bwd_kernel" in r["Name"]]
     steps = sum(int(r["Calls"]) for r in rows) / 45.0  # 15 transitions x 3 networks per optimiser step
     v["BWDMS"] = f"{sum(int(r['TotalDurationNs']) for r in rows) / 1e6 / steps:.1f}"
+    with open(f"{d}/train_kernel_stats.csv") as fh:
+        allrows = list(csv.DictReader(fh))
+    per_step = lambda key: sum(int(r["TotalDurationNs"]) for r in allrows if key in r["Name"]) / 1e6 / steps
+    v["FWDMS"], v["WGMS"] = f"{per_step('particle_net_train_fwd_kernel'):.1f}", f"{per_step('weight_grad_h_kernel'):.1f}"
     t16, t32 = par["teacher_forced"], par["teacher_forced_f32"]
     v["TFMM16"], v["TFMM32"] = f"{t16['resample_index_mismatch_fraction']:.1e}", f"{t32['resample_index_mismatch_fraction']:.1e}"
     v["DQ"] = f"{max(t16['mismatch_certificate']['max_D_over_Q'], t32['mismatch_certificate']['max_D_over_Q']):.1e}"
