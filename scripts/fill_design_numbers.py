@@ -97,6 +97,7 @@ def main(d, design, check):
     v["K1SWEEP"] = " / ".join(f"{sweep[n]:.1f}" for n in (64, 128, 256, 512, 1024))
     wg = avg_us(f"{d}/train_kernel_stats.csv", "weight_grad_h_kernel")[0]
     v["WGUS"] = f"{wg:.0f}"
+    v["WGTBS"] = f"{0.5625e9 / (wg * 1e-6) / 1e12:.1f}"  # 8 layers x 262,144 rows x (128 B dz + 128 B stash + 4 B scale)
     with open(f"{d}/train_kernel_stats.csv") as fh:
         rows = [r for r in csv.DictReader(fh) if "particle_net_train_bwd_kernel" in r["Name"]]
     steps = sum(int(r["Calls"]) for r in rows) / 45.0  # 15 transitions x 3 networks per optimiser step
