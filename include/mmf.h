@@ -557,9 +557,9 @@ typedef struct MmfPfTrainArgs {
                                 ReLU masks are then those of the forward pass that produced the loss.  0: exact fp32 */
   int32_t backward_f16x3;    /* ABI 36.  backward, with compact = 1: `packed_t` of every network is an MMF_PREC_F16X3 blob of
                                 the transposed layers and the backward data path multiplies on the f16 MFMA with three
-                                products per product; each layer's input tile (32 rows) is scaled by the power of two that
-                                brings its largest magnitude to [2^7, 2^8) and the result scaled back (exact: the backward
-                                is linear in the gradients).  0: exact fp32 products on an MMF_PREC_F32 blob */
+                                products per product; each ROW of a layer's input is scaled by the power of two that
+                                brings its largest magnitude to [2^7, 2^8) and its result scaled back (exact: the backward
+                                is linear in the gradients and rows do not mix).  0: exact fp32 products on an MMF_PREC_F32 blob */
 } MmfPfTrainArgs;
 
 int mmf_pf_train_forward(const MmfPfTrainArgs* args /* host */, void* stream);
