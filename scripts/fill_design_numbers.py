@@ -86,6 +86,15 @@ def main(d, design, check):
     m0, m4 = k2["variant0_column_half_pipeline"]["measurement"], k2["variant4_row_tile_pipeline"]["measurement"]
     v["MFMABUSY0"], v["CLK0"], v["MFMABUSY4"], v["CLK4"] = (f"{m0['mfma_busy_fraction']:.3f}", f"{m0['effective_clock_GHz']:.2f}",
                                                           f"{m4['mfma_busy_fraction']:.3f}", f"{m4['effective_clock_GHz']:.2f}")
+    try:
+        k4 = json.load(open(f"{d}/pmc_k4_sq_counters.json"))["kernels"]
+        c23, cst = k4["conv2b_conv3"], k4["stem_conv2a"]
+        v["K4BUSY23"], v["K4CLK23"] = f"{c23['mfma_busy_fraction']:.3f}", f"{c23['effective_clock_GHz']:.2f}"
+        v["K4BUSYSTEM"], v["K4CLKSTEM"] = f"{cst['mfma_busy_fraction']:.3f}", f"{cst['effective_clock_GHz']:.2f}"
+        v["K4CONF23"] = f"{c23['counters']['SQ_LDS_BANK_CONFLICT'] / c23['counters']['SQ_INSTS_LDS']:.2f}"
+        v["K4CONFSTEM"] = f"{cst['counters']['SQ_LDS_BANK_CONFLICT'] / cst['counters']['SQ_INSTS_LDS']:.2f}"
+    except OSError:
+        pass
     bare = float(re.search(r"32x32x16 fill 0: .*? ([0-9.]+) TFLOP/s", open(f"{d}/ubench_mfma_shape.txt").read()).group(1))
     v["BARE"], v["BAREFRAC"] = f"{bare:,.0f}", f"{bare / 2500:.3f}"
     exec_pf = lambda m: m["counters"]["SQ_INSTS_MFMA"] * 32768.0 / (m["avg_us_under_pmc"] * 1e-6) / 1e15

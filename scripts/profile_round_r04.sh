@@ -53,6 +53,9 @@ for tag in ("variant0_column_half_pipeline", "variant4_row_tile_pipeline"):
         out[tag] = str(e)
 print(json.dumps(out, indent=1))
 PY
+# K4: the same counters for the image-encoder kernels of the EKF bench
+bash scripts/pmc_k4_r04.sh final > /dev/null 2>&1
+cp gpurun_out/pmc_k4_r04/final.json $OUT/pmc_k4_sq_counters.json
 bash scripts/debug/k2_rowpipe_ab.sh > $OUT/bench_k2_rowpipe_ab.txt 2>&1
 ./scripts/ubench/mfma_shape > $OUT/ubench_mfma_shape.txt 2>&1
 # plain bench lines (un-profiled)
@@ -73,6 +76,8 @@ python scripts/debug/rccl_probe.py 2>&1 | grep -E "^rank|^world|Duplicate GPU" |
 python scripts/bench_k4.py > $OUT/bench_k4.txt 2>> $OUT/bench.err
 python scripts/bench_k1.py > $OUT/bench_k1.txt 2>> $OUT/bench.err
 python scripts/bench_k1.py --batch-sweep > $OUT/bench_k1_dephase_ab.txt 2>> $OUT/bench.err
+# kernel-level checks of the compact training path against fp64 / the exact-fp32 kernel
+{ python scripts/debug/wgrad_h_check.py; python scripts/debug/bwd_h_check.py; } 2>&1 | grep -v amdgpu.ids > $OUT/check_train_f16_kernels.txt
 # the sizes the reference itself runs: persistent loop (default) vs the loop of launches, with the stamps of one step
 python scripts/bench_reference_sizes.py > $OUT/bench_reference_sizes.txt 2>> $OUT/bench.err
 { echo "# MMF_PF_PERSISTENT=1 (default)"; MMF_PERSIST_STAMPS=40 python scripts/bench_reference_sizes.py --only eval --no-cpu --eval-repeats 1 2>&1 | grep -v amdgpu.ids;
