@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""Fill the @@NAME@@ placeholders of a DESIGN.md draft from the committed files of a profile round, so that every
-number of the round's sections is read off an artefact (``tests/test_docs_cpu.py`` then ties text and files together).
+"""DESIGN.md is GENERATED: ``DESIGN.md.in`` holds the text with @@NAME@@ placeholders for every number of the round's
+sections, this script fills them from the committed files of the profile round, so each such number is read off an
+artefact (``tests/test_docs_cpu.py`` checks that DESIGN.md is what this script makes of the template and the files).
 
-    python scripts/fill_design_numbers.py profiles/r04 DESIGN.md [--check]   # --check: print the table, write nothing
+    python scripts/fill_design_numbers.py profiles/r04 DESIGN.md.in DESIGN.md [--check | --stdout]
+    --check: print the table of values, write nothing;  --stdout: write the filled text to stdout
 """
 import csv
 import json
@@ -35,7 +37,7 @@ def e6(v):
     return f"{v / 1e6:.3f}e6"
 
 
-def main(d, design, check):
+def main(d, design, out_path, check, to_stdout=False):
     pf, drv, ekf = line(f"{d}/bench_door_pf_n1.json"), line(f"{d}/bench_driver_flags_door_pf.json"), line(f"{d}/bench_door_ekf_n1.json")
     cfg = pf["configs"]
     by = lambda p: next(v for k, v in cfg.items() if k.startswith(p))
@@ -44,6 +46,11 @@ def main(d, design, check):
     v = {}
     v["HEAD"], v["HEADMS"] = e9(pf["value"]), f"{pf['ms_per_step']:.3f}"
     v["DRV"], v["DRVMS"] = e9(drv["value"]), f"{drv['ms_per_step']:.3f}"
+    try:  # the same kernels on another box of the pool (an earlier profile round of this round)
+        v["HEADOB"], v["DRVOB"] = e9(line(f"{d}/bench_door_pf_n1_other_box.json")["value"]), e9(line(f"{d}/bench_driver_flags_door_pf_other_box.json")["value"])
+        v["EKFOB"] = e6(line(f"{d}/bench_door_ekf_n1_other_box.json")["value"])
+    except OSError:
+        pass
     v["ESSLO"], v["ESSHI"] = f"{ess['per_step_batch_mean_min']:.3f}", f"{ess['per_step_batch_mean_max']:.3f}"
     v["BENCHS"] = f"{pf['bench_seconds']:.0f}"
     v["EKF"], v["EKFMS"] = e6(ekf["value"]), f"{ekf['ms_per_step']:.3f}"
@@ -128,13 +135,18 @@ def main(d, design, check):
         for k in sorted(v):
             print(f"{k:12s} {v[k]}")
     if missing:
-        print("no value for:", missing)
+        print("no value for:", missing, file=sys.stderr)
     if not check:
         for k, val in v.items():
             text = text.replace(f"@@{k}@@", val)
-        open(design, "w").write(text)
-        print(f"filled {len(names) - len(missing)} placeholders, {len(missing)} left")
+        if to_stdout:
+            sys.stdout.write(text)
+            return
+        open(out_path, "w").write(text)
+        print(f"filled {len(names) - len(missing)} placeholders, {len(missing)} left -> {out_path}")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1].rstrip("/"), sys.argv[2], "--check" in sys.argv[3:])
+    flags = [a for a in sys.argv[1:] if a.startswith("--")]
+    pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+    main(pos[0].rstrip("/"), pos[1], pos[2] if len(pos) > 2 else pos[1].replace(".in", ""), "--check" in flags, "--stdout" in flags)

@@ -78,3 +78,13 @@ def test_summary_is_what_the_script_generates_from_the_committed_files():
                          capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-1000:]
     assert out.stdout.strip() == committed.strip()
+
+
+def test_design_is_generated_from_its_template_and_the_committed_files():
+    """``DESIGN.md.in`` holds the text, ``scripts/fill_design_numbers.py`` fills its @@NAME@@ placeholders from
+    ``profiles/r04``: an edit of DESIGN.md itself, or a re-profile without regenerating, fails here."""
+    out = subprocess.run([sys.executable, os.path.join("scripts", "fill_design_numbers.py"), os.path.join("profiles", "r04"),
+                          "DESIGN.md.in", "--stdout"], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-1000:]
+    assert "@@" not in out.stdout
+    assert out.stdout == _design()
