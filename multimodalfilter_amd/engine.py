@@ -191,6 +191,32 @@ def range_flag(device) -> torch.Tensor:
     return _RANGE_FLAGS[key]
 
 
+_PERSISTENT_WARNED = False
+
+
+def persistent_loop_gave_up(device) -> bool:
+    """After a persistent particle-filter loop: did it abort (bit 2 of the range flag: a hand-off's bounded spin ran
+    out because a workgroup of the launch was not resident, e.g. another process shares the GPU)?  Clears the bit,
+    switches the persistent form off for the rest of the process and warns once; the caller re-runs the loop as a
+    loop of launches.  One 4-byte device->host read."""
+    global PF_PERSISTENT, _PERSISTENT_WARNED
+    flag = _RANGE_FLAGS.get(str(device))
+    if flag is None:
+        return False
+    bits = int(flag.item())
+    if not bits & 4:
+        return False
+    flag.bitwise_and_(~4)
+    PF_PERSISTENT = False
+    if not _PERSISTENT_WARNED:
+        _PERSISTENT_WARNED = True
+        import warnings
+        warnings.warn("the persistent particle-filter loop gave up waiting for a hand-off (a workgroup of its launch was not "
+                      "resident -- is another process using this GPU?); this forward_loop is re-run as a loop of launches and the "
+                      "persistent form is switched off for this process (MMF_PF_PERSISTENT=0 does so from the start)")
+    return True
+
+
 def check_range(device):
     """Raise if any f16x3 launch since the last check saturated its operand split (one
     4-byte device->host read; filters call it once per ``forward_loop`` / on demand)."""

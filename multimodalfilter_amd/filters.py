@@ -351,6 +351,9 @@ class ParticleFilter(base.Filter):
             keep.append(sync)
             a.persistent, a.n_sync_words = 1, n_words
             a.sync_words = ctypes.c_void_p(_abi.ptr(sync, dtype=torch.int32))
+            # the persistent launch needs ALL its workgroups resident; if it gives up (another process on this GPU),
+            # the loop is re-run from this copy of the belief as a loop of launches -- see below
+            belief_backup = (states_a.clone(), logw_a.clone())
         events = None
         names = ["particle_net_dynamics"] + ["particle_net_measure"] * (1 if fused_measure else len(nets)) + ["pf_reweight_resample"]
         stride = 1
@@ -358,6 +361,13 @@ class ParticleFilter(base.Filter):
             stride = max(1, int(timer.loop_stride))
             events = timer.loop_events(2 * len(names) * len(range(stride // 2, T, stride)))  # pf_loop.hip samples t % stride == stride // 2
         loc = _abi.pf_forward_loop(a, like, events, stride)
+        if a.persistent and engine.persistent_loop_gave_up(dev):
+            # bounded spins ran out (a workgroup of the launch was not resident): nothing of this call can be used.
+            # Restore the belief, take the launch-per-step path for this call and for the rest of the process.
+            states_a.copy_(belief_backup[0])
+            logw_a.copy_(belief_backup[1])
+            a.persistent = 0
+            loc = _abi.pf_forward_loop(a, like, events, stride)
         if timer is not None:
             R = N * M
             dflops = 2.0 * R * engine.particle_net_macs(d, dyn._net.n_res, dyn._net.n_out)

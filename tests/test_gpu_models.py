@@ -318,6 +318,72 @@ def test_native_step_loop_equals_stepwise(resample, T, alpha, method):
     f(observations={k: v[0] for k, v in obs.items()}, controls=ctrl[0])
 
 
+def test_persistent_loop_that_gives_up_is_rerun_as_a_loop_of_launches():
+    """The persistent launch needs all of its workgroups resident at once; when a hand-off's bounded spin runs out
+    (another process on the GPU) the kernel aborts and raises bit 2 of the range flag.  ``ParticleFilter`` then restores
+    the belief it saved, re-runs the call as a loop of launches, switches the persistent form off for the process and
+    warns once.  Simulated here: the first (persistent) C call is followed by a scrambled belief and the abort bit --
+    estimates and final belief must equal the launch path's, bit for bit, and the next call must not try again."""
+    _need_gpu()
+    import warnings
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import _abi, engine, synthetic
+
+    dev = torch.device("cuda:0")
+    N, M, T, d = 8, 300, 5, 3
+    old_persist, old_warned = engine.PF_PERSISTENT, engine._PERSISTENT_WARNED
+    try:
+        torch.manual_seed(3)
+        f = mmf.door_models.DoorCrossmodalParticleFilter().to(dev).eval()
+        f.num_particles = M
+        traj = {k: v.to(dev) for k, v in synthetic.make_trajectories(state_dim=d, T=T + 1, N=N, seed=23).items()}
+        obs = {k: traj[k][1:] for k in ("image", "gripper_pos", "gripper_sensors")}
+        ctrl = traj["controls"][1:]
+        cov = (torch.eye(d, device=dev) * 0.1)[None].expand(N, d, d)
+        g = torch.Generator(device=dev).manual_seed(5)
+        eps0 = torch.randn((N, M, d), generator=g, device=dev)
+        eps = torch.randn((2 * T, N, M, d), generator=g, device=dev)
+        us = torch.rand((2 * T, N), generator=g, device=dev)
+
+        def run(persistent, sabotage):
+            engine.PF_PERSISTENT, engine._PERSISTENT_WARNED = persistent, False
+            taken = []
+            real = _abi.pf_forward_loop
+
+            def spy(a, like, *r, **k):
+                taken.append(int(a.persistent))
+                loc = real(a, like, *r, **k)
+                if sabotage and a.persistent:  # what an aborted launch leaves behind: garbage and the abort bit
+                    f.particle_states.fill_(float("nan"))
+                    f.particle_log_weights.fill_(0.0)
+                    engine.range_flag(dev).bitwise_or_(4)
+                return loc
+
+            _abi.pf_forward_loop = spy
+            try:
+                f.noise = mmf.StackedNoise(eps0, eps, us)
+                f.initialize_beliefs(mean=traj["states"][0], covariance=cov)
+                with warnings.catch_warnings(record=True) as caught:
+                    warnings.simplefilter("always")
+                    a = f.forward_loop(observations=obs, controls=ctrl)
+                    b = f.forward_loop(observations={k: v[:2] for k, v in obs.items()}, controls=ctrl[:2])
+                return taken, [str(w.message) for w in caught], a, b, f.particle_states.clone(), f.particle_log_weights.clone()
+            finally:
+                _abi.pf_forward_loop = real
+
+        ref = run(False, False)
+        got = run(True, True)
+        assert ref[0] == [0, 0]
+        assert got[0] == [1, 0, 0], got[0]          # persistent, its re-run, and a second call that does not try again
+        assert len(got[1]) == 1 and "gave up" in got[1][0]
+        assert engine.PF_PERSISTENT is False
+        for x, y in zip(ref[2:], got[2:]):
+            assert torch.equal(x, y)
+        engine.check_range(dev)                      # the abort bit was consumed: nothing left to raise
+    finally:
+        engine.PF_PERSISTENT, engine._PERSISTENT_WARNED = old_persist, old_warned
+
+
 @pytest.mark.parametrize("cls,N,M,T,precision,noise", [
     ("DoorCrossmodalParticleFilter", 32, 300, 9, "f16x3", "tensor"),    # the reference's evaluation size (door_models/pf.py:24-27)
     ("DoorCrossmodalParticleFilter", 32, 300, 6, "f32", "tensor"),      # the bit-reproducible mode
