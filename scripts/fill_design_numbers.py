@@ -49,6 +49,8 @@ def main(d, design, out_path, check, to_stdout=False):
     try:  # the same kernels on another box of the pool (an earlier profile round of this round)
         v["HEADOB"], v["DRVOB"] = e9(line(f"{d}/bench_door_pf_n1_other_box.json")["value"]), e9(line(f"{d}/bench_driver_flags_door_pf_other_box.json")["value"])
         v["EKFOB"] = e6(line(f"{d}/bench_door_ekf_n1_other_box.json")["value"])
+        v["HEADOBB"], v["DRVOBB"] = e9(line(f"{d}/bench_door_pf_n1_other_box_b.json")["value"]), e9(line(f"{d}/bench_driver_flags_door_pf_other_box_b.json")["value"])
+        v["EKFOBB"] = e6(line(f"{d}/bench_door_ekf_n1_other_box_b.json")["value"])
     except OSError:
         pass
     v["ESSLO"], v["ESSHI"] = f"{ess['per_step_batch_mean_min']:.3f}", f"{ess['per_step_batch_mean_max']:.3f}"
