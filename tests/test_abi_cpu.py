@@ -134,3 +134,47 @@ def test_size_limits_and_empty_batches_at_the_boundary():
     assert lib.mmf_dynamics_jacobian(P[0], 3, F32, P[1], P[2], P[3], P[4], None, 0, 3, None) == 0
     assert lib.mmf_image_encoder((ctypes.c_void_p * 1)(P[0]), 1, P[1], P[2], P[3], None, F32, 0, 0, None) == 0
     assert lib.mmf_traj_program(P[0], 1, P[1], (ctypes.c_void_p * 8)(), 0, 1, 64, None) == 0
+
+
+def test_every_host_struct_of_the_binding_matches_the_header_field_by_field(tmp_path):
+    """The ctypes structures of ``_abi.py`` against ``include/mmf.h`` as a C compiler lays it out: a small C program
+    (gcc, the header compiled as plain C) prints ``sizeof`` and the ``offsetof`` of every field, which must equal
+    ctypes' -- a field added to one side only, or in another order, fails here instead of corrupting a launch."""
+    import shutil
+    import subprocess
+
+    from multimodalfilter_amd import _abi
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("no gcc")
+    structs = ["MmfParticleNetDesc", "MmfImageEncoderDesc", "MmfPfLoopArgs", "MmfTrainNet", "MmfPfTrainArgs", "MmfTrajInstr",
+               "MmfEkfLoopArgs"]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(ROOT, "include", "mmf.h")}"', "int main(void) {"]
+    for name in structs:
+        cls = getattr(_abi, name)
+        lines.append(f'  printf("{name} size %zu\\n", sizeof({name}));')
+        for field, _t in cls._fields_:
+            lines.append(f'  printf("{name} {field} %zu\\n", offsetof({name}, {field}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    out = subprocess.run([gcc, "-std=c99", "-o", str(exe), str(src)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]  # a field the binding names and the header lacks does not compile
+    got = {}
+    for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines():
+        name, field, value = line.split()
+        got[(name, field)] = int(value)
+    for name in structs:
+        cls = getattr(_abi, name)
+        assert got[(name, "size")] == ctypes.sizeof(cls), (name, got[(name, "size")], ctypes.sizeof(cls))
+        for field, _t in cls._fields_:
+            assert got[(name, field)] == getattr(cls, field).offset, (name, field)
+    # and the header has no field the binding lacks: sizes are equal and every binding field sits where C puts it,
+    # so an extra C field would have to hide in padding -- the structs are checked to have none at their end
+    for name in structs:
+        cls = getattr(_abi, name)
+        last, last_t = cls._fields_[-1]
+        assert getattr(cls, last).offset + ctypes.sizeof(last_t) + 8 > ctypes.sizeof(cls), name
