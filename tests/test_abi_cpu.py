@@ -178,3 +178,20 @@ def test_every_host_struct_of_the_binding_matches_the_header_field_by_field(tmp_
         cls = getattr(_abi, name)
         last, last_t = cls._fields_[-1]
         assert getattr(cls, last).offset + ctypes.sizeof(last_t) + 8 > ctypes.sizeof(cls), name
+
+
+def test_every_entry_point_of_the_header_cites_what_it_replaces():
+    """The boundary contract: each entry point of ``include/mmf.h`` stands in a section whose comment names the
+    reference interface it replaces -- a ``file.py:line`` under ``/root/reference`` or, for the recursion the reference
+    imports, ``torchfilter`` (un-vendored: SURVEY appendix A.2)."""
+    with open(os.path.join(ROOT, "include", "mmf.h")) as fh:
+        text = fh.read()
+    decls = list(re.finditer(r"^(?:int|size_t|const char\*|void)\s+(mmf_\w+)\s*\(", text, re.M))
+    assert len(decls) >= 46
+    for m in decls:
+        if m.group(1) == "mmf_version":
+            continue
+        start = text.rfind("/* ----", 0, m.start())
+        assert start >= 0, m.group(1)
+        section = text[start:m.start()]
+        assert re.search(r"[\w/]+\.py:\d+", section) or "torchfilter" in section, m.group(1)
