@@ -1003,3 +1003,36 @@ def test_native_training_recursion_on_side_streams_is_bit_identical(tname, cls, 
         assert set(g0) == set(g1) and len(g0) > 20
         for k in g0:
             assert torch.equal(g0[k], g1[k]), k
+
+
+def test_compact_training_arguments_are_validated_at_the_boundary():
+    """``mmf_pf_train_backward`` with ``compact = 1`` but no ``dz_scale`` buffer must refuse (MMF_EINVAL through
+    ``MmfError``) instead of writing through a null pointer; with ``compact = 0`` the same call needs none."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine
+
+    dev = torch.device("cuda:0")
+    task = om.TASKS["door"]
+    d, N, M, T = task.state_dim, 3, 64, 2
+    obs, ctrl, x0, target, g = _data(task, T, N, 71)
+    cov = (torch.eye(d) * 0.1)[None].expand(N, d, d)
+    torch.manual_seed(7)
+    f = mmf.door_models.DoorParticleFilter().to(dev).train()
+    f.num_particles = M
+    engine.set_training_backend("hip")
+    real = mmf._abi.pf_train_backward
+
+    def without_scale(a, *rest):
+        a.dz_scale = None
+        return real(a, *rest)
+
+    try:
+        mmf._abi.pf_train_backward = without_scale
+        f.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
+        pred = f.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
+        loss = torch.mean((pred - target.to(dev)) ** 2)
+        with pytest.raises(mmf._abi.MmfError):
+            loss.backward()
+    finally:
+        mmf._abi.pf_train_backward = real
+        engine.set_training_backend(None)
