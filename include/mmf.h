@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 36
+#define MMF_ABI_VERSION 37
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -42,6 +42,11 @@ extern "C" {
                            * product, f32 accumulate (BASELINE config 5's "bf16 measurement CNN on MFMA")   */
 #define MMF_PREC_F16X3 1  /* operands split x = hi + lo (2 x f16, exact to 2^-22), products
                              hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulate   */
+#define MMF_PREC_F16X3_DUAL 3 /* mmf_pack_particle_net only (ABI 37): the f16x3 halves of every 64x64 layer as ONE
+                             row-major, XOR-swizzled LDS image [out row][hi 64 | lo 64] that serves BOTH the forward
+                             product (row reads, ds_read_b128) and the transposed product of the backward
+                             (ds_read_b64_tr_b16): the fused training kernel keeps one copy of the weights in LDS.
+                             Same blob size and section offsets as the other precisions */
 
 int mmf_version(void);
 
@@ -460,6 +465,42 @@ int mmf_dynamics_forward_loop(const float* packed, int n_res, int precision, con
                               const float* traj_bias, float* out, int32_t* range_flag, int T, int N, int d,
                               void* stream);
 
+/* ---------------------------------------------------------------- K6, fused: one network call of the training backward
+ * Recompute (the forward pass's f16x3 arithmetic), backward data path and weight / bias gradients of ONE per-particle
+ * network over N * M rows in one kernel (the dynamics network: three launches -- encoder forward, trunk, encoder
+ * backward), replacing mmf_particle_net_train_forward + _backward + _weight_grads of the reference's training step
+ * (/root/reference/crossmodal/train_helpers.py:124-162 over door_models/dynamics.py:102-134, door_models/pf.py:63-107).
+ *  packed_dual  mmf_pack_particle_net(.., MMF_PREC_F16X3_DUAL)
+ *  kind         0 dynamics (n_res 3): g_next (N M, d) = dL / d x' in, d_raw (N M, d + 1) = dL / d (dir, gate) out,
+ *               act / g_act scratch (N M, 64) fp32;  1 measurement (n_res 2): d_out (N M) = dL / d log-likelihood
+ *  d_states     out (N M, d): the gradient THROUGH the network (the dynamics' direct path x' = x + .. is the caller's)
+ *  dz_first_h, sc_first, dz_join_h, sc_join, h_last_h: out, the compact (N M, 64) f16 rows + (N M) fp32 row scales the
+ *               narrow reductions read (first-layer / join pre-activation gradients, head input)
+ *  pw, pb       (NL, n_slots, 64, 64) / (NL, n_slots, 64) ACCUMULATED in place, slot = workgroup (grid =
+ *               min(n_slots, 256, ceil(N M / 128))): zero them before the first call, sum over slots after the last
+ */
+typedef struct MmfTrainFusedArgs {
+  const float* packed_dual;
+  int32_t n_res, kind, d, N, M, n_slots;
+  const float* states;
+  const float* traj_bias;
+  const float* d_out;
+  const float* g_next;
+  float* d_raw;
+  float* act;
+  float* g_act;
+  float* d_states;
+  void* dz_first_h;
+  float* sc_first;
+  void* dz_join_h;
+  float* sc_join;
+  void* h_last_h;
+  float* pw;
+  float* pb;
+} MmfTrainFusedArgs;
+
+int mmf_particle_net_train_fused(const MmfTrainFusedArgs* args /* host */, void* stream);
+
 /* ---------------------------------------------------------------- K6: the particle filter's training recursion
  * One C call for the forward recursion of a train-mode (no resampling) particle filter over T steps and
  * one for its backward -- the caller /root/reference/crossmodal/train_helpers.py:124-162
@@ -504,18 +545,12 @@ typedef struct MmfTrainNet {
   float* p_head;            /* (T, N n_slices, 4, 64)                               */
   float* p_dout;            /* (T, N n_slices, 4)                                   */
   float* p_traj;            /* (T, N n_slices, 64)                                  */
+  const float* packed_dual; /* ABI 37, fused = 1: MMF_PREC_F16X3_DUAL blob            */
 } MmfTrainNet;
 
 typedef struct MmfPfTrainArgs {
   int32_t T, N, M, d, n_meas, n_res_dyn, n_res_meas, logw_stride, precision;
   int32_t chunk_traj, n_splits, n_slices;
-  int32_t concurrent;        /* 1: small problems -- the measurement networks' backward chains and the dynamics recompute
-                                of a step run on private side streams (fork / join by events on `stream`), and the
-                                forward's measurement launches likewise; the scratch buffers stash / mask / dz / raw /
-                                d_tmp then hold n_meas + 1 consecutive sets (sized for max(NLd, NLm) layers and
-                                chunk_traj * M rows each) and d_raw (n_meas + 8) * chunk_traj * M floats.  Same kernels,
-                                same accumulation order: results are bit-identical to concurrent = 0.  Measured slower at
-                                32 x 30 x 16 (event fork / join costs more than 25 us kernels overlap): the host side leaves it off */
   MmfTrainNet dyn;
   MmfTrainNet meas[MMF_LOOP_MAX_MEAS];
   const float* dyn_bias;
@@ -550,7 +585,7 @@ typedef struct MmfPfTrainArgs {
                                 parameter gradients see the rounding (2^-11 relative per stored element, measured
                                 <= 1e-3 of the gradient norm -- tests/test_gpu_training.py).  0: fp32 buffers (bit-identical
                                 to ABI 34) */
-  float* dz_scale;           /* compact: scratch (max(NLd, NLm) + 1, chunk_traj M) [x (n_meas + 1) sets if concurrent]; else unused */
+  float* dz_scale;           /* compact: scratch (max(NLd, NLm) + 1, chunk_traj M); else unused */
   int32_t recompute_f16x3;   /* ABI 36.  backward, with compact = 1 and precision = MMF_PREC_F16X3: the recompute of a step's
                                 activations runs on `packed` (the forward pass's f16x3 blob) with the forward pass's own
                                 three-product arithmetic instead of exact fp32 products on `packed_f32`: the stash and the
@@ -560,6 +595,15 @@ typedef struct MmfPfTrainArgs {
                                 products per product; each ROW of a layer's input is scaled by the power of two that
                                 brings its largest magnitude to [2^7, 2^8) and its result scaled back (exact: the backward
                                 is linear in the gradients and rows do not mix).  0: exact fp32 products on an MMF_PREC_F32 blob */
+  int32_t fused;             /* ABI 37.  backward, with compact = recompute_f16x3 = backward_f16x3 = 1: every network's recompute,
+                                backward data path and weight gradients run as ONE kernel per network call
+                                (mmf_particle_net_train_fused: layer inputs and pre-activation gradients never reach HBM);
+                                each MmfTrainNet then carries `packed_dual`, and pw / pb are (NL, n_splits, 64, 64) /
+                                (NL, n_splits, 64) partials, ZEROED by the caller, one slot per workgroup (n_splits <= 256 =
+                                the largest grid).  stash / dz / dz_scale then only hold the three rows-by-64 slots the narrow
+                                reductions read (layer slots 2 and NL).  fused_act, fused_g_act: scratch (chunk_traj M, 64) fp32 */
+  float* fused_act;
+  float* fused_g_act;
 } MmfPfTrainArgs;
 
 int mmf_pf_train_forward(const MmfPfTrainArgs* args /* host */, void* stream);

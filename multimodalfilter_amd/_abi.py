@@ -17,9 +17,9 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 36
+ABI_VERSION = 37
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
-PREC_F32, PREC_F16X3, PREC_BF16 = 0, 1, 2
+PREC_F32, PREC_F16X3, PREC_BF16, PREC_F16X3_DUAL = 0, 1, 2, 3
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
 IMAGE_PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16": PREC_BF16}  # image encoder (K4)
 
@@ -73,20 +73,28 @@ class MmfPfLoopArgs(Structure):
 
 class MmfTrainNet(Structure):
     _fields_ = [("packed", _FP), ("packed_f32", _FP), ("packed_t", _FP), ("head_w", _FP), ("pw", _FP), ("pb", _FP),
-                ("p_first", _FP), ("p_head", _FP), ("p_dout", _FP), ("p_traj", _FP)]
+                ("p_first", _FP), ("p_head", _FP), ("p_dout", _FP), ("p_traj", _FP), ("packed_dual", _FP)]
 
 
 class MmfPfTrainArgs(Structure):
     _fields_ = [("T", c_int32), ("N", c_int32), ("M", c_int32), ("d", c_int32), ("n_meas", c_int32),
                 ("n_res_dyn", c_int32), ("n_res_meas", c_int32), ("logw_stride", c_int32), ("precision", c_int32),
-                ("chunk_traj", c_int32), ("n_splits", c_int32), ("n_slices", c_int32), ("concurrent", c_int32),
+                ("chunk_traj", c_int32), ("n_splits", c_int32), ("n_slices", c_int32),
                 ("dyn", MmfTrainNet), ("meas", MmfTrainNet * LOOP_MAX_MEAS),
                 ("dyn_bias", _FP), ("meas_bias", _FP * LOOP_MAX_MEAS), ("meas_logw", _FP * LOOP_MAX_MEAS),
                 ("noise", _FP), ("scale_tril", _FP), ("g_estimates", _FP),
                 ("states", _FP), ("logw", _FP), ("estimates", _FP), ("d_states0", _FP), ("d_logw0", _FP),
                 ("stash", _FP), ("mask", _FP), ("dz", _FP), ("raw", _FP), ("d_raw", _FP), ("loglik", _FP), ("ll_steps", _FP),
                 ("g_states_a", _FP), ("g_states_b", _FP), ("g_logw_a", _FP), ("g_logw_b", _FP), ("d_tmp", _FP),
-                ("range_flag", _FP), ("compact", c_int32), ("dz_scale", _FP), ("recompute_f16x3", c_int32), ("backward_f16x3", c_int32)]
+                ("range_flag", _FP), ("compact", c_int32), ("dz_scale", _FP), ("recompute_f16x3", c_int32), ("backward_f16x3", c_int32),
+                ("fused", c_int32), ("fused_act", _FP), ("fused_g_act", _FP)]
+
+
+class MmfTrainFusedArgs(Structure):
+    _fields_ = [("packed_dual", _FP), ("n_res", c_int32), ("kind", c_int32), ("d", c_int32), ("N", c_int32), ("M", c_int32),
+                ("n_slots", c_int32), ("states", _FP), ("traj_bias", _FP), ("d_out", _FP), ("g_next", _FP), ("d_raw", _FP),
+                ("act", _FP), ("g_act", _FP), ("d_states", _FP), ("dz_first_h", _FP), ("sc_first", _FP), ("dz_join_h", _FP),
+                ("sc_join", _FP), ("h_last_h", _FP), ("pw", _FP), ("pb", _FP)]
 
 
 class MmfEkfLoopArgs(Structure):
@@ -145,6 +153,7 @@ SIGNATURES = {
     "mmf_particle_net_weight_grads_acc": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_train_forward": (c_int, [POINTER(MmfPfTrainArgs), c_void_p]),
     "mmf_pf_train_backward": (c_int, [POINTER(MmfPfTrainArgs), c_void_p]),
+    "mmf_particle_net_train_fused": (c_int, [POINTER(MmfTrainFusedArgs), c_void_p]),
     "mmf_particle_net_train_backward": (c_int, [_FP, _FP, c_int, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_image_encoder_floats": (c_size_t, []),
     "mmf_image_encoder_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -436,6 +445,12 @@ def pf_train_forward(args: MmfPfTrainArgs, like: torch.Tensor):
 def pf_train_backward(args: MmfPfTrainArgs, like: torch.Tensor):
     with _on(like):
         _check(load().mmf_pf_train_backward(ctypes.byref(args), stream_of(like)), "mmf_pf_train_backward")
+
+
+def particle_net_train_fused(args: MmfTrainFusedArgs, like: torch.Tensor):
+    """One fused network call of the training backward (see include/mmf.h)."""
+    with _on(like):
+        _check(load().mmf_particle_net_train_fused(ctypes.byref(args), stream_of(like)), "mmf_particle_net_train_fused")
 
 
 def fuse_virtual_sensors(z, tril, w, z_out, tril_out, mode: int):

@@ -84,32 +84,6 @@ __global__ __launch_bounds__(kThreads) void dyn_epilogue_bwd_kernel(const float*
 
 inline int blocks(size_t n) { return static_cast<int>((n + kThreads - 1) / kThreads); }
 
-// Small problems (the reference trains 32 x 30 particles): a network's kernels are a handful of workgroups each,
-// so the independent chains of a step -- one per measurement network, and the dynamics recompute -- run on
-// private side streams, forked from and joined into the caller's stream by events.
-struct SideStreams {
-  hipStream_t s[MMF_LOOP_MAX_MEAS + 1] = {};
-  hipEvent_t fork = nullptr, done[MMF_LOOP_MAX_MEAS + 1] = {};
-  bool ready = false;
-  int init() {
-    if (ready) return 0;
-    for (auto& x : s)
-      if (hipStreamCreateWithFlags(&x, hipStreamNonBlocking) != hipSuccess) return MMF_EINVAL;
-    if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return MMF_EINVAL;
-    for (auto& e : done)
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return MMF_EINVAL;
-    ready = true;
-    return 0;
-  }
-};
-thread_local SideStreams g_side;
-
-#define MMF_HIP(call)                                      \
-  {                                                        \
-    hipError_t e_ = (call);                                \
-    if (e_ != hipSuccess) return static_cast<int>(e_);     \
-  }
-
 int check(const MmfPfTrainArgs* a) {
   if (!a) return MMF_EINVAL;
   if (a->T < 0 || a->N < 1 || a->M < 1 || a->n_meas < 1 || a->n_meas > MMF_LOOP_MAX_MEAS) return MMF_EINVAL;
@@ -130,27 +104,18 @@ extern "C" int mmf_pf_train_forward(const MmfPfTrainArgs* a, void* stream) {
   hipStream_t hs = static_cast<hipStream_t>(stream);
   const size_t row = static_cast<size_t>(a->N), R = row * a->M;
   const int K = a->n_meas;
-  const bool conc = a->concurrent && K > 1;
-  if (conc && (rc = g_side.init())) return rc;
   for (int t = 0; t < a->T; ++t) {
     const float* x = a->states + t * R * a->d;
     float* xn = a->states + (t + 1) * R * a->d;
     rc = mmf_pf_dynamics(a->dyn.packed, a->n_res_dyn, a->precision, x, a->dyn_bias + t * row * MMF_UNITS,
                          a->noise + t * R * a->d, a->scale_tril, xn, a->range_flag, a->N, a->M, a->d, stream);
     if (rc) return rc;
-    if (conc) MMF_HIP(hipEventRecord(g_side.fork, hs));
     float* ll = a->ll_steps + static_cast<size_t>(t) * K * R;  // (K, R): kept for the backward's softmax over modalities
     for (int k = 0; k < K; ++k) {
       const float* lw = a->meas_logw[k] ? a->meas_logw[k] + t * row * a->logw_stride : nullptr;
-      hipStream_t sk = (conc && k > 0) ? g_side.s[k] : hs;  // modality 0 stays on the caller's stream
-      if (sk != hs) MMF_HIP(hipStreamWaitEvent(sk, g_side.fork, 0));
       rc = mmf_pf_measure(a->meas[k].packed, a->n_res_meas, a->precision, xn, a->meas_bias[k] + t * row * MMF_UNITS, lw,
-                          a->logw_stride, ll + k * R, 0, a->range_flag, a->N, a->M, a->d, sk);
+                          a->logw_stride, ll + k * R, 0, a->range_flag, a->N, a->M, a->d, hs);
       if (rc) return rc;
-      if (sk != hs) {
-        MMF_HIP(hipEventRecord(g_side.done[k], sk));
-        MMF_HIP(hipStreamWaitEvent(hs, g_side.done[k], 0));
-      }
     }
     const float* loglik = ll;
     if (K > 1) {
@@ -168,7 +133,7 @@ extern "C" int mmf_pf_train_forward(const MmfPfTrainArgs* a, void* stream) {
 extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
   int rc = check(a);
   if (rc) return rc;
-  if (!a->g_estimates || !a->stash || !a->mask || !a->dz || !a->raw || !a->d_raw || !a->g_states_a || !a->g_states_b || !a->g_logw_a ||
+  if (!a->g_estimates || !a->stash || (!a->fused && (!a->mask || !a->raw)) || !a->dz || !a->d_raw || !a->g_states_a || !a->g_states_b || !a->g_logw_a ||
       !a->g_logw_b || !a->d_tmp || !a->d_states0 || !a->d_logw0 || a->chunk_traj < 1 || a->n_splits < 1 || a->n_slices < 1)
     return MMF_EINVAL;
   hipStream_t hs = static_cast<hipStream_t>(stream);
@@ -176,20 +141,22 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
   const size_t row = static_cast<size_t>(N), R = row * M;
   const int NLd = 3 + 2 * a->n_res_dyn, NLm = 3 + 2 * a->n_res_meas;
   const int NLmax = NLd > NLm ? NLd : NLm;
-  const bool conc = a->concurrent != 0;
-  if (conc && (rc = g_side.init())) return rc;
-  // scratch set s (concurrent: one per measurement network + one for the dynamics; else one for all)
+  // fused (ABI 37): recompute + backward + weight gradients of a network call as ONE kernel (particle_net_fused.hip);
+  // stash / dz / dz_scale then hold only the three (C, 64) row slots of the narrow reductions
+  const bool fused = a->fused != 0;
+  if (fused && (!a->compact || !a->recompute_f16x3 || !a->backward_f16x3 || a->precision != MMF_PREC_F16X3 || !a->fused_act ||
+                !a->fused_g_act || a->n_splits > 256))
+    return MMF_EINVAL;
   const size_t Cmax = static_cast<size_t>(a->chunk_traj < N ? a->chunk_traj : N) * M;
-  const size_t set_act = static_cast<size_t>(NLmax + 1) * Cmax * MMF_UNITS, set_mask = static_cast<size_t>(NLmax + 1) * Cmax * 2;
   // compact: stash / dz are f16 arrays of the same shapes (element offsets are the same, bytes half) + row scales of dz
   const bool cmp = a->compact != 0;
   if (cmp && !a->dz_scale) return MMF_EINVAL;
   const size_t esz = cmp ? 2 : 4;
   const bool f16r = cmp && a->recompute_f16x3 != 0 && a->precision == MMF_PREC_F16X3;
   const bool f16b = cmp && a->backward_f16x3 != 0;
-  auto stash_of = [&](int set) { return reinterpret_cast<char*>(a->stash) + (conc ? set * set_act : 0) * esz; };
-  auto dz_of = [&](int set) { return reinterpret_cast<char*>(a->dz) + (conc ? set * set_act : 0) * esz; };
-  auto scale_of = [&](int set) { return cmp ? a->dz_scale + (conc ? set * static_cast<size_t>(NLmax + 1) * Cmax : 0) : nullptr; };
+  auto stash_of = [&](int set) { return reinterpret_cast<char*>(a->stash) + 0 * esz; };
+  auto dz_of = [&](int set) { return reinterpret_cast<char*>(a->dz) + 0 * esz; };
+  auto scale_of = [&](int set) { return cmp ? a->dz_scale + 0 : nullptr; };
   auto net_fwd = [&](const MmfTrainNet& net, int n_res, int kind, const float* xs, const float* bias, char* stash, uint32_t* mask,
                      float* raw, int Nc, hipStream_t s) {
     // compact + recompute_f16x3: the recompute in the forward pass's own arithmetic, on the forward pass's blob
@@ -221,10 +188,30 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
                : mmf_particle_net_small_grads(reinterpret_cast<const float*>(dz + oL), reinterpret_cast<const float*>(dz + o2),
                                               reinterpret_cast<const float*>(stash + oL), xs, d_out, pf, ph, pd, pt, Nc, M, d, n_out, SL, s);
   };
-  auto mask_of = [&](int set) { return a->mask + (conc ? set * set_mask : 0); };
-  auto raw_of = [&](int set) { return a->raw + (conc ? set * Cmax * 8 : 0); };
-  auto tmp_of = [&](int set) { return a->d_tmp + (conc ? set * Cmax * d : 0); };
-  float* d_raw_dyn = a->d_raw + (conc ? static_cast<size_t>(K) * Cmax : 0);
+  // fused: one launch (dynamics: three) per network call, then the narrow reductions on the rows it left
+  auto net_fused = [&](const MmfTrainNet& net, int n_res, int kind, const float* xs, const float* bias, const float* d_out,
+                       const float* g_next, float* d_raw, float* d_states, int NL, size_t C, size_t slot0, int Nc, int n_out) {
+    if (!net.packed_dual) return static_cast<int>(MMF_EINVAL);
+    char *stash = stash_of(0), *dz = dz_of(0);
+    float* sc = scale_of(0);
+    MmfTrainFusedArgs f{};
+    f.packed_dual = net.packed_dual; f.n_res = n_res; f.kind = kind; f.d = d; f.N = Nc; f.M = M; f.n_slots = S;
+    f.states = xs; f.traj_bias = bias; f.d_out = d_out; f.g_next = g_next; f.d_raw = d_raw; f.act = a->fused_act;
+    f.g_act = a->fused_g_act; f.d_states = d_states;
+    f.dz_first_h = dz; f.sc_first = sc; f.dz_join_h = dz + C * MMF_UNITS * 2; f.sc_join = sc + C; f.h_last_h = stash;
+    f.pw = net.pw; f.pb = net.pb;
+    int r = mmf_particle_net_train_fused(&f, stream);
+    if (r) return r;
+    float *pf = net.p_first + slot0 * MMF_UNITS * 4, *ph = net.p_head + slot0 * 4 * MMF_UNITS, *pd = net.p_dout + slot0 * 4,
+          *pt = net.p_traj + slot0 * MMF_UNITS;
+    (void)NL;
+    return mmf_internal_small_grads_h(f.dz_first_h, f.sc_first, f.dz_join_h, f.sc_join, f.h_last_h, xs, kind == 1 ? d_out : d_raw, pf, ph,
+                                      pd, pt, Nc, M, d, n_out, SL, stream);
+  };
+  auto mask_of = [&](int set) { return a->mask + 0; };
+  auto raw_of = [&](int set) { return a->raw + 0; };
+  auto tmp_of = [&](int set) { return a->d_tmp + 0; };
+  float* d_raw_dyn = a->d_raw + 0;
   float* g_next = a->g_states_a;   // dL/d states[t+1] arriving from step t+1 (none at the last step)
   float* g_tot = a->g_states_b;
   float* g_lw = a->g_logw_a;       // dL/d logw[t+1] arriving from step t+1
@@ -256,12 +243,18 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
         combine_bwd_kernel<<<blocks(C), kThreads, 0, hs>>>(ll, d_a, a->d_raw, K, R, r0, C);
         MMF_CHECK_LAUNCH();
       }
-      if (conc) MMF_HIP(hipEventRecord(g_side.fork, hs));
       for (int k = 0; k < K; ++k) {
         const MmfTrainNet& net = a->meas[k];
         const float* d_out = K > 1 ? a->d_raw + k * C : d_a + r0;
-        hipStream_t sk = conc ? g_side.s[k] : hs;
-        if (conc) MMF_HIP(hipStreamWaitEvent(sk, g_side.fork, 0));
+        hipStream_t sk = hs;
+        if (fused) {
+          rc = net_fused(net, a->n_res_meas, 1, xn + r0 * d, a->meas_bias[k] + (t * row + n0) * MMF_UNITS, d_out, nullptr, nullptr,
+                         tmp_of(k), NLm, C, slot0, Nc, 1);
+          if (rc) return rc;
+          add_kernel<<<blocks(C * d), kThreads, 0, hs>>>(g_tot + r0 * d, tmp_of(k), C * d);
+          MMF_CHECK_LAUNCH();
+          continue;
+        }
         char *stash = stash_of(k), *dz = dz_of(k);
         float* sc = scale_of(k);
         rc = net_fwd(net, a->n_res_meas, 1, xn + r0 * d, a->meas_bias[k] + (t * row + n0) * MMF_UNITS, stash, mask_of(k), raw_of(k), Nc, sk);
@@ -273,30 +266,24 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
         first_wgrad_meas[k] = false;
         rc = net_sgrads(net, dz, sc, stash, NLm, C, xn + r0 * d, d_out, slot0, Nc, 1, sk);
         if (rc) return rc;
-        if (conc) {
-          MMF_HIP(hipEventRecord(g_side.done[k], sk));
-        } else {
-          add_kernel<<<blocks(C * d), kThreads, 0, hs>>>(g_tot + r0 * d, tmp_of(k), C * d);
-          MMF_CHECK_LAUNCH();
-        }
+        add_kernel<<<blocks(C * d), kThreads, 0, hs>>>(g_tot + r0 * d, tmp_of(k), C * d);
+        MMF_CHECK_LAUNCH();
       }
       // ---- dynamics network: x' = x + dir sigmoid(gate) + L eps
-      {
+      if (fused) {
+        // the sigmoid-gate epilogue's backward runs inside the trunk kernel (d_raw_dyn is its output)
+        rc = net_fused(a->dyn, a->n_res_dyn, 0, x + r0 * d, a->dyn_bias + (t * row + n0) * MMF_UNITS, nullptr, g_tot + r0 * d, d_raw_dyn,
+                       tmp_of(K), NLd, C, slot0, Nc, d + 1);
+        if (rc) return rc;
+        sum2_kernel<<<blocks(C * d), kThreads, 0, hs>>>(g_tot + r0 * d, tmp_of(K), g_next + r0 * d, C * d);
+        MMF_CHECK_LAUNCH();
+      } else {
         const MmfTrainNet& net = a->dyn;
-        hipStream_t sd = conc ? g_side.s[K] : hs;  // the recompute needs nothing of this step's gradients
-        if (conc) MMF_HIP(hipStreamWaitEvent(sd, g_side.fork, 0));
+        hipStream_t sd = hs;
         char *stash = stash_of(K), *dz = dz_of(K);
         float* sc = scale_of(K);
         rc = net_fwd(net, a->n_res_dyn, 0, x + r0 * d, a->dyn_bias + (t * row + n0) * MMF_UNITS, stash, mask_of(K), raw_of(K), Nc, sd);
         if (rc) return rc;
-        if (conc) {
-          MMF_HIP(hipEventRecord(g_side.done[K], sd));
-          for (int k = 0; k <= K; ++k) MMF_HIP(hipStreamWaitEvent(hs, g_side.done[k], 0));
-          for (int k = 0; k < K; ++k) {  // the same adds in the same order as the sequential path
-            add_kernel<<<blocks(C * d), kThreads, 0, hs>>>(g_tot + r0 * d, tmp_of(k), C * d);
-            MMF_CHECK_LAUNCH();
-          }
-        }
         if (d == 2) dyn_epilogue_bwd_kernel<2><<<blocks(C), kThreads, 0, hs>>>(raw_of(K), g_tot + r0 * d, d_raw_dyn, C);
         else dyn_epilogue_bwd_kernel<3><<<blocks(C), kThreads, 0, hs>>>(raw_of(K), g_tot + r0 * d, d_raw_dyn, C);
         MMF_CHECK_LAUNCH();

@@ -505,12 +505,6 @@ def _assemble_param_grads(net: PackedParticleNet, params, dW, db, g_first, g_hea
 # buffers inside the 256 MiB Infinity Cache) 65.7, 65,536 56.1, 262,144 45.0 -- on-die hand-offs do not pay
 # for the small launches (150 KB of weights staged per workgroup for 4 tiles, half-empty grids)
 TRAIN_CHUNK_ROWS = int(os.environ.get("MMF_TRAIN_CHUNK_ROWS", "262144"))
-# MmfPfTrainArgs.concurrent: below this many rows (N * M) the independent chains of a training step (one per
-# measurement network + the dynamics recompute) run on side streams, forked / joined by events; results are
-# bit-identical (tests/test_gpu_training.py).  OFF by default -- measured at the reference's 32 x 30 x 16: 10.75 ms
-# per optimiser step against 10.22 on one stream: the ~10 event records / waits per time step cost more than
-# the overlap of kernels that are 25 us long buys.
-TRAIN_CONCURRENT_ROWS = int(os.environ.get("MMF_TRAIN_CONCURRENT_ROWS", "0"))
 # MmfPfTrainArgs.compact: the recompute buffers of the backward in half the bytes (activations as f16, pre-activation
 # gradients as f16 relative to the largest magnitude of their 32-row tile + one fp32 scale per row and layer).  They are the
 # recursion's HBM traffic (written once, read once by the weight-gradient pass).  Only the PARAMETER gradients see the
@@ -526,6 +520,12 @@ TRAIN_RECOMPUTE_F16X3 = os.environ.get("MMF_TRAIN_RECOMPUTE_F16X3", "1") != "0"
 # three-product f16 arithmetic too, every layer's input tile scaled by an exact power of two into the f16 range and
 # the result scaled back (the backward is linear in the gradients).  MMF_TRAIN_BACKWARD_F16X3=0: exact fp32 products.
 TRAIN_BACKWARD_F16X3 = os.environ.get("MMF_TRAIN_BACKWARD_F16X3", "1") != "0"
+# MmfPfTrainArgs.fused (round 5, with the three above): recompute + backward data path + weight gradients of a network call
+# as ONE kernel (csrc/particle_net_fused.hip) -- layer inputs and pre-activation gradients never reach HBM; the weight
+# gradients accumulate in registers across the launch (one partial per workgroup).  MMF_TRAIN_FUSED=0: the three passes
+# over the compact buffers (round 4), kept as the cross-check of tests/test_gpu_training.py.
+TRAIN_FUSED = os.environ.get("MMF_TRAIN_FUSED", "1") != "0"
+TRAIN_FUSED_SLOTS = 256  # weight-gradient partials per layer = the largest grid of the fused kernel
 
 
 class PfTrainLoopFunction(torch.autograd.Function):
@@ -565,7 +565,6 @@ class PfTrainLoopFunction(torch.autograd.Function):
         # forward pass in the engine's arithmetic mode (f16x3 by default: the inference kernels); the backward
         # recomputes the SAME particle sets' activations with exact fp32 products
         a.precision = dyn_net.precision_code()
-        a.concurrent = int(R <= TRAIN_CONCURRENT_ROWS)
         blobs = [dyn_net.blob(_abi.PREC_F32)] + [m.blob(_abi.PREC_F32) for m, _ in meas]
         fwd_blobs = [dyn_net.blob()] + [m.blob() for m, _ in meas]
         a.dyn.packed, a.dyn.packed_f32 = P(fwd_blobs[0]), P(blobs[0])
@@ -613,8 +612,12 @@ class PfTrainLoopFunction(torch.autograd.Function):
         f16b = bool(f16r and TRAIN_BACKWARD_F16X3)
         a.backward_f16x3 = int(f16b)
         a.chunk_traj, a.n_splits, a.n_slices = chunk_traj, S, SL
-        a.concurrent = int(N * M <= TRAIN_CONCURRENT_ROWS)
-        sets = K + 1 if a.concurrent else 1  # private scratch per concurrently running network
+        fused = bool(f16b and TRAIN_FUSED and all(n.n_res == (3 if i == 0 else 2) for i, n in enumerate(nets)))
+        a.fused = int(fused)
+        if fused:
+            S = min(TRAIN_FUSED_SLOTS, max(1, -(-C // 128)))  # one partial per workgroup (4 tiles of 32 rows per pass)
+            a.n_splits = S
+        sets = 1
         bufs = []
         head_ws, tblobs = [], []
         n_par = [len(n._sources()) for n in nets]
@@ -624,11 +627,14 @@ class PfTrainLoopFunction(torch.autograd.Function):
         for i, net in enumerate(nets):
             NL = 3 + 2 * net.n_res
             tn = a.dyn if i == 0 else a.meas[i - 1]
-            b = dict(pw=E(NL + 1, S, U, U), pb=E(NL + 1, S, U), p_first=E(T, N * SL, U, 4), p_head=E(T, N * SL, 4, U),
+            Z = (lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)) if fused else E  # fused: accumulated in place
+            b = dict(pw=Z(NL + 1, S, U, U), pb=Z(NL + 1, S, U), p_first=E(T, N * SL, U, 4), p_head=E(T, N * SL, 4, U),
                      p_dout=E(T, N * SL, 4), p_traj=E(T, N * SL, U))
             bufs.append(b)
             head_ws.append(params[offs[i + 1] - 2].to(torch.float32).contiguous())
-            tblobs.append(_transposed_blob(net, _abi.PREC_F16X3 if f16b else _abi.PREC_F32))
+            tblobs.append(None if fused else _transposed_blob(net, _abi.PREC_F16X3 if f16b else _abi.PREC_F32))
+            if fused:
+                tn.packed_dual = P(net.blob(_abi.PREC_F16X3_DUAL))
             tn.packed_f32 = P(ctx.blobs[i])
             tn.packed = P(ctx.fwd_blobs[i]) if f16r else tn.packed_f32
             tn.packed_t, tn.head_w = P(tblobs[i]), P(head_ws[i])
@@ -641,9 +647,14 @@ class PfTrainLoopFunction(torch.autograd.Function):
         g_est = g_est.to(torch.float32).contiguous()
         a.compact = int(TRAIN_COMPACT_STASH)
         A = (lambda *shape: torch.empty(shape, dtype=torch.float16, device=dev)) if a.compact else E
-        scratch = dict(stash=A(sets, NLmax + 1, C, U), mask=torch.empty((sets, NLmax + 1, C, 2), dtype=torch.int32, device=dev),
-                       dz=A(sets, NLmax + 1, C, U), dz_scale=E(sets, NLmax + 1, C) if a.compact else None, raw=E(sets, C, 8), d_raw=E(K + 8, C), ga=E(N, M, d), gb=E(N, M, d),
-                       la=E(N, M), lb=E(N, M), d_tmp=E(sets, C, d), d_states0=E(N, M, d), d_logw0=E(N, M))
+        if fused:  # only the three (C, 64) row slots of the narrow reductions + the dynamics' encoder hand-offs
+            scratch = dict(stash=A(1, C, U), mask=None, dz=A(2, C, U), dz_scale=E(2, C), raw=None, d_raw=E(K + 8, C), ga=E(N, M, d), gb=E(N, M, d),
+                           la=E(N, M), lb=E(N, M), d_tmp=E(1, C, d), d_states0=E(N, M, d), d_logw0=E(N, M), act=E(C, U), g_act=E(C, U))
+            a.fused_act, a.fused_g_act = P(scratch["act"]), P(scratch["g_act"])
+        else:
+            scratch = dict(stash=A(sets, NLmax + 1, C, U), mask=torch.empty((sets, NLmax + 1, C, 2), dtype=torch.int32, device=dev),
+                           dz=A(sets, NLmax + 1, C, U), dz_scale=E(sets, NLmax + 1, C) if a.compact else None, raw=E(sets, C, 8), d_raw=E(K + 8, C), ga=E(N, M, d), gb=E(N, M, d),
+                           la=E(N, M), lb=E(N, M), d_tmp=E(sets, C, d), d_states0=E(N, M, d), d_logw0=E(N, M))
         a.dyn_bias, a.noise, a.scale_tril, a.g_estimates = P(keep["dyn_bias"]), P(keep["eps"]), P(keep["tril"]), P(g_est)
         a.states, a.logw, a.estimates = P(keep["states"]), P(keep["logw"]), P(keep["est"])
         a.loglik, a.ll_steps = P(keep["loglik"]), P(keep["ll_steps"])
@@ -660,7 +671,11 @@ class PfTrainLoopFunction(torch.autograd.Function):
             b = bufs[i]
             dW, db = b["pw"].sum(1), b["pb"].sum(1)
             n_out = net.n_out
-            g_first = b["p_first"].sum((0, 1))[:, :d]
+            g_first_all = b["p_first"].sum((0, 1))
+            g_first = g_first_all[:, :d]
+            if fused:  # the fused kernel leaves no dz rows of the first layer to sum: column d of the narrow reduction is its bias gradient
+                db = db.clone()
+                db[3 + 2 * net.n_res] = g_first_all[:, d]
             g_head = b["p_head"].sum((0, 1))[:n_out]
             per_traj_dout = b["p_dout"].view(T * N, SL, 4).sum(1)
             g_head_b = per_traj_dout.sum(0)[:n_out]

@@ -951,15 +951,20 @@ def test_recompute_in_the_forward_arithmetic_tracks_the_exact_fp32_recompute(tna
 
 
 @pytest.mark.parametrize("tname,cls,N,M,T,chunk_rows", [
-    ("door", "DoorCrossmodalParticleFilter", 32, 30, 6, 262144),  # the reference's training shape, one chunk
-    ("door", "DoorCrossmodalParticleFilter", 5, 300, 3, 600),     # ragged chunks: the scratch sets are sized for the largest
-    ("door", "DoorParticleFilter", 3, 100, 3, 100),               # one measurement network: only the dynamics recompute forks
+    ("door", "DoorCrossmodalParticleFilter", 32, 30, 6, 262144),  # the reference's training shape, one chunk, tiles straddle trajectories
+    ("door", "DoorCrossmodalParticleFilter", 5, 300, 3, 600),     # ragged chunks: partial tiles, fewer workgroups than slots
+    ("door", "DoorParticleFilter", 3, 100, 3, 100),               # one measurement network
+    ("push", "PushUnimodalParticleFilter", 4, 2048, 3, 262144),   # config 5's filter: whole tiles, 64 workgroups
 ])
-def test_native_training_recursion_on_side_streams_is_bit_identical(tname, cls, N, M, T, chunk_rows):
-    """``MmfPfTrainArgs.concurrent`` (small problems: the measurement networks' backward chains and the dynamics
-    recompute of a step on private side streams, the forward's second measurement launch likewise): the same
-    kernels, the same accumulation order -- loss, estimates and EVERY parameter gradient equal the single-stream
-    run's bit for bit, twice in a row (a missing event wait shows as a race)."""
+def test_fused_network_calls_track_the_three_pass_backward(tname, cls, N, M, T, chunk_rows):
+    """``MmfPfTrainArgs.fused`` (round 5): recompute + backward data path + weight gradients of every network call in
+    ONE kernel (``mmf_particle_net_train_fused``) against the three passes over the compact f16 buffers (round 4).
+    Both differentiate the forward pass's own f16x3 activations with the same three-product backward, so the recursion's
+    gradients (``d states``, through them every per-trajectory network's parameters) agree to the accumulation order;
+    the per-particle networks' weight gradients multiply the same f16-rounded operands but scale ``dz`` differently
+    (running exponent per layer instead of a scale per 32-row tile) -- both within 2^-11 relative per element.  Loss
+    and estimates are bit-identical (the forward is untouched); every gradient within 2e-3 of its scale, twice in a
+    row with identical bits (the fused kernel's summation order is fixed: no atomics)."""
     import multimodalfilter_amd as mmf
     from multimodalfilter_amd import engine
 
@@ -974,15 +979,16 @@ def test_native_training_recursion_on_side_streams_is_bit_identical(tname, cls, 
     f = mmf.model_types(tname)[cls]().to(dev).train()
     f.num_particles = M
     engine.set_training_backend("hip")
-    old_chunk, old_conc = engine.TRAIN_CHUNK_ROWS, engine.TRAIN_CONCURRENT_ROWS
+    old_chunk, old_fused, old_prec = engine.TRAIN_CHUNK_ROWS, engine.TRAIN_FUSED, engine.DEFAULT_PRECISION
     engine.TRAIN_CHUNK_ROWS = chunk_rows
+    engine.set_default_precision("f16x3")
     seen = []
     real = mmf._abi.pf_train_backward
-    mmf._abi.pf_train_backward = lambda a, *rest: (seen.append(int(a.concurrent)), real(a, *rest))[1]
+    mmf._abi.pf_train_backward = lambda a, *rest: (seen.append(int(a.fused)), real(a, *rest))[1]
     results = []
     try:
-        for conc_rows in (0, 1 << 20, 1 << 20):
-            engine.TRAIN_CONCURRENT_ROWS = conc_rows
+        for fused in (False, True, True):
+            engine.TRAIN_FUSED = fused
             f.zero_grad(set_to_none=True)
             f.noise = mmf.ReplayNoise([eps0] + eps, [])
             f.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
@@ -995,14 +1001,36 @@ def test_native_training_recursion_on_side_streams_is_bit_identical(tname, cls, 
     finally:
         mmf._abi.pf_train_backward = real
         engine.set_training_backend(None)
-        engine.TRAIN_CHUNK_ROWS, engine.TRAIN_CONCURRENT_ROWS = old_chunk, old_conc
+        engine.TRAIN_CHUNK_ROWS, engine.TRAIN_FUSED = old_chunk, old_fused
+        engine.set_default_precision(old_prec)
     assert seen == [0, 1, 1]
-    (l0, p0, g0) = results[0]
-    for l1, p1, g1 in results[1:]:
-        assert torch.equal(l0, l1) and torch.equal(p0, p1)
-        assert set(g0) == set(g1) and len(g0) > 20
-        for k in g0:
-            assert torch.equal(g0[k], g1[k]), k
+    (l0, p0, g0), (l1, p1, g1), (l2, p2, g2) = results
+    assert torch.equal(l0, l1) and torch.equal(p0, p1) and torch.equal(l1, l2)
+    assert set(g0) == set(g1) and len(g0) > 20
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k  # run to run: the same bits
+    top = max(float(v.abs().max()) for v in g0.values())
+    worst = max((float((g0[k] - g1[k]).abs().max()) / max(1e-3 * top, float(g0[k].abs().max())), k) for k in g0)
+    print("fused vs three-pass backward, largest relative gradient difference:", worst)
+    assert worst[0] < 2e-3, worst
+    assert all(bool(torch.isfinite(v).all()) for v in g1.values())
+
+
+@pytest.mark.parametrize("task,kind", [("door", "dynamics"), ("door", "measure"), ("push", "dynamics"), ("push", "measure")])
+@pytest.mark.parametrize("N,M", [(3, 40), (2, 64), (5, 7), (32, 30), (7, 300)])
+def test_k6_fused_network_call_matches_the_exact_fp32_step_kernels(task, kind, N, M):
+    """``mmf_particle_net_train_fused`` through the C ABI against ``engine.ParticleNetFunction`` (the exact-fp32 K6 step
+    kernels, themselves held to fp64 autograd above): ``d states`` per ROW to 1e-4 (the data path: f16x3 products with a
+    power-of-two scale per row, also for trajectories whose gradients are 10^4 below their neighbours'), the
+    per-trajectory bias gradient, and every weight / bias gradient rebuilt from the kernel's outputs (``pw`` / ``pb``
+    partials, the compact rows of the narrow reductions) to 1e-2 of the tensor's largest entry (f16-rounded operands:
+    2^-11 relative per element, sums of a few hundred mixed-sign products)."""
+    from _fused_case import run_case
+
+    worst, row_err = run_case(task, kind, N, M, verbose=False, return_rows=True)
+    print("fused network call vs exact-fp32 step kernels:", worst, row_err)
+    assert row_err < 1e-4, row_err
+    assert worst < 1e-2, worst
 
 
 def test_compact_training_arguments_are_validated_at_the_boundary():
