@@ -17,7 +17,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # particle_net.hip: with the SLP vectoriser on, the f16x3 operand split (x - float(hi) -> f16)
 # becomes cvt + cvt + v_pk_add_f32 + cvt; without it the same source selects
 # v_fma_mixlo_f16 / v_fma_mixhi_f16 (2 instructions per pair fewer; K2 is VALU-issue bound)
-EXTRA_FLAGS = {"particle_net.hip": ["-fno-slp-vectorize"], "particle_net_fused.hip": ["-fno-slp-vectorize"], "image_encoder.hip": ["-fno-slp-vectorize"]}
+# particle_net_fused.hip: its kernels run one wave per SIMD with > 256 registers; by default hipcc then puts every MFMA
+# result in AGPRs and copies it to VGPRs for the VALU work between layers (~170 v_accvgpr_* per layer and tile);
+# with VGPR-form MFMAs the chain stays in VGPRs and only the parked state (weight-gradient accumulators, f16 copies of
+# the layer inputs) moves through AGPRs
+EXTRA_FLAGS = {"particle_net.hip": ["-fno-slp-vectorize"], "particle_net_fused.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"], "image_encoder.hip": ["-fno-slp-vectorize"]}
 OBJ = os.path.join(CSRC, "_obj")
 
 

@@ -29,6 +29,13 @@
 //    c_p that brings it to [2^7, 2^8) before its own operand split, so the exchanged value is that split's hi half
 //    times 2^(7 - (E - e_row)) -- one v_pk_mul_f16 per pair -- and the MFMAs accumulate straight into the resident
 //    accumulators (no per-tile partial product, no fp32 fix-up); the stored partial is accW 2^(E - 141).
+//  * ONE wave per SIMD (the kernel needs ~450 registers per lane) has nothing to hide a round trip behind, so the
+//    instruction stream itself is pipelined: weight fragments are requested one group of three MFMAs ahead of their
+//    use, across layer and tile boundaries; the exchange slots' operands one product ahead; the transposed product is
+//    issued BEFORE the exchange's barrier, so the hand-off runs under the matrix pipe.  Only 256 of the registers can be
+//    VGPRs: the two groups that never need one between their definition and their use -- weight-gradient accumulators
+//    and the f16 layer inputs -- are parked in AGPRs BY HAND (v_accvgpr_write / _read); left to the register allocator
+//    the split costs scratch reloads in the middle of every layer, each an exposed L2 round trip.
 //
 // The dynamics network (9 layers = 144 KB) does not leave room for the exchange slots: it runs as three launches --
 // encoder forward (first layer + block 0: writes its 64 outputs per particle, fp32), trunk (join + 3 blocks + head +
@@ -39,6 +46,21 @@
 // head's input (3 x 128 B per particle), for the narrow reductions of small_grads_h_kernel.
 
 #include "particle_net_train_common.h"
+
+// Phase clocks for scripts/ubench/fused_phases.hip (compiled out of the library): wave 0 of workgroup 0 accumulates
+// s_memtime differences per phase of a tile.  The stamps serialise what they measure: read shares.
+#ifdef MMF_FUSED_PHASE_CLOCKS
+__device__ unsigned long long g_fused_phases[16];
+#define FUSED_STAMP(i)                                                                \
+  do {                                                                                \
+    unsigned long long t_;                                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+    phase_acc[i] += t_ - phase_prev;                                                  \
+    phase_prev = t_;                                                                  \
+  } while (0)
+#else
+#define FUSED_STAMP(i)
+#endif
 
 namespace {
 
@@ -66,9 +88,9 @@ struct FusedLayout {
   static constexpr int L1 = (PART == kEnc || PART == kEncFwd) ? 2 : NL;
   static constexpr int NLAY = L1 - L0;
   static constexpr int kImgBytes = NLAY * kLayerFloats * 4;
-  // small section: W0 (64 x 8) | biases (NL x 64) | head weights (4 x 64) | head bias (8)
+  // small section: W0 (64 x 8) | biases (NL x 64) | head weights (4 x 64) | head bias (8) | W0 transposed (4 x 64)
   static constexpr int kTailFloats = blob_floats(NRES) - off_bias(NRES);
-  static constexpr int kSmallFloats = off_layers() + kTailFloats;
+  static constexpr int kSmallFloats = off_layers() + kTailFloats + 4 * kUnits;
   static constexpr int kSmallOff = kImgBytes;
   static constexpr int kXchgOff = kSmallOff + ((kSmallFloats * 4 + 255) / 256) * 256;
   static constexpr int kSlotBytes = 8192;  // dz image (4 KB) | a image (4 KB)
@@ -127,14 +149,21 @@ __device__ __forceinline__ void split_act_nr(const Act<1>& x, SplitAct<1>& o, fl
 }
 
 // g *= [a > 0] with a given as the f16 hi halves of the operand split that consumed it (element (t, r) <-> half
-// (r & 7) of fragment 2 t + (r >> 3)); an activation below 2^-25 counts as 0
+// (r & 7) of fragment 2 t + (r >> 3)); an activation below 2^-25 counts as 0.  The mask is arithmetic: clamp(a 2^24)
+// is exactly 0 or 1 for a non-negative f16 (v_fma_mix_f32 reads the half in place, the clamp is its output modifier),
+// so a masked element costs two VALU instructions and no VCC round trip (compare + select: three and a wait state).
 __device__ __forceinline__ void mask_by_halves(const half8 (&s)[4], Act<1>& g) {
+  const float big = 16777216.f;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const unsigned short bits = __builtin_bit_cast(v8i16, s[2 * t + (r >> 3)])[r & 7];
-      g.v[t][0][r] = (bits & 0x7fffu) ? g.v[t][0][r] : 0.f;
+    for (int r = 0; r < 16; r += 2) {
+      const unsigned w = __builtin_bit_cast(u32x4, s[2 * t + (r >> 3)])[(r & 7) >> 1];
+      float m0, m1;
+      asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0] clamp" : "=v"(m0) : "v"(w), "v"(big));
+      asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(m1) : "v"(w), "v"(big));
+      g.v[t][0][r] *= m0;
+      g.v[t][0][r + 1] *= m1;
     }
 }
 __device__ __forceinline__ void mask_by_act(const Act<1>& a, Act<1>& g) {
@@ -142,6 +171,49 @@ __device__ __forceinline__ void mask_by_act(const Act<1>& a, Act<1>& g) {
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) g.v[t][0][r] = a.v[t][0][r] > 0.f ? g.v[t][0][r] : 0.f;
+}
+
+// lanes j and j + 32 hold the two halves of particle j's features: combine them with ONE v_permlane32_swap (a VALU
+// operation) instead of a __shfl_xor (ds_bpermute: an LDS-pipe round trip a lone wave per SIMD cannot hide)
+__device__ __forceinline__ float halves_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float halves_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float row_absmax_swap(const Act<1>& a) {
+  float m = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(a.v[t][0][r]));
+  return halves_max(m);
+}
+
+// ---- registers parked in AGPRs by hand (see the header).  The compiler cannot look into the asm, so the wait states
+// it would insert around MFMA results are spelled out where they can matter: `agpr_park_after_mfma` for a value an MFMA
+// has just written, `agpr_fetch_for_mfma` for one an MFMA is about to read as its C operand.
+__device__ __forceinline__ unsigned agpr_park(unsigned v) {
+  unsigned a;
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
+  return a;
+}
+__device__ __forceinline__ unsigned agpr_fetch(unsigned a) {
+  unsigned v;
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+  return v;
+}
+__device__ __forceinline__ unsigned agpr_park_after_mfma(unsigned v) {
+  unsigned a;
+  asm volatile("s_nop 15\n\ts_nop 3\n\tv_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
+  return a;
+}
+__device__ __forceinline__ unsigned agpr_fetch_for_mfma(unsigned a) {
+  unsigned v;
+  asm volatile("v_accvgpr_read_b32 %0, %1\n\ts_nop 3" : "=v"(v) : "a"(a));
+  return v;
 }
 
 __device__ __forceinline__ void load_rows_f32(const float* __restrict__ base, Act<1>& a, int row, int h, float scale) {
@@ -170,12 +242,14 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
   const float* sBias = small + off_layers();
   const float* sWhead = sBias + NL * kUnits;
   const float* sBhead = sWhead + kHeadRows * kUnits;
-  float* tmax = lds + LY::kScaleOff / 4;  // the four waves' tile maxima of the layer being exchanged
+  float* sW0T = small + off_layers() + LY::kTailFloats;  // [i][f] = W_in[f][i]: d states reads 4 features per ds_read_b128
+  float* tmax = lds + LY::kScaleOff / 4;                 // the four waves' tile maxima of the layer being exchanged
   {
     const float4* src = reinterpret_cast<const float4*>(a.blob + off_layers() + L0 * kLayerFloats);
     mmf::stage_to_lds<NLAY * kLayerFloats / 4, 256, 4>(src, reinterpret_cast<float4*>(lds), threadIdx.x);
     for (int i = threadIdx.x; i < off_layers(); i += 256) small[i] = a.blob[i];
     for (int i = threadIdx.x; i < LY::kTailFloats; i += 256) small[off_layers() + i] = a.blob[off_bias(NRES) + i];
+    sW0T[threadIdx.x] = a.blob[(threadIdx.x & 63) * kW0Cols + (threadIdx.x >> 6)];
   }
   __syncthreads();
 
@@ -192,53 +266,94 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
   float neg_one = -1.0f;  // in an SGPR, opaque to the optimiser (split_pair)
   asm volatile("" : "+s"(neg_one));
 
-  // acc += W_l in  (rows of the image: the forward product)
-  auto layer_fwd = [&](int li, const SplitAct<1>& sp, Act<1>& acc) {
-    asm volatile("" ::: "memory");  // see mfma_layer: keep LICM from hoisting the fragment reads
-    const unsigned char* img = ldsb + li * (kLayerFloats * 4);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const half8 ahi = *reinterpret_cast<const half8*>(img + ((base_r ^ (32 * s)) + 8192 * t));
-        const half8 alo = *reinterpret_cast<const half8*>(img + ((base_r ^ (128 + 32 * s)) + 8192 * t));
-        acc.v[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, sp.hi[s][0], acc.v[t][0], 0, 0, 0);
-        acc.v[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, sp.lo[s][0], acc.v[t][0], 0, 0, 0);
-        acc.v[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, sp.hi[s][0], acc.v[t][0], 0, 0, 0);
-      }
+  // ---- weight fragments, one group (3 MFMAs) ahead of their use, across layer and tile boundaries.
+  // Group g = 4 t + s: output row tile t, k-step s.
+  struct Frag {
+    half8 hi, lo;
   };
-  // acc += W_l^T in  (columns of the same image through the transposing read: the backward product)
-  auto layer_bwd = [&](int li, const SplitAct<1>& sp, Act<1>& acc) {
-    asm volatile("" ::: "memory");
+  auto frag_rows = [&](int li, int g) -> Frag {  // rows of the image: the forward product's A operand
     const unsigned char* img = ldsb + li * (kLayerFloats * 4);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const half8 ahi = lds_tr_pair(img + ((base_t ^ (64 * t)) + 4096 * s), img + ((base_t ^ (64 * t + 32)) + 2048 + 4096 * s));
-        const half8 alo = lds_tr_pair(img + ((base_t ^ (128 + 64 * t)) + 4096 * s), img + ((base_t ^ (128 + 64 * t + 32)) + 2048 + 4096 * s));
-        acc.v[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, sp.hi[s][0], acc.v[t][0], 0, 0, 0);
-        acc.v[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, sp.lo[s][0], acc.v[t][0], 0, 0, 0);
-        acc.v[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, sp.hi[s][0], acc.v[t][0], 0, 0, 0);
-      }
+    const int t = g >> 2, s = g & 3;
+    Frag f;
+    f.hi = *reinterpret_cast<const half8*>(img + ((base_r ^ (32 * s)) + 8192 * t));
+    f.lo = *reinterpret_cast<const half8*>(img + ((base_r ^ (128 + 32 * s)) + 8192 * t));
+    return f;
   };
+  auto frag_cols = [&](int li, int g) -> Frag {  // columns of the same image through the transposing read: W_l^T
+    const unsigned char* img = ldsb + li * (kLayerFloats * 4);
+    const int t = g >> 2, s = g & 3;
+    Frag f;
+    f.hi = lds_tr_pair(img + ((base_t ^ (64 * t)) + 4096 * s), img + ((base_t ^ (64 * t + 32)) + 2048 + 4096 * s));
+    f.lo = lds_tr_pair(img + ((base_t ^ (128 + 64 * t)) + 4096 * s), img + ((base_t ^ (128 + 64 * t + 32)) + 2048 + 4096 * s));
+    return f;
+  };
+  Frag cur = frag_rows(0, 0);  // the first product of every tile is the forward product of local layer 0
+  // acc += W_li in (TR: W_li^T in); the last group requests group 0 of the NEXT product (layer `ln`, NTR: transposed)
+  auto product = [&](auto trc, auto ntrc, int li, int ln, const SplitAct<1>& sp, Act<1>& acc) {
+    constexpr bool TR = decltype(trc)::value, NTR = decltype(ntrc)::value;
+    asm volatile("" ::: "memory");  // see mfma_layer: keep LICM from hoisting the fragment reads out of the tile loop
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      Frag nxt;
+      if (g < 7) nxt = TR ? frag_cols(li, g + 1) : frag_rows(li, g + 1);
+      else nxt = NTR ? frag_cols(ln, 0) : frag_rows(ln, 0);
+      const int t = g >> 2, s = g & 3;
+      acc.v[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.hi, sp.hi[s][0], acc.v[t][0], 0, 0, 0);
+      acc.v[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.hi, sp.lo[s][0], acc.v[t][0], 0, 0, 0);
+      acc.v[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.lo, sp.hi[s][0], acc.v[t][0], 0, 0, 0);
+      cur = nxt;
+    }
+    // issue order: the reads of group g + 1, then the MFMAs of group g
+#pragma unroll
+    for (int g = 0; g < 7; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x100, TR ? 4 : 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, NTR ? 4 : 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using Rows = std::false_type;
+  using Cols = std::true_type;
 
-  // this wave's quadrant of every layer's weight gradient, and (nt == 0) its half of the bias gradient
-  f32x16 accW[BWD ? NLAY : 1];
+  // this wave's quadrant of every layer's weight gradient (parked: 16 AGPRs per layer), its half of the bias gradient
+  // (stored by nt == 0), and the exponent field the accumulators are relative to: accW = dW 2^(141 - Eacc), 0 = nothing yet
+  unsigned accWp[BWD ? NLAY : 1][16];
   float accB[BWD ? NLAY : 1];
-  int Eacc[BWD ? NLAY : 1];  // exponent field the accumulators are relative to: accW = dW 2^(141 - Eacc); 0 = nothing summed yet
+  int Eacc[BWD ? NLAY : 1];
   if constexpr (BWD) {
 #pragma unroll
     for (int l = 0; l < NLAY; ++l) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) accW[l][r] = 0.f;
+      for (int r = 0; r < 16; ++r) accWp[l][r] = agpr_park(0u);
       accB[l] = 0.f;
       Eacc[l] = 0;
     }
   }
 
+#ifdef MMF_FUSED_PHASE_CLOCKS
+  unsigned long long phase_acc[16] = {}, phase_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(phase_prev)::"memory");
+#endif
   const int ntiles = (a.R + 31) / 32;
   const int ngroups = (ntiles + 3) / 4;
+  // a tile's first inputs are requested one tile ahead (a dependent HBM access with nothing to issue otherwise)
+  constexpr int KS0 = (D + 2) / 2;
+  auto first_inputs = [&](int grp, float (&b)[KS0]) {
+    int r = (grp * 4 + wave) * 32 + j;
+    r = r < a.R ? r : a.R - 1;
+#pragma unroll
+    for (int s = 0; s < KS0; ++s) {
+      const int comp = 2 * s + h;
+      b[s] = comp < D ? a.states[static_cast<size_t>(r) * D + comp] : (comp == D ? 1.f : 0.f);
+    }
+  };
+  float bnext[KS0];
+  if constexpr (FIRST) {
+    if (static_cast<int>(blockIdx.x) < ngroups) first_inputs(blockIdx.x, bnext);
+  }
+
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int base = (grp * 4 + wave) * 32;
     const bool valid = base + j < a.R;  // a tile past the end: every lane invalid, contributes zeros
@@ -247,38 +362,69 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
 
     Act<1> X, H;
     SplitAct<1> sp;
-    half8 st[BWD ? NLAY : 1][4];  // f16 copy of every layer's input (the hi halves of its operand split)
+    // f16 copy of every layer's input (the hi halves of its operand split), parked in AGPRs until the backward
+    unsigned st[BWD ? NLAY : 1][16];
+    half8 sv[4];  // the copy the backward is working with: fetched once per layer (exchange, then the ReLU mask)
     auto keep = [&](int li) {
       if constexpr (BWD) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) st[li][k] = sp.hi[k][0];
+        for (int k = 0; k < 4; ++k) {
+          const u32x4 w = __builtin_bit_cast(u32x4, sp.hi[k][0]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) st[li][4 * k + e] = agpr_park(w[e]);
+        }
       }
     };
+    auto fetch = [&](int li) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        u32x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = agpr_fetch(st[li][4 * k + e]);
+        sv[k] = __builtin_bit_cast(half8, w);
+      }
+    };
+    // the incoming gradient of the tile, requested now (one or D registers)
+    float gin[NOUT];
+    if constexpr (JOIN) {
+      if constexpr (KIND == kMeasure) {
+        gin[0] = valid ? a.d_out[row] : 0.f;
+      } else {
+#pragma unroll
+        for (int i = 0; i < D; ++i) gin[i] = valid ? a.g_next[static_cast<size_t>(row) * D + i] : 0.f;
+      }
+    }
+    FUSED_STAMP(0);  // tile top: input requests
 
     // ------------------------------------------------------------------ forward (the inference kernels' arithmetic)
     if constexpr (FIRST) {
+      float bcur[KS0];
+#pragma unroll
+      for (int s = 0; s < KS0; ++s) bcur[s] = bnext[s];
+      if (grp + static_cast<int>(gridDim.x) < ngroups) first_inputs(grp + gridDim.x, bnext);
       zero_act(X);
-      constexpr int KS0 = (D + 2) / 2;
 #pragma unroll
       for (int s = 0; s < KS0; ++s) {
         const int comp = 2 * s + h;
-        const float b = comp < D ? a.states[static_cast<size_t>(row) * D + comp] : (comp == D ? 1.f : 0.f);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const float w = sW0[(32 * t + j) * kW0Cols + comp];
-          X.v[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b, X.v[t][0], 0, 0, 0);
+          X.v[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, bcur[s], X.v[t][0], 0, 0, 0);
         }
       }
       relu<1, false>(X, true);
       split_act_nr(X, sp, neg_one);
       keep(0);
       add_bias<1, false>(sBias, H, h, 1.f);
-      layer_fwd(0, sp, H);
+      product(Rows{}, Rows{}, 0, 1, sp, H);
       relu<1, false, true>(H, true);
       split_act_nr(H, sp, neg_one);
       keep(1);
       add_bias_packed<1>(sBias + kUnits, X, h);
-      layer_fwd(1, sp, X);
+      // kEncFwd: next = layer 0 of the next tile; kEnc: the backward starts with layer 1's transposed product
+      if constexpr (PART == kEncFwd) product(Rows{}, Rows{}, 1, 0, sp, X);
+      else if constexpr (PART == kEnc) product(Rows{}, Cols{}, 1, 1, sp, X);
+      else product(Rows{}, Rows{}, 1, 2, sp, X);
       relu<1, false, true>(X, true);
     } else {
       load_rows_f32(a.act_in, X, row, h, 1.f);
@@ -288,10 +434,10 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
     if constexpr (BWD) {
     float raw[NOUT];
     if constexpr (JOIN) {
-      load_rows_f32(a.traj_bias, H, traj, h, 1.f);
+      load_rows_f32(a.traj_bias, H, traj, h, 1.f);  // (32 registers: not worth carrying through the encoder layers)
       split_act_nr(X, sp, neg_one);
       keep(2 - L0);
-      layer_fwd(2 - L0, sp, H);
+      product(Rows{}, Rows{}, 2 - L0, 3 - L0, sp, H);
       if constexpr (KIND == kMeasure) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -305,12 +451,14 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
         split_act_nr(H, sp, neg_one);
         keep(l1 - L0);
         add_bias<1, false>(sBias + l1 * kUnits, X, h, 1.f);
-        layer_fwd(l1 - L0, sp, X);
+        product(Rows{}, Rows{}, l1 - L0, l1 + 1 - L0, sp, X);
         relu<1, false, true>(X, true);
         split_act_nr(X, sp, neg_one);
         keep(l1 + 1 - L0);
         add_bias_packed<1>(sBias + (l1 + 1) * kUnits, H, h);
-        layer_fwd(l1 + 1 - L0, sp, H);
+        // the last forward layer hands over to the backward's first product: its own transposed image
+        if constexpr (l1 + 2 == NL) product(Rows{}, Cols{}, l1 + 1 - L0, l1 + 1 - L0, sp, H);
+        else product(Rows{}, Rows{}, l1 + 1 - L0, l1 + 2 - L0, sp, H);
         relu<1, false, true>(H, true);
       });
       // head: each lane holds 32 of the 64 features of its particle
@@ -325,16 +473,20 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
 #pragma unroll
             for (int e = 0; e < 4; ++e) part = __builtin_fmaf(w[e], H.v[t][0][4 * g + e], part);
           }
-        raw[o] = part + __shfl_xor(part, 32) + sBhead[o];
+        raw[o] = halves_sum(part) + sBhead[o];
       }
       stash_store_h(a.h_last_h, H, row, valid, h);
     }
+    FUSED_STAMP(1);  // forward
 
     // ------------------------------------------------------------------ backward
     Act<1> G, T;
-    // in -> (scaled, split) operand of W_l^T; exchange (dz_l, a_l) and add this workgroup's 128 particles to dW_l
-    auto bwd_layer = [&](auto lc, const Act<1>& in, Act<1>& acc, float m) {
+    // in -> (scaled, split) operand of W_l^T (RES: accumulated onto acc, the block's skip path; else acc = W_l^T in);
+    // exchange (dz_l, a_l) and add this workgroup's 128 particles to dW_l
+    auto bwd_layer = [&](auto lc, auto resc, const Act<1>& in, Act<1>& acc, float m) {
       constexpr int li = decltype(lc)::value - L0;
+      constexpr bool RES = decltype(resc)::value;
+      FUSED_STAMP(2);  // between layers: masks, row maxima, head / join stores
       // c = 2^(134 - e): m c in [2^7, 2^8); rows that are all zero / non-finite / below 2^-110 keep c = 1
       const int e = (__float_as_int(m) >> 23) & 0xff;
       const bool ok = e > 16 && e < 255;
@@ -349,33 +501,43 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           x.v[t][0][r] = in.v[t][0][r] * c;
-          acc.v[t][0][r] *= c;
+          if constexpr (RES) acc.v[t][0][r] *= c;
+          else acc.v[t][0][r] = 0.f;
         }
       SplitAct<1> bs;
       split_act_nr(x, bs, neg_one);
+      FUSED_STAMP(3);  // prologue: scale, split
+      // the transposed product is issued first: the exchange below runs while the matrix pipe works through it
+      if constexpr (li > 0) product(Cols{}, Cols{}, li, li - 1, bs, acc);
+      else product(Cols{}, Rows{}, 0, 0, bs, acc);  // next: the first forward product of the next tile
+      FUSED_STAMP(4);  // transposed product issued
       __syncthreads();  // (A) every wave is done reading the previous layer's slots; the four tile maxima are written
+      FUSED_STAMP(5);  // barrier A
       const float mG = fmaxf(fmaxf(tmax[0], tmax[1]), fmaxf(tmax[2], tmax[3]));
       const int eG = __builtin_amdgcn_readfirstlane((__float_as_int(mG) >> 23) & 0xff);
       // running exponent of this layer's accumulators: a larger group rescales what has been summed so far (exact
       // powers of two, rare: only when a new largest magnitude appears), a smaller one is stored relative to it
-      if (eG > 40 && eG < 255 && eG > Eacc[li]) {
+      float down = 1.f;
+      const bool rescale = eG > 40 && eG < 255 && eG > Eacc[li];
+      if (rescale) {
         const int sh = Eacc[li] ? Eacc[li] - eG + 127 : 0;
-        const float down = sh > 0 ? __int_as_float(sh << 23) : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accW[li][r] *= down;
-        accB[li] *= down;
+        down = sh > 0 ? __int_as_float(sh << 23) : 0.f;
         Eacc[li] = eG;
       }
-      const int delta = Eacc[li] - e;
-      // exchanged value = dz 2^(141 - Eacc): the group's largest row at most in [2^14, 2^15)
-      const float fac32 = (ok && Eacc[li] != 0 && delta <= 31 && delta >= 0) ? __int_as_float((134 - delta) << 23) : 0.f;
+      // exchanged value = dz 2^(141 - Eacc): the group's largest row at most in [2^14, 2^15).  (Straight-line: a
+      // conditional here becomes an exec-masked block in the middle of the layer.)
+      const unsigned delta = static_cast<unsigned>(Eacc[li] - e);  // < 0: only when nothing of this layer is summed yet
+      const unsigned dcl = delta < 32u ? delta : 32u;
+      const float fac_all = __int_as_float((134 - static_cast<int>(dcl)) << 23);
+      const float fac32 = (ok & (Eacc[li] != 0) & (delta < 32u)) ? fac_all : 0.f;
       const _Float16 fac = static_cast<_Float16>(fac32);
       const half8 fac8 = {fac, fac, fac, fac, fac, fac, fac, fac};
       unsigned char* slot = ldsb + LY::kXchgOff + wave * LY::kSlotBytes;
+      fetch(li);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const u32x4 dzh = __builtin_bit_cast(u32x4, bs.hi[k][0] * fac8);
-        const u32x4 ah = __builtin_bit_cast(u32x4, st[li][k]);
+        const u32x4 ah = __builtin_bit_cast(u32x4, sv[k]);
 #pragma unroll
         for (int gg = 0; gg < 2; ++gg) {
           const int off = wx ^ (64 * (k >> 1) + 16 * (2 * (k & 1) + gg));
@@ -383,50 +545,76 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
           *reinterpret_cast<uint2*>(slot + 4096 + off) = make_uint2(ah[2 * gg], ah[2 * gg + 1]);
         }
       }
-      layer_bwd(li, bs, acc);
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc.v[t][0][r] *= inv;
-      __syncthreads();  // (B) the four slots are written
+      // this layer's accumulators come out of their AGPRs for the eight products below
+      f32x16 accW;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const unsigned char* sl = ldsb + LY::kXchgOff + s * LY::kSlotBytes;
+      for (int r = 0; r < 16; ++r) accW[r] = __uint_as_float(r == 15 ? agpr_fetch_for_mfma(accWp[li][r]) : agpr_fetch(accWp[li][r]));
+      if (rescale) {  // wave-uniform, rare
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const half8 A = lds_tr_pair(sl + (rxa + 2048 * kk), sl + ((rxa ^ 32) + 512 + 2048 * kk));
-          const half8 B = lds_tr_pair(sl + 4096 + (rxb + 2048 * kk), sl + 4096 + ((rxb ^ 32) + 512 + 2048 * kk));
-          accW[li] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, accW[li], 0, 0, 0);
-          if (nt == 0) {
-            const half2v one2 = {static_cast<_Float16>(1.f), static_cast<_Float16>(1.f)};
-#pragma unroll
-            for (int d2 = 0; d2 < 4; ++d2) accB[li] = __builtin_amdgcn_fdot2(half2v{A[2 * d2], A[2 * d2 + 1]}, one2, accB[li], false);
-          }
-        }
+        for (int r = 0; r < 16; ++r) accW[r] *= down;
+        accB[li] *= down;
       }
+      FUSED_STAMP(6);  // exchange writes + epilogue
+      __syncthreads();  // (B) the four slots are written
+      FUSED_STAMP(7);  // barrier B
+      // operands of product i = 2 slot + k-step, one product ahead of the MFMA that takes them
+      auto xload = [&](int i, half8& A, half8& B) {
+        const unsigned char* sl = ldsb + LY::kXchgOff + (i >> 1) * LY::kSlotBytes + 2048 * (i & 1);
+        A = lds_tr_pair(sl + rxa, sl + ((rxa ^ 32) + 512));
+        B = lds_tr_pair(sl + 4096 + rxb, sl + 4096 + ((rxb ^ 32) + 512));
+      };
+      __builtin_amdgcn_sched_barrier(0);
+      half8 A, B;
+      xload(0, A, B);
+      const half2v one2 = {static_cast<_Float16>(1.f), static_cast<_Float16>(1.f)};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        half8 An, Bn;
+        if (i < 7) xload(i + 1, An, Bn);
+        accW = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, accW, 0, 0, 0);
+#pragma unroll
+        for (int d2 = 0; d2 < 4; ++d2) accB[li] = __builtin_amdgcn_fdot2(half2v{A[2 * d2], A[2 * d2 + 1]}, one2, accB[li], false);
+        A = An;
+        B = Bn;
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // operands of products 0 and 1
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accWp[li][r] = r == 0 ? agpr_park_after_mfma(__float_as_uint(accW[r])) : agpr_park(__float_as_uint(accW[r]));
+      FUSED_STAMP(8);  // weight-gradient products
     };
+    using Skip = std::true_type;
+    using NoSkip = std::false_type;
     auto bwd_block = [&](auto l1c) {  // residual block of layers l1, l1 + 1; G = dL / d (block output, post-ReLU)
       constexpr int l1 = decltype(l1c)::value;
       // (the caller has applied the block output's ReLU mask to G)       dz2 = G
-      zero_act(T);
-      bwd_layer(std::integral_constant<int, l1 + 1>{}, G, T, row_absmax(G));   // T = W2^T dz2
-      mask_by_halves(st[l1 + 1 - L0], T);                                        // dz1 = T * [h > 0]
-      bwd_layer(std::integral_constant<int, l1>{}, T, G, row_absmax(T));       // G = dz2 + W1^T dz1
+      bwd_layer(std::integral_constant<int, l1 + 1>{}, NoSkip{}, G, T, row_absmax_swap(G));  // T = W2^T dz2
+      mask_by_halves(sv, T);                                                                   // dz1 = T * [h > 0]  (sv = st[l1 + 1])
+      bwd_layer(std::integral_constant<int, l1>{}, Skip{}, T, G, row_absmax_swap(T));        // G = dz2 + W1^T dz1
     };
 
     if constexpr (HEAD) {
       float go[NOUT];
       if constexpr (KIND == kMeasure) {
-        go[0] = valid ? a.d_out[row] : 0.f;
+        go[0] = gin[0];
       } else {
         // x' = x + dir sigmoid(gate): d dir_i = g_i s, d gate = (sum_i g_i dir_i) s (1 - s)
         const float s = 1.0f / (1.0f + expf(-raw[D]));
         float dot = 0.f;
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-          const float gi = valid ? a.g_next[static_cast<size_t>(row) * D + i] : 0.f;
-          go[i] = gi * s;
-          dot += gi * raw[i];
+          go[i] = gin[i] * s;
+          dot += gin[i] * raw[i];
         }
         go[D] = dot * s * (1.0f - s);
         if (valid && h == 0) {
@@ -449,14 +637,13 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
         constexpr int l1 = 3 + 2 * b;
         bwd_block(std::integral_constant<int, l1>{});
         // G = dL / d (input of layer l1) = the previous block's output (post-ReLU), or the join layer's output
-        if constexpr (l1 > 3 || KIND == kMeasure) mask_by_halves(st[l1 - L0], G);
+        if constexpr (l1 > 3 || KIND == kMeasure) mask_by_halves(sv, G);  // sv = st[l1], left by the block's last layer
       });
       // join layer: G = dL / d (its pre-activation output)
       {
-        const float mj = row_absmax(G);
+        const float mj = row_absmax_swap(G);
         dz_store_h(a.dz_join_h, a.sc_join, G, row, valid, h, tile_absmax(mj));
-        zero_act(T);
-        bwd_layer(std::integral_constant<int, 2>{}, G, T, mj);
+        bwd_layer(std::integral_constant<int, 2>{}, NoSkip{}, G, T, mj);
       }
       if constexpr (PART == kTrunk) {
         stash_store(a.g_out, T, row, valid, h);
@@ -470,27 +657,41 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
     if constexpr (FIRST) {
       // G = dL / d (encoder output, post-ReLU): the ReLU that ends block 0 (kEnc: X still holds that output)
       if constexpr (PART == kEnc) mask_by_act(X, G);
-      else mask_by_halves(st[2], G);
+      else mask_by_halves(sv, G);  // sv = st[2], left by the join layer
       bwd_block(std::integral_constant<int, 0>{});
-      mask_by_halves(st[0], G);  // first layer (d -> 64): dz_in = da0 * [a0 > 0]
-      const float mf = row_absmax(G);
+      mask_by_halves(sv, G);  // first layer (d -> 64): dz_in = da0 * [a0 > 0]  (sv = st[0])
+      const float mf = row_absmax_swap(G);
       dz_store_h(a.dz_first_h, a.sc_first, G, row, valid, h, tile_absmax(mf));
-      // d states[i] = sum_f W_in[f][i] dz_in[f]
+      // d states[i] = sum_f W_in[f][i] dz_in[f]: four features of the lane's 32 per ds_read_b128 of the transposed copy
+      float ds[D];
+#pragma unroll
+      for (int i = 0; i < D; ++i) ds[i] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int i = 0; i < D; ++i) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(sW0T + i * kUnits + 32 * t + 8 * g + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ds[i] = __builtin_fmaf(w[e], G.v[t][0][4 * g + e], ds[i]);
+          }
+#pragma unroll
       for (int i = 0; i < D; ++i) {
-        float part = 0.f;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) part += sW0[(32 * t + rowmap(r, h)) * kW0Cols + i] * G.v[t][0][r];
-        part += __shfl_xor(part, 32);
-        if (valid && h == 0) a.d_states[static_cast<size_t>(row) * D + i] = part;
+        const float v = halves_sum(ds[i]);
+        if (valid && h == 0) a.d_states[static_cast<size_t>(row) * D + i] = v;
       }
     }
+    FUSED_STAMP(9);  // first layer, d states
     }  // BWD
   }
+#ifdef MMF_FUSED_PHASE_CLOCKS
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int i = 0; i < 16; ++i) g_fused_phases[i] = phase_acc[i];
+#endif
 
   if constexpr (BWD) {
-    // accW[li][r] of lane (c, h2) = dW_l[32 mt + rowmap(r, h2)][32 nt + c] 2^(141 - Eacc): added to this workgroup's partial
+    // accW[r] of lane (c, h2) = dW_l[32 mt + rowmap(r, h2)][32 nt + c] 2^(141 - Eacc): added to this workgroup's partial
 #pragma unroll
     for (int li = 0; li < NLAY; ++li) {
       const float fs = Eacc[li] ? __int_as_float((Eacc[li] - 14) << 23) : 0.f;
@@ -498,12 +699,10 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float* qp = pw + (32 * mt + rowmap(r, h)) * kUnits;
-        *qp += accW[li][r] * fs;
+        *qp += __uint_as_float(agpr_fetch(accWp[li][r])) * fs;
       }
-      if (nt == 0) {
-        const float v = (accB[li] + __shfl_xor(accB[li], 32)) * fs;
-        if (h == 0) a.pb[(static_cast<size_t>(L0 + li) * a.slots + blockIdx.x) * kUnits + 32 * mt + j] += v;
-      }
+      const float v = halves_sum(accB[li]) * fs;
+      if (nt == 0 && h == 0) a.pb[(static_cast<size_t>(L0 + li) * a.slots + blockIdx.x) * kUnits + 32 * mt + j] += v;
     }
   }
 }
