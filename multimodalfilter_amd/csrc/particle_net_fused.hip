@@ -193,8 +193,8 @@ __device__ __forceinline__ float row_absmax_swap(const Act<1>& a) {
 }
 
 // ---- registers parked in AGPRs by hand (see the header).  The compiler cannot look into the asm, so the wait states
-// it would insert around MFMA results are spelled out where they can matter: `agpr_park_after_mfma` for a value an MFMA
-// has just written, `agpr_fetch_for_mfma` for one an MFMA is about to read as its C operand.
+// it would insert around MFMA results are spelled out where they can matter: `settle_mfma_result` on a value an MFMA
+// has just written, before it is parked; `settle_mfma_operand` on one fetched for an MFMA's C operand.
 __device__ __forceinline__ unsigned agpr_park(unsigned v) {
   unsigned a;
   asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
@@ -205,14 +205,12 @@ __device__ __forceinline__ unsigned agpr_fetch(unsigned a) {
   asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
   return v;
 }
-__device__ __forceinline__ unsigned agpr_park_after_mfma(unsigned v) {
-  unsigned a;
-  asm volatile("s_nop 15\n\ts_nop 3\n\tv_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
-  return a;
-}
-__device__ __forceinline__ unsigned agpr_fetch_for_mfma(unsigned a) {
+// (wait states tied to the VALUE, so that neither the scheduler nor the asm's neighbours can slip between them and it)
+__device__ __forceinline__ void settle_mfma_result(f32x16& acc) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc)); }
+__device__ __forceinline__ void settle_mfma_operand(f32x16& acc) { asm volatile("s_nop 3" : "+v"(acc)); }
+__device__ __forceinline__ unsigned agpr_fetch_settled(unsigned a) {  // right after the park that wrote it
   unsigned v;
-  asm volatile("v_accvgpr_read_b32 %0, %1\n\ts_nop 3" : "=v"(v) : "a"(a));
+  asm volatile("s_nop 3\n\tv_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
   return v;
 }
 
@@ -552,12 +550,13 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
       // this layer's accumulators come out of their AGPRs for the eight products below
       f32x16 accW;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) accW[r] = __uint_as_float(r == 15 ? agpr_fetch_for_mfma(accWp[li][r]) : agpr_fetch(accWp[li][r]));
+      for (int r = 0; r < 16; ++r) accW[r] = __uint_as_float(agpr_fetch(accWp[li][r]));
       if (rescale) {  // wave-uniform, rare
 #pragma unroll
         for (int r = 0; r < 16; ++r) accW[r] *= down;
         accB[li] *= down;
       }
+      settle_mfma_operand(accW);
       FUSED_STAMP(6);  // exchange writes + epilogue
       __syncthreads();  // (B) the four slots are written
       FUSED_STAMP(7);  // barrier B
@@ -589,8 +588,9 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
         if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+      settle_mfma_result(accW);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) accWp[li][r] = r == 0 ? agpr_park_after_mfma(__float_as_uint(accW[r])) : agpr_park(__float_as_uint(accW[r]));
+      for (int r = 0; r < 16; ++r) accWp[li][r] = agpr_park(__float_as_uint(accW[r]));
       FUSED_STAMP(8);  // weight-gradient products
     };
     using Skip = std::true_type;
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float* qp = pw + (32 * mt + rowmap(r, h)) * kUnits;
-        *qp += __uint_as_float(agpr_fetch(accWp[li][r])) * fs;
+        *qp += __uint_as_float(agpr_fetch_settled(accWp[li][r])) * fs;
       }
       const float v = halves_sum(accB[li]) * fs;
       if (nt == 0 && h == 0) a.pb[(static_cast<size_t>(L0 + li) * a.slots + blockIdx.x) * kUnits + 32 * mt + j] += v;
