@@ -560,32 +560,32 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
       FUSED_STAMP(6);  // exchange writes + epilogue
       __syncthreads();  // (B) the four slots are written
       FUSED_STAMP(7);  // barrier B
-      // operands of product i = 2 slot + k-step, one product ahead of the MFMA that takes them
+      // operands of product i = 2 slot + k-step: the LDS pipe is what bounds this phase (32 transposing reads per wave,
+      // all four waves at once), so the reads of FOUR products are in flight before the first MFMA and the other four
+      // are requested under those MFMAs
       auto xload = [&](int i, half8& A, half8& B) {
         const unsigned char* sl = ldsb + LY::kXchgOff + (i >> 1) * LY::kSlotBytes + 2048 * (i & 1);
         A = lds_tr_pair(sl + rxa, sl + ((rxa ^ 32) + 512));
         B = lds_tr_pair(sl + 4096 + rxb, sl + 4096 + ((rxb ^ 32) + 512));
       };
       __builtin_amdgcn_sched_barrier(0);
-      half8 A, B;
-      xload(0, A, B);
+      half8 A[8], B[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xload(i, A[i], B[i]);
       const half2v one2 = {static_cast<_Float16>(1.f), static_cast<_Float16>(1.f)};
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        half8 An, Bn;
-        if (i < 7) xload(i + 1, An, Bn);
-        accW = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, accW, 0, 0, 0);
+        if (i < 4) xload(i + 4, A[i + 4], B[i + 4]);
+        accW = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], B[i], accW, 0, 0, 0);
 #pragma unroll
-        for (int d2 = 0; d2 < 4; ++d2) accB[li] = __builtin_amdgcn_fdot2(half2v{A[2 * d2], A[2 * d2 + 1]}, one2, accB[li], false);
-        A = An;
-        B = Bn;
+        for (int d2 = 0; d2 < 4; ++d2) accB[li] = __builtin_amdgcn_fdot2(half2v{A[i][2 * d2], A[i][2 * d2 + 1]}, one2, accB[li], false);
       }
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // operands of products 0 and 1
+      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);  // operands of products 0 .. 3
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
+        if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       settle_mfma_result(accW);
