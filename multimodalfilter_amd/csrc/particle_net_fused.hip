@@ -173,6 +173,54 @@ __device__ __forceinline__ void mask_by_act(const Act<1>& a, Act<1>& g) {
     for (int r = 0; r < 16; ++r) g.v[t][0][r] = a.v[t][0][r] > 0.f ? g.v[t][0][r] : 0.f;
 }
 
+// ---- the forward chain, software-pipelined on output ROW tiles (the scheme of particle_net.hip's rowpipe_net_f16, for a
+// lone 32-particle tile): an MFMA holds the SIMD's vector issue for 8 of its 32 cycles, so ~6 independent VALU
+// instructions per MFMA are free.  Rows 0..31 of a layer's output (tile 0) feed k-steps 0, 1 of the next layer and rows
+// 32..63 (tile 1) k-steps 2, 3, so the fragment groups run (t0,s0) (t0,s1) (t1,s0) (t1,s1) | (t0,s2) (t0,s3) |
+// (t1,s2) (t1,s3): tile 1 of the PREVIOUS layer is activated / split / parked under the first four groups, the next
+// layer's accumulator is initialised under the next two, tile 0 of THIS layer is post-processed under the last two.
+constexpr int kPipeT[8] = {0, 0, 1, 1, 0, 0, 1, 1};
+constexpr int kPipeS[8] = {0, 1, 0, 1, 2, 3, 2, 3};
+enum FusedAct { kFaReluSat = 0, kFaReluKeepNan = 1, kFaSaturate = 2 };
+
+template <int T, int ACT>
+__device__ __forceinline__ void act_rows(Act<1>& a) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float v = a.v[T][0][r];
+    a.v[T][0][r] = ACT == kFaReluSat ? relu_sat(v) : ACT == kFaReluKeepNan ? relu_keepnan(v) : clamp_sat(v);
+  }
+}
+// rows of tile T -> k-steps 2 T, 2 T + 1 of the next operand
+template <int T>
+__device__ __forceinline__ void split_rows(const Act<1>& x, SplitAct<1>& o, float neg_one) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    u32x4 hh, ll;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      unsigned a, b;
+      split_pair_plain(x.v[T][0][8 * u + 2 * p], x.v[T][0][8 * u + 2 * p + 1], neg_one, a, b);
+      hh[p] = a;
+      ll[p] = b;
+    }
+    o.hi[2 * T + u][0] = __builtin_bit_cast(half8, hh);
+    o.lo[2 * T + u][0] = __builtin_bit_cast(half8, ll);
+  }
+}
+template <int GROUPS, int READS, int VPM>
+__device__ __forceinline__ void pin_groups() {
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g) {
+    __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);  // the fragments of a later group
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);  // VALU in its shadow
+    }
+  }
+}
+
 // lanes j and j + 32 hold the two halves of particle j's features: combine them with ONE v_permlane32_swap (a VALU
 // operation) instead of a __shfl_xor (ds_bpermute: an LDS-pipe round trip a lone wave per SIMD cannot hide)
 __device__ __forceinline__ float halves_max(float v) {
@@ -318,14 +366,14 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
   // this wave's quadrant of every layer's weight gradient (parked: 16 AGPRs per layer), its half of the bias gradient
   // (stored by nt == 0), and the exponent field the accumulators are relative to: accW = dW 2^(141 - Eacc), 0 = nothing yet
   unsigned accWp[BWD ? NLAY : 1][16];
-  float accB[BWD ? NLAY : 1];
+  unsigned accBp[BWD ? NLAY : 1];
   int Eacc[BWD ? NLAY : 1];
   if constexpr (BWD) {
 #pragma unroll
     for (int l = 0; l < NLAY; ++l) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) accWp[l][r] = agpr_park(0u);
-      accB[l] = 0.f;
+      accBp[l] = agpr_park(0u);
       Eacc[l] = 0;
     }
   }
@@ -363,16 +411,6 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
     // f16 copy of every layer's input (the hi halves of its operand split), parked in AGPRs until the backward
     unsigned st[BWD ? NLAY : 1][16];
     half8 sv[4];  // the copy the backward is working with: fetched once per layer (exchange, then the ReLU mask)
-    auto keep = [&](int li) {
-      if constexpr (BWD) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const u32x4 w = __builtin_bit_cast(u32x4, sp.hi[k][0]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) st[li][4 * k + e] = agpr_park(w[e]);
-        }
-      }
-    };
     auto fetch = [&](int li) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -394,7 +432,21 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
     }
     FUSED_STAMP(0);  // tile top: input requests
 
-    // ------------------------------------------------------------------ forward (the inference kernels' arithmetic)
+    // ------------------------------------------------------------------ forward (the inference kernels' arithmetic,
+    // pipelined on output row tiles: see kPipeT / kPipeS)
+    Frag fr[3];  // fragment groups in flight: the one being multiplied and the next two
+    fr[0] = cur;
+    fr[1] = frag_rows(0, 4 * kPipeT[1] + kPipeS[1]);
+    auto park_ksteps = [&](int li, int k0) {  // hi halves of k-steps k0, k0 + 1 of the operand split -> st[li]
+      if constexpr (BWD) {
+#pragma unroll
+        for (int k = k0; k < k0 + 2; ++k) {
+          const u32x4 w = __builtin_bit_cast(u32x4, sp.hi[k][0]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) st[li][4 * k + e] = agpr_park(w[e]);
+        }
+      }
+    };
     if constexpr (FIRST) {
       float bcur[KS0];
 #pragma unroll
@@ -411,54 +463,82 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
         }
       }
       relu<1, false>(X, true);
-      split_act_nr(X, sp, neg_one);
-      keep(0);
       add_bias<1, false>(sBias, H, h, 1.f);
-      product(Rows{}, Rows{}, 0, 1, sp, H);
-      relu<1, false, true>(H, true);
-      split_act_nr(H, sp, neg_one);
-      keep(1);
-      add_bias_packed<1>(sBias + kUnits, X, h);
-      // kEncFwd: next = layer 0 of the next tile; kEnc: the backward starts with layer 1's transposed product
-      if constexpr (PART == kEncFwd) product(Rows{}, Rows{}, 1, 0, sp, X);
-      else if constexpr (PART == kEnc) product(Rows{}, Cols{}, 1, 1, sp, X);
-      else product(Rows{}, Rows{}, 1, 2, sp, X);
-      relu<1, false, true>(X, true);
     } else {
       load_rows_f32(a.act_in, X, row, h, 1.f);
+      load_rows_f32(a.traj_bias, H, traj, h, 1.f);
+    }
+    split_rows<0>(X, sp, neg_one);
+    split_rows<1>(X, sp, neg_one);
+    park_ksteps(0, 0);
+    park_ksteps(0, 2);
+    static_for<NLAY>([&](auto lc) {
+      constexpr int li = decltype(lc)::value, l = L0 + li;
+      constexpr bool out_h = l == 0 || l == 2 || (l > 2 && (l - 3) % 2 == 1);
+      Act<1>& out = out_h ? H : X;
+      Act<1>& prev = out_h ? X : H;  // this layer's input activation; its registers become the next layer's accumulator
+      constexpr bool last = li == NLAY - 1;
+      // the activation between layer l - 1 and l, and between l and l + 1 (the join layer's output: ReLU for the
+      // measurement networks, none -- only the f16 saturation -- for the dynamics)
+      constexpr int act_in = l == 3 ? (KIND == kMeasure ? kFaReluKeepNan : kFaSaturate) : kFaReluSat;
+      constexpr int act_out = l + 1 == 3 ? (KIND == kMeasure ? kFaReluKeepNan : kFaSaturate) : kFaReluSat;
+      auto step = [&](auto gc) {
+        constexpr int G = decltype(gc)::value, i = 8 * li + G, n = i + 2;
+        if constexpr (n < 8 * NLAY) fr[n % 3] = frag_rows(n / 8, 4 * kPipeT[n % 8] + kPipeS[n % 8]);
+        else if constexpr (n == 8 * NLAY) fr[n % 3] = BWD ? frag_cols(NLAY - 1, 0) : frag_rows(0, 0);  // what follows the forward
+        constexpr int t = kPipeT[G], sk = kPipeS[G];
+        const Frag f = fr[i % 3];
+        out.v[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.hi, sp.hi[sk][0], out.v[t][0], 0, 0, 0);
+        out.v[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.hi, sp.lo[sk][0], out.v[t][0], 0, 0, 0);
+        out.v[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.lo, sp.hi[sk][0], out.v[t][0], 0, 0, 0);
+      };
+      asm volatile("" ::: "memory");  // keep the fragment reads inside the tile loop (see mfma_layer)
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- region 1: k-steps 0, 1 of both output tiles || tile 1 of the previous layer -> k-steps 2, 3
+      step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+      if constexpr (li > 0) {
+        act_rows<1, act_in>(prev);
+        split_rows<1>(prev, sp, neg_one);
+        park_ksteps(li, 2);
+      }
+      pin_groups<4, 2, 6>();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- region 2: tile 0 completes || the next layer's accumulator: bias, skip + bias, or the per-trajectory term
+      step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+      if constexpr (!last) {
+        constexpr int m = l + 1;
+        if constexpr (m == 2) {
+          // the join's per-trajectory term (an L2 hit; consumed by the join layer's first MFMAs, twelve MFMAs from here)
+          load_rows_f32(a.traj_bias, prev, traj, h, 1.f);
+        } else if constexpr (m == 1 || (m > 3 && (m - 3) % 2 == 1)) {
+          add_bias_packed<1>(sBias + m * kUnits, prev, h);  // the block's skip + bias
+        } else {
+          add_bias<1, false>(sBias + m * kUnits, prev, h, 1.f);
+        }
+      }
+      pin_groups<2, 2, 6>();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- region 3: tile 1 completes || tile 0 of this layer -> k-steps 0, 1 of the next
+      step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+      act_rows<0, act_out>(out);
+      if constexpr (!last) {
+        split_rows<0>(out, sp, neg_one);
+        park_ksteps(li + 1, 0);
+      }
+      pin_groups<2, 2, 6>();
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    cur = fr[(8 * NLAY) % 3];
+    {
+      constexpr bool last_is_h = (L0 + NLAY - 1) == 0 || (L0 + NLAY - 1) == 2 || ((L0 + NLAY - 1) > 2 && (L0 + NLAY - 4) % 2 == 1);
+      act_rows<1, kFaReluSat>(last_is_h ? H : X);  // tile 1 of the part's last layer
     }
     if constexpr (PART == kEncFwd) stash_store(a.act_out, X, row, valid, h);
 
     if constexpr (BWD) {
     float raw[NOUT];
     if constexpr (JOIN) {
-      load_rows_f32(a.traj_bias, H, traj, h, 1.f);  // (32 registers: not worth carrying through the encoder layers)
-      split_act_nr(X, sp, neg_one);
-      keep(2 - L0);
-      product(Rows{}, Rows{}, 2 - L0, 3 - L0, sp, H);
-      if constexpr (KIND == kMeasure) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) H.v[t][0][r] = relu_keepnan(H.v[t][0][r]);
-      } else {
-        saturate<1>(H);
-      }
-      static_for<NRES>([&](auto ic) {
-        constexpr int l1 = 3 + 2 * decltype(ic)::value;
-        split_act_nr(H, sp, neg_one);
-        keep(l1 - L0);
-        add_bias<1, false>(sBias + l1 * kUnits, X, h, 1.f);
-        product(Rows{}, Rows{}, l1 - L0, l1 + 1 - L0, sp, X);
-        relu<1, false, true>(X, true);
-        split_act_nr(X, sp, neg_one);
-        keep(l1 + 1 - L0);
-        add_bias_packed<1>(sBias + (l1 + 1) * kUnits, H, h);
-        // the last forward layer hands over to the backward's first product: its own transposed image
-        if constexpr (l1 + 2 == NL) product(Rows{}, Cols{}, l1 + 1 - L0, l1 + 1 - L0, sp, H);
-        else product(Rows{}, Rows{}, l1 + 1 - L0, l1 + 2 - L0, sp, H);
-        relu<1, false, true>(H, true);
-      });
       // head: each lane holds 32 of the 64 features of its particle
 #pragma unroll
       for (int o = 0; o < NOUT; ++o) {
@@ -554,40 +634,42 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
       if (rescale) {  // wave-uniform, rare
 #pragma unroll
         for (int r = 0; r < 16; ++r) accW[r] *= down;
-        accB[li] *= down;
       }
       settle_mfma_operand(accW);
       FUSED_STAMP(6);  // exchange writes + epilogue
       __syncthreads();  // (B) the four slots are written
       FUSED_STAMP(7);  // barrier B
-      // operands of product i = 2 slot + k-step: the LDS pipe is what bounds this phase (32 transposing reads per wave,
-      // all four waves at once), so the reads of FOUR products are in flight before the first MFMA and the other four
-      // are requested under those MFMAs
+      // operands of product i = 2 slot + k-step, one product ahead of the MFMA that takes them (four ahead: no faster,
+      // 48 more registers)
       auto xload = [&](int i, half8& A, half8& B) {
         const unsigned char* sl = ldsb + LY::kXchgOff + (i >> 1) * LY::kSlotBytes + 2048 * (i & 1);
         A = lds_tr_pair(sl + rxa, sl + ((rxa ^ 32) + 512));
         B = lds_tr_pair(sl + 4096 + rxb, sl + 4096 + ((rxb ^ 32) + 512));
       };
       __builtin_amdgcn_sched_barrier(0);
-      half8 A[8], B[8];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xload(i, A[i], B[i]);
+      half8 A, B;
+      xload(0, A, B);
       const half2v one2 = {static_cast<_Float16>(1.f), static_cast<_Float16>(1.f)};
+      float bsum = 0.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        if (i < 4) xload(i + 4, A[i + 4], B[i + 4]);
-        accW = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[i], B[i], accW, 0, 0, 0);
+        half8 An, Bn;
+        if (i < 7) xload(i + 1, An, Bn);
+        accW = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, accW, 0, 0, 0);
 #pragma unroll
-        for (int d2 = 0; d2 < 4; ++d2) accB[li] = __builtin_amdgcn_fdot2(half2v{A[i][2 * d2], A[i][2 * d2 + 1]}, one2, accB[li], false);
+        for (int d2 = 0; d2 < 4; ++d2) bsum = __builtin_amdgcn_fdot2(half2v{A[2 * d2], A[2 * d2 + 1]}, one2, bsum, false);
+        A = An;
+        B = Bn;
       }
-      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);  // operands of products 0 .. 3
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // operands of products 0 and 1
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+      accBp[li] = agpr_park(__float_as_uint(__uint_as_float(agpr_fetch(accBp[li])) * (rescale ? down : 1.f) + bsum));
       settle_mfma_result(accW);
 #pragma unroll
       for (int r = 0; r < 16; ++r) accWp[li][r] = agpr_park(__float_as_uint(accW[r]));
@@ -701,7 +783,7 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
         float* qp = pw + (32 * mt + rowmap(r, h)) * kUnits;
         *qp += __uint_as_float(agpr_fetch_settled(accWp[li][r])) * fs;
       }
-      const float v = halves_sum(accB[li]) * fs;
+      const float v = halves_sum(__uint_as_float(agpr_fetch_settled(accBp[li]))) * fs;
       if (nt == 0 && h == 0) a.pb[(static_cast<size_t>(L0 + li) * a.slots + blockIdx.x) * kUnits + 32 * mt + j] += v;
     }
   }

@@ -24,7 +24,8 @@ static float* dev_random(size_t n, float scale) {
 
 int main(int argc, char** argv) {
   const int N = argc > 1 ? atoi(argv[1]) : 32, M = argc > 2 ? atoi(argv[2]) : 8192, d = 3, kind = argc > 3 ? atoi(argv[3]) : 1;
-  const int n_res = kind == 1 ? 2 : 3, NL = 3 + 2 * n_res;
+  const int n_res_arg = argc > 4 ? atoi(argv[4]) : -1;  // experiment: a measurement network with fewer blocks (register pressure)
+  const int n_res = n_res_arg >= 0 ? n_res_arg : (kind == 1 ? 2 : 3), NL = 3 + 2 * n_res;
   const size_t R = size_t(N) * M;
   // blob: small f16 halves (|w| < 0.1) packed two per float; the fp32 sections (W0, biases, head) small floats
   std::vector<float> hb(blob_floats(n_res));
@@ -52,7 +53,17 @@ int main(int argc, char** argv) {
   for (int rep = 0; rep < 4; ++rep) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    const int rc = mmf_particle_net_train_fused(&c, nullptr);
+    int rc;
+    if (n_res_arg >= 0 && kind == 1) {
+      FusedArgs a{};
+      a.blob = c.packed_dual; a.states = c.states; a.traj_bias = c.traj_bias; a.d_out = c.d_out; a.d_states = c.d_states;
+      a.dz_first_h = static_cast<_Float16*>(c.dz_first_h); a.sc_first = c.sc_first; a.dz_join_h = static_cast<_Float16*>(c.dz_join_h);
+      a.sc_join = c.sc_join; a.h_last_h = static_cast<_Float16*>(c.h_last_h); a.pw = c.pw; a.pb = c.pb; a.R = N * M; a.M = M; a.slots = 256;
+      rc = n_res_arg == 1 ? launch_fused<3, 1, kMeasure, kFull>(a, nullptr) : n_res_arg == 0 ? launch_fused<3, 0, kMeasure, kFull>(a, nullptr)
+                                                                                  : launch_fused<3, 2, kMeasure, kFull>(a, nullptr);
+    } else {
+      rc = mmf_particle_net_train_fused(&c, nullptr);
+    }
     if (rc) { printf("rc %d\n", rc); return 2; }
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
