@@ -269,3 +269,100 @@ def test_counter_noise_makes_an_eight_way_sharded_filter_equal_the_single_proces
             assert np.array_equal(a, b)
         assert np.array_equal(strict.philox_uniforms(4711, 0, T, hi - lo, traj0=lo), strict.philox_uniforms(4711, 0, T, N, traj0=0)[:, lo:hi])
     torch.testing.assert_close(torch.cat(parts, dim=1), whole, rtol=0, atol=1e-5)
+
+
+# ---- the data-parallel TRAINING step (BASELINE config 5; SURVEY.md 8e "Collective (training, C5)"): replicated weights,
+# rank-private subsequence batches, one flat all-reduce of the gradients, optimiser step.  The HIP engine cannot run
+# here; the CPU oracle's train-mode particle filter (torch autograd) stands in as the per-rank model.
+def _train_step(f, traj, eps0, eps, d, lr, all_reduce):
+    from oracle.tf.base import ReplayNoise
+
+    N = traj["states"].shape[1]
+    f.noise = ReplayNoise([eps0] + list(eps), [])
+    cov = (torch.eye(d) * 0.1)[None].expand(N, d, d)
+    opt = torch.optim.SGD(f.parameters(), lr=lr)
+    opt.zero_grad(set_to_none=True)
+    f.initialize_beliefs(mean=traj["states"][0], covariance=cov)
+    pred = f.forward_loop(observations={k: traj[k][1:] for k in ("image", "gripper_pos", "gripper_sensors")},
+                          controls=traj["controls"][1:])
+    loss = torch.mean((pred - traj["states"][1:]) ** 2)
+    loss.backward()
+    if all_reduce:
+        distributed.all_reduce_gradients(f)
+    opt.step()
+    return float(loss.detach())
+
+
+def _train_model(M):
+    from oracle import models as om
+
+    torch.set_num_threads(1)
+    f = om.build("PushUnimodalParticleFilter")
+    f.load_state_dict(om.seeded_state_dict(f, seed=5, gain=1.0))
+    f.train()
+    f.num_particles = M
+    return f
+
+
+def _train_worker(rank, world, port, N, T, M, d, lr, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    distributed.init_from_env(backend="gloo")
+    traj = synthetic.make_trajectories(state_dim=d, T=T, N=N, seed=21)
+    g = torch.Generator().manual_seed(22)
+    eps0 = torch.randn((N, M, d), generator=g)
+    eps = [torch.randn((N, M, d), generator=g) for _ in range(T)]
+    lo, hi = distributed.shard_bounds(N, rank, world)
+    f = _train_model(M)
+    loss = _train_step(f, distributed.shard_trajectories(traj, rank, world), eps0[lo:hi], [e[lo:hi] for e in eps], d, lr, True)
+    torch.save({"loss": loss, "params": {k: v.detach().clone() for k, v in f.named_parameters()}}, os.path.join(out_dir, f"t{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 8])
+def test_data_parallel_training_step_equals_the_single_process_step(tmp_path, world):
+    """After ONE data-parallel optimiser step (``train.train_filter_step(.., all_reduce=True)``'s sequence: backward,
+    ``distributed.all_reduce_gradients``, step) every rank holds the same weights bit for bit, and they equal the
+    weights of a single process stepping on the concatenated batch (equal shards: the mean of the shard losses is the
+    batch loss) to fp32 summation order."""
+    N, T, M, d, lr = 8, 2, 6, 2, 0.05
+    port = _free_port()
+    mp.spawn(_train_worker, args=(world, port, N, T, M, d, lr, str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(tmp_path / f"t{r}.pt") for r in range(world)]
+    for r in range(1, world):
+        for k, v in got[0]["params"].items():
+            assert torch.equal(v, got[r]["params"][k]), (r, k)
+    traj = synthetic.make_trajectories(state_dim=d, T=T, N=N, seed=21)
+    g = torch.Generator().manual_seed(22)
+    eps0 = torch.randn((N, M, d), generator=g)
+    eps = [torch.randn((N, M, d), generator=g) for _ in range(T)]
+    f = _train_model(M)
+    before = {k: v.detach().clone() for k, v in f.named_parameters()}
+    loss = _train_step(f, traj, eps0, eps, d, lr, False)
+    assert abs(sum(x["loss"] for x in got) / world - loss) < 1e-5 * max(1.0, abs(loss))
+    moved = 0
+    for k, v in f.named_parameters():
+        step = (v.detach() - before[k]).abs().max()
+        moved += int(step > 0)
+        torch.testing.assert_close(got[0]["params"][k], v.detach(), rtol=1e-4, atol=1e-6 + 1e-3 * float(step))
+    assert moved > 20  # the step changed the networks (a no-op step would pass the comparison trivially)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_training_leg_preflight(world):
+    """``bench.py --workload push_train --gpus N`` rehearsed with N gloo ranks and no GPU work (``MMF_BENCH_DRY``): the
+    launcher spawns the ranks before anything touches HIP, they rendezvous, and the training leg's one collective -- a
+    flat all-reduce of the filter's 696,993 gradient elements -- leaves the exact average on every rank."""
+    import json
+
+    r = _run_bench({"MMF_BENCH_DRY": "1", "MMF_DIST_BACKEND": "gloo", "OMP_NUM_THREADS": "1"}, "--gpus", str(world),
+                   "--workload", "push_train", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["workload"] == "push_train" and out["n_gpus"] == world and out["world_size_seen"] == world
+    assert out["allreduce_elements"] == 696993 and out["allreduce_average_exact_on_every_rank"] is True
+    assert out["allreduce_ms"] > 0 and out["global_batch"] == 32 * world
