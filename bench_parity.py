@@ -482,7 +482,20 @@ def cpu_baseline_ekf(wl, engine_filter, state_dim, cores, sample_batch=256, samp
     dev = next(engine_filter.parameters()).device
     got = evaluation.run_filter(engine_filter, to_device(traj, dev)).cpu()
     scale = max(1.0, float(want.abs().max()))
-    parity = {"max_rel_err_posterior_mean": float((got - want).abs().max()) / scale}
+
+    def elementwise(a, b, floor=1e-3):  # every entry against its own magnitude (floor: 1e-3 of the tensor's largest)
+        a, b = a.detach().cpu().double(), b.detach().cpu().double()
+        return float(((a - b).abs() / b.abs().clamp_min(floor * float(b.abs().max()))).max())
+
+    # posterior covariances after the last step: every sub-filter's belief (and the fused one where the filter keeps it)
+    subs_o = list(oracle.filter_models) if hasattr(oracle, "filter_models") else [oracle]
+    subs_e = list(engine_filter.filter_models) if hasattr(engine_filter, "filter_models") else [engine_filter]
+    cov_err = max(elementwise(fe._belief_covariance, fo._belief_covariance) for fo, fe in zip(subs_o, subs_e))
+    parity = {"max_rel_err_posterior_mean": float((got - want).abs().max()) / scale,
+              "max_rel_err_posterior_mean_elementwise": elementwise(got, want),
+              "max_rel_err_posterior_covariance": cov_err,
+              "note": "mean: relative to max(1, largest mean); *_elementwise and covariance: every entry relative to max(|its own value|, "
+                      "1e-3 x the tensor's largest), sub-filter beliefs after the sample's last step"}
     return {"value": sample_batch * sample_steps / dt, "unit": "trajectory-steps/s", "cores": cores,
             "kind": "port",
             "sample": f"oracle EKF (oracle/), {wl['cls']}, batch {sample_batch} x {sample_steps} steps "

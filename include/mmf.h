@@ -580,11 +580,12 @@ typedef struct MmfPfTrainArgs {
   int32_t compact;           /* ABI 35.  1: the recompute buffers in half the bytes -- `stash` and `dz` are then f16 arrays of
                                 the SAME SHAPES (half the allocation), activations stored as f16 and the pre-activation
                                 gradients as f16 relative to the largest magnitude of their 32-row tile, kept in `dz_scale`; the
-                                weight-gradient products of the f16 values are exact (f16 MFMA, fp32 accumulate).  The data path of the
-                                backward (d_states, the masks, the recursion's gradients) is untouched: only the
-                                parameter gradients see the rounding (2^-11 relative per stored element, measured
-                                <= 1e-3 of the gradient norm -- tests/test_gpu_training.py).  0: fp32 buffers (bit-identical
-                                to ABI 34) */
+                                weight-gradient products of the f16 values are exact (f16 MFMA, fp32 accumulate).  With
+                                `compact` ALONE the data path of the backward (d_states, the masks, the recursion's
+                                gradients) is untouched: only the parameter gradients see the rounding (2^-11 relative per
+                                stored element, measured <= 1e-3 of the gradient norm -- tests/test_gpu_training.py).
+                                (`backward_f16x3` below additionally moves the DATA path to three-product f16 arithmetic:
+                                see there.)  0: fp32 buffers (bit-identical to ABI 34) */
   float* dz_scale;           /* compact: scratch (max(NLd, NLm) + 1, chunk_traj M); else unused */
   int32_t recompute_f16x3;   /* ABI 36.  backward, with compact = 1 and precision = MMF_PREC_F16X3: the recompute of a step's
                                 activations runs on `packed` (the forward pass's f16x3 blob) with the forward pass's own
@@ -594,7 +595,10 @@ typedef struct MmfPfTrainArgs {
                                 the transposed layers and the backward data path multiplies on the f16 MFMA with three
                                 products per product; each ROW of a layer's input is scaled by the power of two that
                                 brings its largest magnitude to [2^7, 2^8) and its result scaled back (exact: the backward
-                                is linear in the gradients and rows do not mix).  0: exact fp32 products on an MMF_PREC_F32 blob */
+                                is linear in the gradients and rows do not mix).  This changes the numerics of d_states and of
+                                every gradient that flows to earlier steps / the per-trajectory networks: 22 bits per element
+                                down to 2^-14 of its row's largest magnitude (measured vs the exact-fp32 backward: 1.6e-6
+                                overall, <= 5.5e-5 in the worst row).  0: exact fp32 products on an MMF_PREC_F32 blob */
   int32_t fused;             /* ABI 37.  backward, with compact = recompute_f16x3 = backward_f16x3 = 1: every network's recompute,
                                 backward data path and weight gradients run as ONE kernel per network call
                                 (mmf_particle_net_train_fused: layer inputs and pre-activation gradients never reach HBM);

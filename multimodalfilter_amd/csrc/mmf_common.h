@@ -16,6 +16,7 @@
 // the persistent small-problem step loop (pf_persistent.inc, compiled with particle_net.hip); reached through
 // mmf_pf_forward_loop when MmfPfLoopArgs.persistent is set
 int mmf_internal_pf_persistent(const MmfPfLoopArgs* args, void* stream);
+#define MMF_INTERNAL_NOT_RESIDENT (-1000)  /* its grid would not be co-resident on this device: take the launch path */
 
 // COMPACT recompute buffers of the native training recursion (particle_net_train.inc; MmfPfTrainArgs.compact)
 int mmf_internal_train_forward_h(const float* packed, int precision, int n_res, int kind, const float* states, const float* traj_bias,

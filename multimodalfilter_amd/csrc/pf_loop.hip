@@ -172,7 +172,16 @@ int run_as_graph(hipStream_t hs, F&& enqueue) {
 }  // namespace
 
 extern "C" int mmf_pf_forward_loop(const MmfPfLoopArgs* a, void* stream) {
-  if (a && a->persistent) return mmf_internal_pf_persistent(a, stream);  // ONE launch for all T steps (small problems)
+  MmfPfLoopArgs launches;
+  if (a && a->persistent) {  // ONE launch for all T steps (small problems)
+    const int rc = mmf_internal_pf_persistent(a, stream);
+    if (rc != MMF_INTERNAL_NOT_RESIDENT) return rc;
+    // this device cannot hold the persistent grid (a partition, or fewer CUs than planned for): the loop of launches
+    // computes the same bits
+    launches = *a;
+    launches.persistent = 0;
+    a = &launches;
+  }
   if (a && a->use_graph && !a->events)
     return run_as_graph(static_cast<hipStream_t>(stream), [&](void* cs) { return pf_enqueue_steps(a, cs, false); });
   return pf_enqueue_steps(a, stream, true);

@@ -235,27 +235,36 @@ def check_range(device):
             "filter steps are invalid; set MMF_PRECISION=f32 / engine.set_default_precision('f32')")
 
 
-_CHECK_DEPTH = 0  # > 0 while a checked forward_loop / forward is running: inner calls leave the check to it
+import threading
+
+_CHECK = threading.local()  # .depth[device]: > 0 while a checked forward_loop / forward is running ON THIS THREAD for that device
 
 
-def _checked(fn):
+def _checked(fn, *, step: bool):
     import functools
 
     @functools.wraps(fn)
     def wrapper(self, *args, **kwargs):
-        global _CHECK_DEPTH
         dev = None
         for p in self.parameters():
             dev = p.device
             break
-        if _CHECK_DEPTH > 0 or dev is None or dev.type != "cuda":
+        # a bare training step runs the differentiable path (torch ops / exact-fp32 K6 kernels): no launch of it
+        # writes the f16x3 flag, so there is nothing to clear or to read back (one blocking .item() per step otherwise)
+        if dev is None or dev.type != "cuda" or (step and use_autograd(self)):
+            return fn(self, *args, **kwargs)
+        depth = getattr(_CHECK, "depth", None)
+        if depth is None:
+            depth = _CHECK.depth = {}
+        key = str(dev)
+        if depth.get(key, 0) > 0:  # an enclosing checked call on this thread and device owns the check
             return fn(self, *args, **kwargs)
         clear_range(dev)
-        _CHECK_DEPTH += 1
+        depth[key] = 1
         try:
             out = fn(self, *args, **kwargs)
         finally:
-            _CHECK_DEPTH -= 1
+            depth[key] = 0
         check_range(dev)
         return out
 
@@ -266,15 +275,16 @@ def checked_loop(fn):
     """Decorator for ``forward_loop`` methods: the f16x3 range flag (raised by K2 / K4 launches whose
     operands left the f16 range) is cleared on entry and checked on the way out, so a loop reports
     its own launches -- one 4-byte device->host read per loop."""
-    return _checked(fn)
+    return _checked(fn, step=False)
 
 
 def checked_step(fn):
     """Decorator for a filter's ``forward``: a bare step (no ``forward_loop`` around it) checks the range
     flag itself, so an out-of-range f16x3 operand raises at the step that produced it instead of handing
     saturated numbers to the caller -- one 4-byte device->host read per step of a caller-driven loop;
-    steps inside a checked ``forward_loop`` (or inside another filter's step) leave the check to it."""
-    return _checked(fn)
+    steps inside a checked ``forward_loop`` (or inside another filter's step) on the same thread and device leave
+    the check to it; a training step on the differentiable path launches nothing that writes the flag and skips it."""
+    return _checked(fn, step=True)
 
 
 def clear_range(device):
@@ -507,9 +517,15 @@ def _assemble_param_grads(net: PackedParticleNet, params, dW, db, g_first, g_hea
 TRAIN_CHUNK_ROWS = int(os.environ.get("MMF_TRAIN_CHUNK_ROWS", "262144"))
 # MmfPfTrainArgs.compact: the recompute buffers of the backward in half the bytes (activations as f16, pre-activation
 # gradients as f16 relative to the largest magnitude of their 32-row tile + one fp32 scale per row and layer).  They are the
-# recursion's HBM traffic (written once, read once by the weight-gradient pass).  Only the PARAMETER gradients see the
-# rounding (the backward's data path -- d_states, the recursion's gradients -- is computed in registers from fp32):
-# tests/test_gpu_training.py bounds it.  MMF_TRAIN_COMPACT_STASH=0 restores the fp32 buffers (bit-identical to round 3).
+# recursion's HBM traffic (written once, read once by the weight-gradient pass).  With this switch ALONE only the PARAMETER
+# gradients see the rounding (the backward's data path -- d_states, the recursion's gradients -- is computed in registers
+# from fp32); tests/test_gpu_training.py bounds it.  NOTE the defaults below: TRAIN_RECOMPUTE_F16X3 and
+# TRAIN_BACKWARD_F16X3 are ON as well, and with them the data path (d_states, every gradient that flows to earlier steps
+# and to the per-trajectory networks) runs in the forward pass's three-product f16 arithmetic with an exact power-of-two
+# scale PER ROW (an element keeps 22 bits down to 2^-14 of its own particle's largest gradient; measured against the
+# exact-fp32 backward: 1.6e-6 overall, <= 5.5e-5 in the worst row -- scripts/debug/bwd_h_check.py).  The reference trains
+# in fp32: MMF_TRAIN_BACKWARD_F16X3=0 (or MMF_PRECISION=f32) restores exact fp32 products on the data path.
+# MMF_TRAIN_COMPACT_STASH=0 restores the fp32 buffers (bit-identical to round 3).
 TRAIN_COMPACT_STASH = os.environ.get("MMF_TRAIN_COMPACT_STASH", "1") != "0"
 # MmfPfTrainArgs.recompute_f16x3 (with the compact buffers, when the engine's mode is f16x3): the backward recomputes a
 # step's activations with the arithmetic the forward pass used (the inference kernels' three f16 products per product)

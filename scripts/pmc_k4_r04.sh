@@ -31,7 +31,7 @@ for f in glob.glob(f"{src}/**/*counter_collection.csv", recursive=True):
         for k, pat in want.items():
             if pat in r["Kernel_Name"]:
                 cnt[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {"command": "scripts/pmc_k4_r04.sh: rocprofv3 --pmc <8 counters> --kernel-trace -- python3 bench.py --steps 6 --warmup 2 (lean), two passes",
+out = {"command": "scripts/pmc_k4_r04.sh: rocprofv3 --pmc <8 counters> --kernel-trace -- python3 bench.py --workload door_ekf --steps 16 --warmup 0 --preroll-seconds 0 (lean), two passes",
        "unit": "counter value per launch (sum over the chip), averaged over the launches of the pass; us = kernel-trace duration under the counters",
        "kernels": {}}
 for k in want:

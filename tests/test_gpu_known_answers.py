@@ -25,7 +25,7 @@ from oracle import models as om
 from oracle import tf as otf
 from oracle.tf.base import ReplayNoise as OReplay
 
-REL_TOL = 1e-4
+from _tol import REL_TOL, rel_err
 
 
 def _dev():
@@ -125,12 +125,12 @@ def test_engine_ekf_equals_kalman_closed_form(d, loop):
     scale = max(1.0, float(want_o.abs().max()))
     assert float((est - want_o).abs().max()) / scale < REL_TOL
     cov = f._belief_covariance.cpu()
-    assert float((cov - o._belief_covariance).abs().max()) / max(1.0, float(o._belief_covariance.abs().max())) < REL_TOL
+    assert rel_err(cov, o._belief_covariance) < REL_TOL, rel_err(cov, o._belief_covariance)
     for n in range(N):
         want = _kalman_closed_form(A, B, L, Rt, mu0[n], 0.1 * torch.eye(d), us[:, n], zs[:, n])
         for t in range(T):
             assert float((est[t, n].double() - want[t][0]).abs().max()) / scale < REL_TOL, (n, t)
-        assert float((cov[n].double() - want[-1][1]).abs().max()) < REL_TOL
+        assert rel_err(cov[n], want[-1][1]) < REL_TOL, (n, rel_err(cov[n], want[-1][1]))
 
 
 @pytest.mark.parametrize("mode", ["systematic", "multinomial"])
@@ -754,7 +754,7 @@ def test_engine_unscented_filter_known_answers(strategy):
         want = _kalman_closed_form(A, B, L, Rt, mu0[n], 0.1 * torch.eye(d), us[:, n], zs[:, n])
         for t in range(T):
             assert float((est[t, n].double() - want[t][0]).abs().max()) < REL_TOL * max(1.0, float(want[t][0].abs().max())), (n, t)
-        assert float((cov[n].double() - want[-1][1]).abs().max()) < REL_TOL
+        assert rel_err(cov[n], want[-1][1]) < REL_TOL, (n, rel_err(cov[n], want[-1][1]))
 
     # (b)
     task = om.TASKS["door"]
@@ -784,7 +784,7 @@ def test_engine_unscented_filter_known_answers(strategy):
     cov_loop = e._belief_covariance.clone()
     scale = max(1.0, float(want.abs().max()))
     assert float((loop.cpu() - want).abs().max()) / scale < REL_TOL
-    assert float((cov_loop.cpu() - o._belief_covariance).abs().max()) / max(1.0, float(o._belief_covariance.abs().max())) < REL_TOL
+    assert rel_err(cov_loop, o._belief_covariance) < REL_TOL, rel_err(cov_loop, o._belief_covariance)
     e.initialize_beliefs(mean=x0.to(dev), covariance=cov0.to(dev))
     step = torch.stack([e(observations={k: v[t] for k, v in odev.items()}, controls=ctrl[t].to(dev)) for t in range(T)])
     assert torch.equal(step, loop) and torch.equal(e._belief_covariance, cov_loop)
