@@ -52,17 +52,16 @@ PREC_CODE = {"f32": 0, "f16x3": 1}
 
 def k2_kernel_name(d: int, prec: str) -> str:
     """<D, NRES, KIND=measure, CT=2 (64-particle tiles), PREC, WPS=2 waves/SIMD, PIPE (f16x3: the two 32-particle
-    halves run half a layer apart), ROWPIPE (A/B: column tiles in lock step, pipelined on row tiles)>"""
-    variant = os.environ.get("MMF_K2_VARIANT", "0")
-    pipe = "true" if prec == "f16x3" and variant == "0" else "false"
-    rowpipe = "true" if prec == "f16x3" and variant == "4" else "false"
-    return f"particle_net_kernel<{d}, 2, 1, 2, {PREC_CODE[prec]}, 2, {pipe}, {rowpipe}>"
+    halves run half a layer apart)>"""
+    pipe = "true" if prec == "f16x3" else "false"
+    return f"particle_net_kernel<{d}, 2, 1, 2, {PREC_CODE[prec]}, 2, {pipe}>"
 
 
 def k2_kernel_key(d: int, prec: str) -> str:
-    """Prefix that finds the kernel in this round's AND earlier rounds' profile files (r01-r03 printed seven
-    template arguments)."""
-    return k2_kernel_name(d, prec).rsplit(",", 1)[0]
+    """Prefix that finds the kernel in this round's AND earlier rounds' profile files (r01-r03 printed seven template
+    arguments, r04 eight, r05 seven again)."""
+    return ", ".join(k2_kernel_name(d, prec).split(", ")[:6])
+
 
 WORKLOADS = {
     "door_pf": dict(task="door", cls="DoorCrossmodalParticleFilter", kind="pf", batch=256, particles=4096,
@@ -1028,8 +1027,6 @@ def main():
         r = {"kernel": k2_kernel_name(d, prec) + " (measurement network)", "bound": "mfma", "achieved": ach,
              "peak": MFMA_PEAK[prec], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK[prec],
              "traffic": pmc_traffic(k2_kernel_key(d, prec)) if default_shape else None}
-        if dom["launches"] and engine.MEASURE_SEQ:
-            r["launch"] = "one launch = the filter's two measurement networks back to back in every workgroup (mmf_pf_measure_seq)"
         if prec == "f16x3":
             r["note"] = ("achieved counts ALGORITHMIC fp32 FLOPs; the kernel executes 3 f16 MFMA "
                          "products per algorithmic product (executed-MFMA fraction = 3 x frac)")

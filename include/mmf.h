@@ -187,16 +187,6 @@ int mmf_pf_measure(const float* packed, int n_res, int precision, const float* s
                    const float* modality_logw, int logw_stride, float* loglik, int combine,
                    int32_t* range_flag, int N, int M, int d, void* stream);
 
-/* The K enabled modalities of a crossmodal filter in ONE launch: the same arithmetic as K calls of
- * mmf_pf_measure with combine = 0, 1, 1, ... (bit-identical log-likelihoods), every workgroup running the K
- * networks one after the other on its own tiles -- no launch boundary (drained chip + launch gap) between the
- * modalities.  packed / traj_bias / modality_logw: HOST arrays of K device pointers (modality_logw entries or
- * the array itself may be null); 1 <= K <= MMF_LOOP_MAX_MEAS.
- */
-int mmf_pf_measure_seq(const float* const* packed, int n_res, int precision, const float* states,
-                       const float* const* traj_bias, const float* const* modality_logw, int logw_stride,
-                       float* loglik, int32_t* range_flag, int K, int N, int M, int d, void* stream);
-
 /* Forward-mode Jacobian of the dynamics network (replaces torchfilter's default autograd
  * DynamicsModel.jacobian: batch replicated d times + one autograd.grad):
  *  states_in (N, d), traj_bias (N, 64) -> states_out (N, d), jac (N, d, d), jac[n][i][j] = d x'_i / d x_j
@@ -352,7 +342,7 @@ int mmf_conv_weight_grads(const float* g, const float* act, float* partial, floa
 /* ---------------------------------------------------------------- particle-filter step loop
  * Replaces the Python loop of torchfilter's Filter.forward_loop (call site
  * crossmodal/eval_helpers.py:139-142) for the fused models: one call enqueues the kernels of
- * all T steps (mmf_pf_dynamics, mmf_pf_measure per modality or one mmf_pf_measure_seq, mmf_pf_reweight_resample) on
+ * all T steps (mmf_pf_dynamics, mmf_pf_measure per modality, mmf_pf_reweight_resample) on
  * `stream`.  Per-trajectory terms and randomness are indexed by step: row block t of every
  * (T*N, ...) array belongs to step t.
  */
@@ -396,10 +386,6 @@ typedef struct MmfPfLoopArgs {
   int32_t use_graph;         /* != 0 (and events == null): capture the loop's launches on `stream` into a   */
                              /* hipGraph and launch that instead (A/B switch; the executable graph is kept  */
                              /* by the library until its launch has completed -- mmf_loop_graphs_release)   */
-  int32_t measure_seq;       /* != 0 and n_meas > 1: the step's modalities as ONE mmf_pf_measure_seq launch (A/B  */
-                             /* switch: measured slower than one launch per modality, the host leaves it off);    */
-                             /* (bit-identical log-likelihoods); `events` then holds 2*3 entries per sampled  */
-                             /* step: [dynamics, measure (all modalities), resample]                          */
   float soft_alpha;          /* 0 or 1: plain resampling; 0 < alpha < 1 (resample_mode != 0): torchfilter's soft      */
                              /* resampling (mmf_pf_reweight_resample_soft) -- the survivors carry importance weights, */
                              /* so every step reads and writes the log-weights                                        */

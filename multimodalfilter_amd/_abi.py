@@ -66,7 +66,7 @@ class MmfPfLoopArgs(Structure):
                 ("final_location", POINTER(c_int32)), ("events", POINTER(c_void_p)),
                 ("event_stride", c_int32), ("loglik_steps", _FP), ("indices_steps", _FP),
                 ("noise_seed", ctypes.c_uint64), ("noise_step0", ctypes.c_uint32), ("noise_traj0", ctypes.c_uint32),
-                ("noise_mode", c_int32), ("use_graph", c_int32), ("measure_seq", c_int32),
+                ("noise_mode", c_int32), ("use_graph", c_int32),
                 ("soft_alpha", ctypes.c_float), ("estimate_argmax", c_int32), ("estimate_scratch", _FP),
                 ("persistent", c_int32), ("n_sync_words", c_int32), ("sync_words", _FP)]
 
@@ -123,7 +123,6 @@ SIGNATURES = {
     "mmf_pack_particle_net": (c_int, [POINTER(MmfParticleNetDesc), _FP, c_int, c_void_p]),
     "mmf_pf_dynamics": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_measure": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, c_int, _FP, c_int, _FP, c_int, c_int, c_int, c_void_p]),
-    "mmf_pf_measure_seq": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, c_int, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_dynamics_jacobian": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_ekf_step": (c_int, [_FP] * 10 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_ekf_step_gated": (c_int, [_FP] * 10 + [c_int, c_int, c_int, c_int, c_int, _FP, c_void_p]),
@@ -298,17 +297,6 @@ def pf_measure(packed, n_res, precision, states, traj_bias, modality_logw, logw_
                                      ptr(modality_logw), logw_stride, ptr(loglik), int(combine),
                                      ptr(range_flag, dtype=torch.int32), N, M, d,
                                      stream_of(states)), "mmf_pf_measure")
-
-
-def pf_measure_seq(packed, n_res, precision, states, traj_bias, modality_logw, logw_stride, loglik, range_flag, N, M, d):
-    """``packed`` / ``traj_bias`` / ``modality_logw``: K-lists of device tensors (``modality_logw`` entries may be ``None``):
-    the K modalities in one launch, log-likelihoods bit-identical to K ``pf_measure`` calls with combine 0, 1, 1.."""
-    K = len(packed)
-    arr = lambda ts: (c_void_p * K)(*[ptr(t) for t in ts])
-    with _on(states):
-        _check(load().mmf_pf_measure_seq(arr(packed), n_res, precision, ptr(states), arr(traj_bias), arr(modality_logw),
-                                         logw_stride, ptr(loglik), ptr(range_flag, dtype=torch.int32), K, N, M, d,
-                                         stream_of(states)), "mmf_pf_measure_seq")
 
 
 def dynamics_jacobian(packed, n_res, precision, states_in, traj_bias, states_out, jac, range_flag, N, d):

@@ -15,7 +15,7 @@
 //                   conv 32->16, and conv 16->8 as three fused persistent kernels with the activations
 //                   in LDS as split f16 planes; then the split-K linear tail below.
 //   MMF_PREC_BF16   the first two of those kernels with single bf16 products.
-// The per-layer f16x3 kernels (conv_f16x3_kernel<32,...>) remain for A/B runs (MMF_K4_UNFUSED=1).
+// The per-layer f16x3 kernels (conv_f16x3_kernel<32,...>) remain as the TRAINING forward (every activation kept).
 // The 8192->64 linear is a split-K MFMA GEMM followed by a one-wave-per-image tail (bias, ReLU,
 // ResLinear 64).  Rooflines and measurements: DESIGN.md section 3, K4.
 #include <hip/hip_fp16.h>
@@ -1044,38 +1044,17 @@ extern "C" int mmf_image_encoder(const float* const* packed, int n_nets, const f
   }
   c.N = N;
   int rc;
-  if (precision == MMF_PREC_F16X3 && (bf16 || !getenv("MMF_K4_UNFUSED"))) {
-    // fused path (image_encoder_fused.inc): image -> B (bufA), B -> D (bufB), D -> E (bufC)
+  if (precision == MMF_PREC_F16X3) {
+    // fused path (image_encoder_fused.inc): image -> B (bufA), B -> E (bufC): D never reaches HBM
     FusedArgs fa{};
     for (int i = 0; i < n_nets; ++i) fa.packed[i] = packed[i];
     fa.images = images; fa.N = N; fa.range_flag = range_flag;
     fa.out = bufA;
-    const FusedFlavour fl = fused_flavour();  // once per call: both launches and the conv4 decision below share it
-    if ((rc = launch_fused(fa, n_nets, 0, bf16, fl, s))) return rc;
+    if ((rc = launch_fused(fa, n_nets, 0, bf16, s))) return rc;
     fa.bin = bufA; fa.out = bufB;
-    fa.out_e = fl.fuse_conv4 ? bufC : nullptr;  // conv 16->8 in the same kernel: D never reaches HBM
-    if ((rc = launch_fused(fa, n_nets, 1, bf16, fl, s))) return rc;
-    if (!fa.out_e) {
-      Conv4Args c4{};
-      for (int i = 0; i < n_nets; ++i) c4.packed[i] = packed[i];
-      c4.N = N; c4.din = reinterpret_cast<const unsigned char*>(bufB); c4.out = bufC;
-      if ((rc = launch_conv4(c4, n_nets, s))) return rc;
-    }
+    fa.out_e = bufC;
+    if ((rc = launch_fused(fa, n_nets, 1, bf16, s))) return rc;
     bufB = bufC;  // the linear tail reads E
-  } else if (precision == MMF_PREC_F16X3) {
-    c.in = images; c.in_net_stride = 0; c.skip = nullptr; c.out = bufA; c.woff = L.w1; c.boff = L.b1;
-    if ((rc = launch_conv<1, 32, 5, true, false>(c, n_nets, s))) return rc;
-    ConvHArgs hcv{};
-    for (int i = 0; i < n_nets; ++i) hcv.packed[i] = packed[i];
-    hcv.N = N; hcv.range_flag = range_flag;
-    hcv.in = bufA; hcv.skip = nullptr; hcv.out = bufB; hcv.hoff = L.h2a; hcv.boff = L.b2a;
-    if ((rc = launch_conv_h<32, 32, true, false>(hcv, n_nets, s))) return rc;
-    hcv.in = bufB; hcv.skip = bufA; hcv.out = bufC; hcv.hoff = L.h2b; hcv.boff = L.b2b;
-    if ((rc = launch_conv_h<32, 32, true, true>(hcv, n_nets, s))) return rc;
-    hcv.in = bufC; hcv.skip = nullptr; hcv.out = bufA; hcv.hoff = L.h3; hcv.boff = L.b3;
-    if ((rc = launch_conv_h<32, 16, true, false>(hcv, n_nets, s))) return rc;
-    hcv.in = bufA; hcv.out = bufB; hcv.hoff = L.h4; hcv.boff = L.b4;
-    if ((rc = launch_conv_h<16, 8, false, false>(hcv, n_nets, s))) return rc;
   } else {
   // conv 1 -> 32, k5, ReLU                      images -> A
   c.in = images; c.in_net_stride = 0; c.skip = nullptr; c.out = bufA; c.woff = L.w1; c.boff = L.b1;

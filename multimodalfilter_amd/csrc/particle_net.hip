@@ -291,27 +291,15 @@ struct NetArgs {
 };
 
 // blockIdx.y selects one of up to MMF_LOOP_MAX_MEAS independent problems of the same shape (the
-// sub-filters of a fused EKF evaluate their Jacobians in one launch).  `seq` > 1 instead runs that many
-// problems ONE AFTER THE OTHER in every workgroup -- the modalities of a crossmodal particle filter, whose
-// second network combines its log-likelihood with the first's (logsumexp in the epilogue): the tile -> wave
-// mapping is the same in every pass, so a lane re-reads what it wrote itself, and the launch boundary
-// between the two networks (a drained chip, a launch gap) disappears.
+// sub-filters of a fused EKF evaluate their Jacobians in one launch).
 struct NetArgsMulti {
   NetArgs a[MMF_LOOP_MAX_MEAS];
-  int seq = 1;  // problems a workgroup runs back to back (blockIdx.y covers the rest): see mmf_pf_measure_seq
 };
 
-template <int D, int NRES, int KIND, int CT, int PREC, int WPS, bool PIPE = false, bool ROWPIPE = false>
+template <int D, int NRES, int KIND, int CT, int PREC, int WPS, bool PIPE = false>
 __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMulti multi) {
-#pragma unroll 1
-  for (int pass = 0; pass < multi.seq; ++pass) {
-  const NetArgs a = multi.a[blockIdx.y * multi.seq + pass];
-  if (pass) {
-    __threadfence();   // this lane's log-likelihoods of the previous pass, before it reads them back
-    __syncthreads();   // every wave is done with the previous network's weights in LDS
-  }
+  const NetArgs a = multi.a[blockIdx.y];
   static_assert(!PIPE || (CT == 2 && PREC == MMF_PREC_F16X3 && KIND != kJacobian), "pipelined halves: f16x3, 64-particle tiles");
-  static_assert(!ROWPIPE || (!PIPE && PREC == MMF_PREC_F16X3 && KIND != kJacobian), "row-tile pipeline: f16x3");
   constexpr int kThreads = WPS * 256;           // WPS waves per SIMD, one workgroup per CU (LDS)
   constexpr int kWavesPerBlock = kThreads / MMF_WAVE;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -407,7 +395,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
           X.v[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, bcur[s][c], X.v[t][c], 0, 0, 0);
       }
     }
-    if constexpr (!ROWPIPE) relu<CT, JAC>(X, primal);  // (the row-tile pipeline's prologue applies it)
+    relu<CT, JAC>(X, primal);
 
     SplitAct<F16 ? CT : 0> SP;
     short2v amax = {0, 0};  // f16x3: largest hi halves handed to the MFMAs in this tile
@@ -492,22 +480,6 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
         __builtin_amdgcn_sched_barrier(0);
       });
       relu_half<1>(H);
-    } else if constexpr (ROWPIPE) {
-      // column tiles in lock step (one LDS read per weight fragment for all of them), pipelined on output ROW tiles
-      rowpipe_net_f16<CT, NRES, KIND>(lds, X, H, SP, [&](Act<CT>& acc) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int c = 0; c < CT; ++c) {
-            const float* tb = a.traj_bias + static_cast<size_t>(col_traj[c]) * kUnits + 32 * t + 4 * h;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const f32x4 b = *reinterpret_cast<const f32x4*>(tb + 8 * g);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) acc.v[t][c][4 * g + e] = b[e];
-            }
-          }
-      }, lane, neg_one, amax);
     } else {
     // ---- encoder residual block (layers 0, 1)
     if constexpr (F16) res_block_f16<CT, false, JAC>(lds, NRES, 0, X, H, SP, lane, neg_one, amax, primal);
@@ -678,10 +650,9 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
       }
     }
   }
-  }  // pass
 }
 
-template <int D, int NRES, int KIND, int PREC, int CT, int WPS, bool PIPE = false, bool ROWPIPE = false>
+template <int D, int NRES, int KIND, int PREC, int CT, int WPS, bool PIPE = false>
 int launch_variant(const NetArgsMulti& m, int count, hipStream_t s) {
   const NetArgs& a = m.a[0];
   const size_t lds = static_cast<size_t>(blob_floats(NRES)) * sizeof(float);
@@ -690,7 +661,7 @@ int launch_variant(const NetArgsMulti& m, int count, hipStream_t s) {
   int grid = (ntiles + waves - 1) / waves;
   if (grid > 256) grid = 256;
   if (grid < 1) grid = 1;
-  auto k = particle_net_kernel<D, NRES, KIND, CT, PREC, WPS, PIPE, ROWPIPE>;
+  auto k = particle_net_kernel<D, NRES, KIND, CT, PREC, WPS, PIPE>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   if (e != hipSuccess) return static_cast<int>(e);
@@ -704,13 +675,10 @@ int launch_ct(const NetArgsMulti& m, int count, hipStream_t s) {
   const NetArgs& a = m.a[0];
   // small problems: 32-particle tiles spread over more waves; large: 64-particle tiles
   const bool big = a.R >= 256 * 8 * 64;
-  static const int variant = [] { const char* v = getenv("MMF_K2_VARIANT"); return v ? atoi(v) : 0; }();
+  // f16x3: the two 32-particle halves of a 64-particle tile half a layer apart (PIPE).  The organisations that were
+  // measured and lost -- 32-particle tiles at 2 or 3 waves per SIMD, the unpipelined 64-particle tile, the row-tile
+  // pipeline (bit-identical, 1-6 % slower) -- are gone from the product; profiles/r02 .. r04 keep their A/B files.
   if constexpr (PREC == MMF_PREC_F16X3 && KIND != kJacobian) {
-    if (big && variant == 1) return launch_variant<D, NRES, KIND, PREC, 1, 3>(m, count, s);  // 32-particle tiles, 3 waves/SIMD
-    if (big && variant == 2) return launch_variant<D, NRES, KIND, PREC, 1, 2>(m, count, s);
-    if (big && variant == 3) return launch_variant<D, NRES, KIND, PREC, 2, 2, false>(m, count, s);  // unpipelined
-    if (big && variant == 4) return launch_variant<D, NRES, KIND, PREC, 2, 2, false, true>(m, count, s);  // row-tile pipeline: half the LDS fragment reads
-    if (!big && variant == 5) return launch_variant<D, NRES, KIND, PREC, 1, 2, false, true>(m, count, s);  // small problems, row-tile pipeline
     if (big) return launch_variant<D, NRES, KIND, PREC, 2, 2, true>(m, count, s);
   }
   if (big) return launch_variant<D, NRES, KIND, PREC, 2, 2>(m, count, s);
@@ -850,26 +818,6 @@ extern "C" int mmf_pf_measure(const float* packed, int n_res, int precision, con
   a.logw_stride = logw_stride; a.loglik = loglik; a.combine = combine; a.R = N * M; a.M = M;
   a.range_flag = range_flag;
   return launch<kMeasure>(a, d, n_res, precision, static_cast<hipStream_t>(stream));
-}
-
-extern "C" int mmf_pf_measure_seq(const float* const* packed, int n_res, int precision, const float* states,
-                                  const float* const* traj_bias, const float* const* modality_logw, int logw_stride,
-                                  float* loglik, int* range_flag, int K, int N, int M, int d, void* stream) {
-  if (!packed || !states || !traj_bias || !loglik) return MMF_EINVAL;
-  if (K < 1 || K > MMF_LOOP_MAX_MEAS || N < 0 || M < 1) return MMF_EINVAL;
-  if (static_cast<long long>(N) * M > 0x7fffffffLL / 8) return MMF_ETOOLARGE;
-  if (N == 0) return 0;
-  NetArgsMulti m{};
-  for (int k = 0; k < K; ++k) {
-    if (!packed[k] || !traj_bias[k]) return MMF_EINVAL;
-    NetArgs& a = m.a[k];
-    a.packed = packed[k]; a.states_in = states; a.traj_bias = traj_bias[k];
-    a.mod_logw = modality_logw ? modality_logw[k] : nullptr;
-    a.logw_stride = logw_stride; a.loglik = loglik; a.combine = k > 0; a.R = N * M; a.M = M;
-    a.range_flag = range_flag;
-  }
-  m.seq = K;
-  return launch_multi<kMeasure>(m, 1, d, n_res, precision, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mmf_dynamics_jacobian(const float* packed, int n_res, int precision, const float* states_in,

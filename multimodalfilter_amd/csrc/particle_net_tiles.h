@@ -218,13 +218,9 @@ using half2v = __attribute__((ext_vector_type(2))) _Float16;
 using f32x2v = __attribute__((ext_vector_type(2))) float;
 __device__ __forceinline__ void split_pair(float x0, float x1, float neg_one, unsigned& hi, unsigned& lo) {
   const half2v h = __builtin_convertvector(f32x2v{x0, x1}, half2v);  // v_cvt_pk_f16_f32: round to nearest even
-#ifdef MMF_EXP_NO_SPLIT_LO  // scripts/k2_experiments.sh: what do the 3 residual instructions cost? (wrong results)
-  const half2v l = h;
-#else
   const float r0 = __builtin_fmaf(static_cast<float>(h[0]), neg_one, x0);
   const float r1 = __builtin_fmaf(static_cast<float>(h[1]), neg_one, x1);
   const half2v l = __builtin_convertvector(f32x2v{r0, r1}, half2v);
-#endif
   hi = __builtin_bit_cast(unsigned, h);
   lo = __builtin_bit_cast(unsigned, l);
 }
@@ -360,14 +356,12 @@ __device__ __forceinline__ void split_half(const Act<2>& x, SplitAct<2>& o, floa
         h[p] = hh;
         l[p] = ll;
       }
-#ifndef MMF_EXP_NO_RANGE  // scripts/k2_experiments.sh: what does range tracking cost?
       constexpr unsigned kMask = SIGNED ? 0x7fff7fffu : 0xffffffffu;
       const short2v m01 = __builtin_elementwise_max(__builtin_bit_cast(short2v, h[0] & kMask),
                                                     __builtin_bit_cast(short2v, h[1] & kMask));
       const short2v m23 = __builtin_elementwise_max(__builtin_bit_cast(short2v, h[2] & kMask),
                                                     __builtin_bit_cast(short2v, h[3] & kMask));
       amax = __builtin_elementwise_max(amax, __builtin_elementwise_max(m01, m23));
-#endif
       o.hi[2 * tp + u][C] = __builtin_bit_cast(half8, h);
       o.lo[2 * tp + u][C] = __builtin_bit_cast(half8, l);
     }
@@ -416,9 +410,7 @@ __device__ __forceinline__ void mfma_half(const float* __restrict__ Wl, const fl
       const FragPair nxt = g < 7 ? load_frag(Wl, lane, g + 1) : load_frag(next, lane, 0);
       acc.v[t][C] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.hi, in.hi[s][C], acc.v[t][C], 0, 0, 0);
       acc.v[t][C] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.hi, in.lo[s][C], acc.v[t][C], 0, 0, 0);
-#ifndef MMF_EXP_TWO_PRODUCTS  // scripts/k2_experiments.sh: what does the third MFMA cost?
       acc.v[t][C] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.lo, in.hi[s][C], acc.v[t][C], 0, 0, 0);
-#endif
       cur = nxt;
     }
 }

@@ -27,8 +27,7 @@ static int pf_enqueue_steps(const MmfPfLoopArgs* a, void* stream, bool with_even
   float* lw_cur = a->logw_a;
   float* lw_other = a->logw_b;
   hipStream_t hs = static_cast<hipStream_t>(stream);
-  const bool seq_measure = a->measure_seq != 0 && a->n_meas > 1;
-  int ev = 0;  // optional timing events: [sample][dynamics, measure x n_meas (or one fused launch), resample][start, end]
+  int ev = 0;  // optional timing events: [sample][dynamics, measure x n_meas, resample][start, end]
   const int stride = a->event_stride > 1 ? a->event_stride : 1;
   bool sampled = false;  // an event record costs a barrier packet: long loops sample every stride-th step
   auto mark = [&]() {
@@ -55,18 +54,7 @@ static int pf_enqueue_steps(const MmfPfLoopArgs* a, void* stream, bool with_even
     // parity certificates keep every step's log-likelihoods and ancestors (null on the timed path)
     float* ll = a->loglik_steps ? a->loglik_steps + t * nm : a->loglik;
     int32_t* anc = a->indices_steps ? a->indices_steps + t * nm : nullptr;
-    if (seq_measure) {  // all modalities in one launch (mmf_pf_measure_seq): same arithmetic, no launch boundary between them
-      const float *bias[MMF_LOOP_MAX_MEAS], *lw[MMF_LOOP_MAX_MEAS];
-      for (int k = 0; k < a->n_meas; ++k) {
-        bias[k] = a->meas_bias[k] + t * row * MMF_UNITS;
-        lw[k] = a->meas_logw[k] ? a->meas_logw[k] + t * row * a->logw_stride : nullptr;
-      }
-      if ((rc = mark())) return rc;
-      rc = mmf_pf_measure_seq(a->meas_packed, a->n_res_meas, a->precision, other, bias, lw, a->logw_stride, ll,
-                              a->range_flag, a->n_meas, a->N, a->M, a->d, stream);
-      if (rc) return rc;
-      if ((rc = mark())) return rc;
-    } else {
+    {
       for (int k = 0; k < a->n_meas; ++k) {
         const float* lw = a->meas_logw[k] ? a->meas_logw[k] + t * row * a->logw_stride : nullptr;
         if ((rc = mark())) return rc;

@@ -138,13 +138,6 @@ def image_encoder_precision_code() -> int:
 # hipGraph replay of the native particle-filter step loop (A/B switch, off by default: at the reference's
 # evaluation size the launches enqueued from C already keep the GPU 93 % busy -- DESIGN.md, T3)
 LOOP_GRAPH = os.environ.get("MMF_LOOP_GRAPH", "0") not in ("", "0")
-# The modalities of a crossmodal particle filter as ONE launch per step (mmf_pf_measure_seq: every workgroup
-# runs the networks one after the other on its own tiles; bit-identical to one launch per modality --
-# tests/test_gpu_kernels.py, tests/test_gpu_models.py).  OFF by default: measured at 256 x 4096 the fused launch
-# takes 0.297 ms against 2 x 0.140 (step 0.589 vs 0.568 ms), at 32 x 300 the step 0.0611 vs 0.0591 ms -- the
-# workgroup-wide barrier between the two networks (every wave waits for the slowest before the weights are
-# re-staged) costs more than the launch boundary it removes.
-MEASURE_SEQ = os.environ.get("MMF_MEASURE_SEQ", "0") not in ("", "0")
 # Small particle-filter loops (mmf_pf_persistent_plan > 0: e.g. the reference's 32 x 300 evaluation) as ONE persistent
 # launch per forward_loop: role-specialised workgroups keep one network's weights in LDS for all T steps and hand the
 # particles over through L2 (csrc/pf_persistent.inc); bit-identical to the launch-per-step loop.  "0": A/B, off.

@@ -338,8 +338,6 @@ class ParticleFilter(base.Filter):
             est_scratch = torch.empty((N, d), dtype=torch.float32, device=dev)
             keep.append(est_scratch)
             a.estimate_argmax, a.estimate_scratch = 1, P(est_scratch)
-        fused_measure = engine.MEASURE_SEQ and len(nets) > 1
-        a.measure_seq = int(fused_measure)
         timer = engine.kernel_timer()
         if (engine.PF_PERSISTENT and mode == 1 and timer is None and not self.record_indices and not engine.LOOP_GRAPH
                 and a.soft_alpha == 0.0 and not a.estimate_argmax and d in (2, 3)
@@ -355,7 +353,7 @@ class ParticleFilter(base.Filter):
             # the loop is re-run from this copy of the belief as a loop of launches -- see below
             belief_backup = (states_a.clone(), logw_a.clone())
         events = None
-        names = ["particle_net_dynamics"] + ["particle_net_measure"] * (1 if fused_measure else len(nets)) + ["pf_reweight_resample"]
+        names = ["particle_net_dynamics"] + ["particle_net_measure"] * len(nets) + ["pf_reweight_resample"]
         stride = 1
         if timer is not None:
             stride = max(1, int(timer.loop_stride))
@@ -374,7 +372,7 @@ class ParticleFilter(base.Filter):
             work = [(dflops, R * 4.0 * 3 * d)]
             mwork = [(2.0 * R * engine.particle_net_macs(d, net.n_res, net.n_out), R * 4.0 * (d + 1 + (k > 0)))
                      for k, (net, _, _) in enumerate(nets)]
-            work += [(sum(w[0] for w in mwork), sum(w[1] for w in mwork))] if fused_measure else mwork
+            work += mwork
             work.append((0.0, R * 4.0 * (2 + 2 * d)))
             timer.add_loop_records(names, work, events)
         self.particle_states = states_b if loc & 1 else states_a

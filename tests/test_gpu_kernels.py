@@ -713,81 +713,6 @@ def test_k2_full_size_cross_checks(task):
         assert _rel_err(a.cpu(), b.cpu()) < 1e-4
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"], indirect=True)
-@pytest.mark.parametrize("task", ["door", "push"])
-@pytest.mark.parametrize("N,M", [(1, 1), (3, 5), (4, 300), (2, 4096), (33, 4001), (256, 1024)])
-def test_k2_measurement_networks_in_one_launch_equal_one_launch_each(task, N, M, precision):
-    """``mmf_pf_measure_seq`` (every workgroup runs the crossmodal filter's measurement networks one after the
-    other on its own tiles, the second combining with what the first wrote) against one ``mmf_pf_measure``
-    launch per modality with combine = 0, 1: the fused log-likelihoods are the SAME BITS, in both arithmetic
-    modes, for ragged tile counts and for launches wider than the chip."""
-    import multimodalfilter_amd as mmf
-    from multimodalfilter_amd import _abi, engine
-
-    dev = _cuda()
-    spec = om.TASKS[task]
-    d = spec.state_dim
-    g = torch.Generator().manual_seed(N * 17 + M)
-    x = torch.randn((N, M, d), generator=g).to(dev)
-    obs = {"image": torch.randn((N, 32, 32), generator=g).clamp(-1, 1).to(dev),
-           "gripper_pos": torch.randn((N, 3), generator=g).to(dev),
-           "gripper_sensors": torch.randn((N, 7), generator=g).to(dev)}
-    torch.manual_seed(5)
-    models = mmf.door_models if task == "door" else mmf.push_models
-    f = getattr(models, ("Door" if task == "door" else "Push") + "CrossmodalParticleFilter")().to(dev).eval()
-    meas = f.measurement_model
-    with torch.no_grad():
-        ctx = meas.encode_observations(obs)
-        nets, stride = meas.fused_measurements(ctx)
-    assert len(nets) == 2 and stride == 2
-    prec = nets[0][0].precision_code()
-    flag = engine.range_flag(dev)
-    one_each = torch.full((N, M), float("nan"), device=dev)
-    for k, (net, bias, lw) in enumerate(nets):
-        _abi.pf_measure(net.blob(), net.n_res, prec, x, bias, lw, stride, one_each, k > 0, flag, N, M, d)
-    fused = torch.full((N, M), float("nan"), device=dev)
-    _abi.pf_measure_seq([n.blob() for n, _, _ in nets], nets[0][0].n_res, prec, x, [b for _, b, _ in nets],
-                        [lw for _, _, lw in nets], stride, fused, flag, N, M, d)
-    torch.cuda.synchronize()
-    assert bool(torch.isfinite(one_each).all())
-    assert torch.equal(fused, one_each)
-    # and it is the measurement model's own answer
-    want = meas(states=x, observations=obs)
-    assert torch.equal(fused, want)
-
-
-@pytest.mark.parametrize("image_precision", [None, "bf16"])
-@pytest.mark.parametrize("N,nets", [(1, 1), (37, 2), (300, 3), (1500, 2), (5000, 2)])
-def test_k4_conv4_inside_conv2b_conv3_is_bit_identical_to_the_conv4_kernel(N, nets, image_precision):
-    """Round 3: conv 16->8 runs in the Y waves of ``conv2b_conv3_kernel`` (D rows stay in an LDS ring, E leaves)
-    instead of as ``conv4_kernel`` (``MMF_K4_CONV4_KERNEL=1``).  Same MFMA sequence per output row, so the encoders'
-    features are the SAME BITS either way -- for one image, for workgroups that walk several images (ring slots
-    reused across image boundaries), for more images than a launch chunk, in both product modes; three repetitions
-    each (a ring hazard would show as a run-to-run difference)."""
-    from multimodalfilter_amd import engine, layers
-
-    dev = _cuda()
-    torch.manual_seed(N)
-    encs = [layers.image_encoder(64).to(dev) for _ in range(nets)]
-    img = (torch.randn((N, 32, 32), device=dev) * 0.5).clamp(-1, 1)
-    old_env = os.environ.get("MMF_K4_CONV4_KERNEL")
-    engine.set_image_encoder_precision(image_precision)
-    try:
-        os.environ["MMF_K4_CONV4_KERNEL"] = "1"
-        want = torch.stack(engine.encode_images(encs, img))
-        os.environ["MMF_K4_CONV4_KERNEL"] = "0"
-        for _ in range(3):
-            got = torch.stack(engine.encode_images(encs, img))
-            assert torch.equal(got, want)
-        assert bool(torch.isfinite(got).all()) and float(got.abs().max()) > 0
-    finally:
-        engine.set_image_encoder_precision(None)
-        if old_env is None:
-            os.environ.pop("MMF_K4_CONV4_KERNEL", None)
-        else:
-            os.environ["MMF_K4_CONV4_KERNEL"] = old_env
-
-
 @pytest.mark.parametrize("layer,what", [(0, "stem output (A / B planes)"), (2, "ResConv output (C rows, X waves)"),
                                         (3, "conv 32->16 output (D rows, Y waves: the ring of the fused conv 16->8)"),
                                         (5, "conv 16->8 output (E, split by the linear layer)")])

@@ -824,41 +824,6 @@ print("RCCL-OK")
     assert out.returncode == 0 and "RCCL-OK" in out.stdout, out.stderr[-2000:]
 
 
-@pytest.mark.parametrize("cls,N,M,T", [("DoorCrossmodalParticleFilter", 32, 300, 12), ("PushCrossmodalParticleFilter", 5, 4096, 4)])
-def test_native_loop_with_one_measurement_launch_per_step_is_bit_identical(cls, N, M, T):
-    """``MmfPfLoopArgs.measure_seq`` (``engine.MEASURE_SEQ``, off by default): the step's modalities as one launch -- estimates, particle set and
-    log-weights of a free-running filter equal the one-launch-per-modality loop's bit for bit."""
-    _need_gpu()
-    import multimodalfilter_amd as mmf
-    from multimodalfilter_amd import engine, synthetic
-
-    dev = torch.device("cuda:0")
-    task = "door" if cls.startswith("Door") else "push"
-    d = om.TASKS[task].state_dim
-    traj = {k: v.to(dev) for k, v in synthetic.make_trajectories(state_dim=d, T=T, N=N, seed=9).items()}
-    eps0, eps, us = synthetic.draw_filter_noise(T=T, N=N, M=M, state_dim=d, seed=10)
-    noise = (eps0.to(dev), torch.stack(eps).to(dev), torch.stack(us).to(dev))
-    torch.manual_seed(1)
-    f = mmf.model_types(task)[cls]().to(dev).eval()
-    f.num_particles = M
-    obs = {k: traj[k][1:] for k in ("image", "gripper_pos", "gripper_sensors")}
-    cov = (torch.eye(d, device=dev) * 0.1)[None].expand(N, d, d)
-    old = engine.MEASURE_SEQ
-    out = {}
-    try:
-        for seq in (False, True):
-            engine.MEASURE_SEQ = seq
-            f.noise = mmf.StackedNoise(*noise)
-            f.initialize_beliefs(mean=traj["states"][0], covariance=cov)
-            est = f.forward_loop(observations=obs, controls=traj["controls"][1:])
-            out[seq] = (est.clone(), f.particle_states.clone(), f.particle_log_weights.clone())
-    finally:
-        engine.MEASURE_SEQ = old
-    for a, b in zip(out[False], out[True]):
-        assert torch.equal(a, b)
-    assert bool(torch.isfinite(out[True][0]).all())
-
-
 @pytest.mark.parametrize("index", [0, 1])
 def test_likelihood_map_call_of_the_reference_notebook(index):
     """The third caller of the path: ``scripts/door_task/vis_pf_likelihoods.ipynb`` cell 3 evaluates ONE
