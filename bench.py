@@ -671,6 +671,8 @@ def leg_ekf(name, wl, *, K, W, device, seed=7100, cpu_batch=256, cpu_steps=6, pl
     out["cpu_baseline"] = base
     out["parity"] = {"max_rel_err_posterior_mean_vs_oracle": parity["max_rel_err_posterior_mean"],
                      "max_rel_err_posterior_covariance_vs_oracle": parity["max_rel_err_posterior_covariance"],
+                     "max_rel_err_posterior_covariance_per_matrix_vs_oracle": parity["max_rel_err_posterior_covariance_per_matrix"],
+                     "max_rel_err_posterior_mean_per_vector_vs_oracle": parity["max_rel_err_posterior_mean_per_vector"],
                      "sample": f"{cpu_batch} trajectories x {cpu_steps + 1} steps, same weights / inputs; CPU oracle"}
     out["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
     del run, traj

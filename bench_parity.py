@@ -490,12 +490,22 @@ def cpu_baseline_ekf(wl, engine_filter, state_dim, cores, sample_batch=256, samp
     # posterior covariances after the last step: every sub-filter's belief (and the fused one where the filter keeps it)
     subs_o = list(oracle.filter_models) if hasattr(oracle, "filter_models") else [oracle]
     subs_e = list(engine_filter.filter_models) if hasattr(engine_filter, "filter_models") else [engine_filter]
+    def normwise(a, b, dims):  # worst matrix / vector of the batch against its own Frobenius norm
+        a, b = a.detach().cpu().double(), b.detach().cpu().double()
+        axes = tuple(range(b.dim() - dims, b.dim()))
+        den = b.pow(2).sum(axes).sqrt()
+        return float(((a - b).pow(2).sum(axes).sqrt() / den.clamp_min(1e-3 * float(den.max()))).max())
+
     cov_err = max(elementwise(fe._belief_covariance, fo._belief_covariance) for fo, fe in zip(subs_o, subs_e))
+    cov_fro = max(normwise(fe._belief_covariance, fo._belief_covariance, 2) for fo, fe in zip(subs_o, subs_e))
     parity = {"max_rel_err_posterior_mean": float((got - want).abs().max()) / scale,
+              "max_rel_err_posterior_mean_per_vector": normwise(got, want, 1),
               "max_rel_err_posterior_mean_elementwise": elementwise(got, want),
               "max_rel_err_posterior_covariance": cov_err,
-              "note": "mean: relative to max(1, largest mean); *_elementwise and covariance: every entry relative to max(|its own value|, "
-                      "1e-3 x the tensor's largest), sub-filter beliefs after the sample's last step"}
+              "max_rel_err_posterior_covariance_per_matrix": cov_fro,
+              "note": "mean: relative to max(1, largest mean); *_per_vector / *_per_matrix: the worst vector / matrix of the batch against its "
+                      "own Frobenius norm (the bar of tests/_tol.py: 1e-4); *_elementwise and covariance: every entry relative to "
+                      "max(|its own value|, 1e-3 x the tensor's largest); sub-filter beliefs after the sample's last step"}
     return {"value": sample_batch * sample_steps / dt, "unit": "trajectory-steps/s", "cores": cores,
             "kind": "port",
             "sample": f"oracle EKF (oracle/), {wl['cls']}, batch {sample_batch} x {sample_steps} steps "

@@ -1030,9 +1030,14 @@ def encode_images(encoders, images: torch.Tensor):
                 object.__setattr__(e, "_mmf_packed", PackedImageEncoder(e))
             packs.append(e._mmf_packed.blob())
         feats = [torch.empty((N, 64), dtype=torch.float32, device=images.device) for _ in grp]
-        # bounded workspace: at most _IMAGE_CHUNK images per launch sequence
-        for c0 in range(0, N, _IMAGE_CHUNK):
-            n = min(_IMAGE_CHUNK, N - c0)
+        # bounded workspace: at most _IMAGE_CHUNK images per launch sequence, in EQUAL chunks (round 5: 5,120 images run
+        # as 2 x 2,560, not 4,096 + 1,024 -- the short chunk's persistent grids spent a third of their launch filling
+        # and draining, profiles/r04: 0.265 PF against 0.31), a multiple of 256 so every workgroup of the persistent
+        # grids gets the same number of images
+        n_chunks = -(-N // _IMAGE_CHUNK)
+        per = min(_IMAGE_CHUNK, -(-(-(-N // n_chunks)) // 256) * 256) if N > 256 else N
+        for c0 in range(0, N, per):
+            n = min(per, N - c0)
             chunk = images[c0:c0 + n]
             feat = torch.empty((len(grp), n, 64), dtype=torch.float32, device=images.device)
             ws = _image_workspace(images.device, n, len(grp))
