@@ -459,7 +459,8 @@ int mmf_dynamics_forward_loop(const float* packed, int n_res, int precision, con
  *  packed_dual  mmf_pack_particle_net(.., MMF_PREC_F16X3_DUAL)
  *  kind         0 dynamics (n_res 3): g_next (N M, d) = dL / d x' in, d_raw (N M, d + 1) = dL / d (dir, gate) out,
  *               act / g_act scratch (N M, 64) fp32;  1 measurement (n_res 2): d_out (N M) = dL / d log-likelihood
- *  d_states     out (N M, d): the gradient THROUGH the network (the dynamics' direct path x' = x + .. is the caller's)
+ *  d_states     out (N M, d): the gradient THROUGH the network (the dynamics' direct path x' = x + .. is the caller's),
+ *               plus d_states_base when that is given
  *  dz_first_h, sc_first, dz_join_h, sc_join, h_last_h: out, the compact (N M, 64) f16 rows + (N M) fp32 row scales the
  *               narrow reductions read (first-layer / join pre-activation gradients, head input)
  *  pw, pb       (NL, n_slots, 64, 64) / (NL, n_slots, 64) ACCUMULATED in place, slot = workgroup (grid =
@@ -483,6 +484,8 @@ typedef struct MmfTrainFusedArgs {
   void* h_last_h;
   float* pw;
   float* pb;
+  const float* d_states_base; /* null, or (N M, d) values ADDED to what is written to d_states (may be d_states itself: the
+                                 caller's running gradient is updated in place, no separate add pass) */
 } MmfTrainFusedArgs;
 
 int mmf_particle_net_train_fused(const MmfTrainFusedArgs* args /* host */, void* stream);

@@ -94,7 +94,7 @@ class MmfTrainFusedArgs(Structure):
     _fields_ = [("packed_dual", _FP), ("n_res", c_int32), ("kind", c_int32), ("d", c_int32), ("N", c_int32), ("M", c_int32),
                 ("n_slots", c_int32), ("states", _FP), ("traj_bias", _FP), ("d_out", _FP), ("g_next", _FP), ("d_raw", _FP),
                 ("act", _FP), ("g_act", _FP), ("d_states", _FP), ("dz_first_h", _FP), ("sc_first", _FP), ("dz_join_h", _FP),
-                ("sc_join", _FP), ("h_last_h", _FP), ("pw", _FP), ("pb", _FP)]
+                ("sc_join", _FP), ("h_last_h", _FP), ("pw", _FP), ("pb", _FP), ("d_states_base", _FP)]
 
 
 class MmfEkfLoopArgs(Structure):

@@ -109,7 +109,8 @@ struct FusedArgs {
   float* d_raw;            // dynamics trunk out: (R, D + 1) dL / d (dir, gate)
   const float* g_in;       // kEnc: (R, 64) fp32 dL / d encoder output
   float* g_out;            // kTrunk out
-  float* d_states;         // (R, D): through the network only
+  float* d_states;         // (R, D): through the network only ..
+  const float* d_states_base;  // .. or, when given, that plus these (R, D) values (may be d_states itself: accumulate)
   _Float16* dz_first_h;    // compact slots for small_grads_h_kernel
   float* sc_first;
   _Float16* dz_join_h;
@@ -760,8 +761,11 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
           }
 #pragma unroll
       for (int i = 0; i < D; ++i) {
-        const float v = halves_sum(ds[i]);
-        if (valid && h == 0) a.d_states[static_cast<size_t>(row) * D + i] = v;
+        float v = halves_sum(ds[i]);
+        if (valid && h == 0) {
+          if (a.d_states_base) v += a.d_states_base[static_cast<size_t>(row) * D + i];
+          a.d_states[static_cast<size_t>(row) * D + i] = v;
+        }
       }
     }
     FUSED_STAMP(9);  // first layer, d states
@@ -840,7 +844,7 @@ extern "C" int mmf_particle_net_train_fused(const MmfTrainFusedArgs* c, void* st
   if (c->N == 0) return 0;
   FusedArgs a{};
   a.blob = c->packed_dual; a.states = c->states; a.traj_bias = c->traj_bias; a.d_out = c->d_out; a.g_next = c->g_next;
-  a.d_raw = c->d_raw; a.d_states = c->d_states;
+  a.d_raw = c->d_raw; a.d_states = c->d_states; a.d_states_base = c->d_states_base;
   a.dz_first_h = static_cast<_Float16*>(c->dz_first_h); a.sc_first = c->sc_first;
   a.dz_join_h = static_cast<_Float16*>(c->dz_join_h); a.sc_join = c->sc_join;
   a.h_last_h = static_cast<_Float16*>(c->h_last_h);

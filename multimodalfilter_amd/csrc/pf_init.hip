@@ -72,10 +72,10 @@ __global__ __launch_bounds__(256) void pf_init_particles_kernel(
 //     G_m = g_lw_m + w_m sum_i x_mi g_est_i;   d a_k = G_k - w_k sum_m G_m;   d x_mi = w_m g_est_i
 // One workgroup per trajectory, two passes over its M particles.
 template <int D>
-__global__ __launch_bounds__(256) void pf_reweight_backward_kernel(
+__global__ __launch_bounds__(1024) void pf_reweight_backward_kernel(
     const float* __restrict__ lw, const float* __restrict__ states, const float* __restrict__ g_est,
     const float* __restrict__ g_lw, float* __restrict__ d_a, float* __restrict__ d_states, int M) {
-  __shared__ float red[4];
+  __shared__ float red[16];
   const int n = blockIdx.x, tid = threadIdx.x;
   const size_t base = static_cast<size_t>(n) * M;
   float ge[D];
@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void pf_reweight_backward_kernel(
   sum = mmf::wave_sum(sum);
   if ((tid & 63) == 0) red[tid >> 6] = sum;
   __syncthreads();
-  const float S = red[0] + red[1] + red[2] + red[3];
+  float S = 0.f;
+  for (int w = 0; w < static_cast<int>(blockDim.x >> 6); ++w) S += red[w];  // fixed order
   for (int m = tid; m < M; m += blockDim.x) d_a[base + m] -= expf(lw[base + m]) * S;
 }
 
@@ -110,8 +111,11 @@ extern "C" int mmf_pf_reweight_backward(const float* logw_out, const float* stat
   if (N < 0 || M < 1) return MMF_EINVAL;
   if (N == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (d == 2) pf_reweight_backward_kernel<2><<<N, 256, 0, s>>>(logw_out, states, g_estimate, g_logw_out, d_a, d_states, M);
-  else if (d == 3) pf_reweight_backward_kernel<3><<<N, 256, 0, s>>>(logw_out, states, g_estimate, g_logw_out, d_a, d_states, M);
+  // one workgroup per trajectory: with few trajectories of many particles (config 5: 32 x 8192) the launch is ONE
+  // latency chain per workgroup -- 1024 threads quarter it (43 -> ~12 us at 32 x 8192)
+  const int threads = M >= 2048 ? 1024 : 256;
+  if (d == 2) pf_reweight_backward_kernel<2><<<N, threads, 0, s>>>(logw_out, states, g_estimate, g_logw_out, d_a, d_states, M);
+  else if (d == 3) pf_reweight_backward_kernel<3><<<N, threads, 0, s>>>(logw_out, states, g_estimate, g_logw_out, d_a, d_states, M);
   else return MMF_EINVAL;
   MMF_CHECK_LAUNCH();
   return 0;

@@ -190,14 +190,15 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
   };
   // fused: one launch (dynamics: three) per network call, then the narrow reductions on the rows it left
   auto net_fused = [&](const MmfTrainNet& net, int n_res, int kind, const float* xs, const float* bias, const float* d_out,
-                       const float* g_next, float* d_raw, float* d_states, int NL, size_t C, size_t slot0, int Nc, int n_out) {
+                       const float* g_next, float* d_raw, float* d_states, const float* d_states_base, int NL, size_t C,
+                       size_t slot0, int Nc, int n_out) {
     if (!net.packed_dual) return static_cast<int>(MMF_EINVAL);
     char *stash = stash_of(0), *dz = dz_of(0);
     float* sc = scale_of(0);
     MmfTrainFusedArgs f{};
     f.packed_dual = net.packed_dual; f.n_res = n_res; f.kind = kind; f.d = d; f.N = Nc; f.M = M; f.n_slots = S;
     f.states = xs; f.traj_bias = bias; f.d_out = d_out; f.g_next = g_next; f.d_raw = d_raw; f.act = a->fused_act;
-    f.g_act = a->fused_g_act; f.d_states = d_states;
+    f.g_act = a->fused_g_act; f.d_states = d_states; f.d_states_base = d_states_base;
     f.dz_first_h = dz; f.sc_first = sc; f.dz_join_h = dz + C * MMF_UNITS * 2; f.sc_join = sc + C; f.h_last_h = stash;
     f.pw = net.pw; f.pb = net.pb;
     int r = mmf_particle_net_train_fused(&f, stream);
@@ -248,11 +249,10 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
         const float* d_out = K > 1 ? a->d_raw + k * C : d_a + r0;
         hipStream_t sk = hs;
         if (fused) {
+          // the network's d states is added to the running gradient in the kernel's own store (same sum, same order)
           rc = net_fused(net, a->n_res_meas, 1, xn + r0 * d, a->meas_bias[k] + (t * row + n0) * MMF_UNITS, d_out, nullptr, nullptr,
-                         tmp_of(k), NLm, C, slot0, Nc, 1);
+                         g_tot + r0 * d, g_tot + r0 * d, NLm, C, slot0, Nc, 1);
           if (rc) return rc;
-          add_kernel<<<blocks(C * d), kThreads, 0, hs>>>(g_tot + r0 * d, tmp_of(k), C * d);
-          MMF_CHECK_LAUNCH();
           continue;
         }
         char *stash = stash_of(k), *dz = dz_of(k);
@@ -272,11 +272,10 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
       // ---- dynamics network: x' = x + dir sigmoid(gate) + L eps
       if (fused) {
         // the sigmoid-gate epilogue's backward runs inside the trunk kernel (d_raw_dyn is its output)
+        // dL/d states[t] = direct path (g_tot) + through the network: written by the encoder-backward launch itself
         rc = net_fused(a->dyn, a->n_res_dyn, 0, x + r0 * d, a->dyn_bias + (t * row + n0) * MMF_UNITS, nullptr, g_tot + r0 * d, d_raw_dyn,
-                       tmp_of(K), NLd, C, slot0, Nc, d + 1);
+                       g_next + r0 * d, g_tot + r0 * d, NLd, C, slot0, Nc, d + 1);
         if (rc) return rc;
-        sum2_kernel<<<blocks(C * d), kThreads, 0, hs>>>(g_tot + r0 * d, tmp_of(K), g_next + r0 * d, C * d);
-        MMF_CHECK_LAUNCH();
       } else {
         const MmfTrainNet& net = a->dyn;
         hipStream_t sd = hs;
