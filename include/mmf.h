@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 37
+#define MMF_ABI_VERSION 38
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -616,6 +616,16 @@ int mmf_pf_train_backward(const MmfPfTrainArgs* args /* host */, void* stream);
  *               floats, zero-padded) at b_off
  *   STORE       io[io][row*io_stride + io_off + 0:out_dim] = act(slot[src[0]])
  *   STORE_DIAG  io[io][row*io_stride + io_off + 0:d*d] = diag(act(slot[src[0]][0:d])), d = out_dim
+ * Round 5 -- the reverse mode of a program is ANOTHER program over the same slot file (train_helpers.py:124-162: the
+ * reference differentiates these networks with torch autograd, a GEMM + a reduction + an element-wise launch per
+ * nn.Linear), built by trajprog.py from the forward list; it needs four more instructions, and LOAD / LINEAR write at
+ * slot[dst][dst_off + ..] (LOAD applies `act`):
+ *   MASK        slot[dst][dst_off + c] = io[..][c] > 0 ? slot[dst][dst_off + c] : 0     (backward of a ReLU, from the stashed output)
+ *   ADD         slot[dst][dst_off + c] += slot[src[0]][src_off[0] + c]
+ *   ZERO        slot[dst][dst_off + c] = 0
+ *   LOAD_ADD    slot[dst][dst_off + c] += io[..][c]                     c < out_dim throughout
+ * The transposed layers are LINEARs over a second blob; parameter gradients are mmf_traj_weight_grads over the rows
+ * the two programs stashed.
  */
 #define MMF_TRAJ_MAX_IO 8
 #define MMF_TRAJ_SLOTS 8
@@ -623,6 +633,10 @@ int mmf_pf_train_backward(const MmfPfTrainArgs* args /* host */, void* stream);
 #define MMF_TRAJ_LINEAR 1
 #define MMF_TRAJ_STORE 2
 #define MMF_TRAJ_STORE_DIAG 3
+#define MMF_TRAJ_MASK 4
+#define MMF_TRAJ_ADD 5
+#define MMF_TRAJ_ZERO 6
+#define MMF_TRAJ_LOAD_ADD 7
 #define MMF_TRAJ_ACT_NONE 0
 #define MMF_TRAJ_ACT_RELU 1
 #define MMF_TRAJ_ACT_SIGMOID 2
@@ -639,6 +653,7 @@ typedef struct MmfTrajInstr {
   int32_t act;
   int32_t io, io_stride, io_off;
   float fparam;
+  int32_t dst_off;      /* first feature written in slot[dst] (multiple of 4; LINEAR reads its residual there too) */
 } MmfTrajInstr;
 
 /*  prog     (n_instr) MmfTrajInstr on the DEVICE
@@ -651,6 +666,50 @@ typedef struct MmfTrajInstr {
  */
 int mmf_traj_program(const MmfTrajInstr* prog, int n_instr, const float* weights,
                      float* const* io, int R, int n_slots, int vec_width, void* stream);
+
+/* The weight blob of a program, gathered on the device from the parameters where they lie (an optimiser updates them in
+ * place, so the descriptor table is built once per program): per part
+ *   MMF_TRAJ_PACK_LAYER       fragments of W[0:rows][col0 : col0 + dim] (W row-major with row stride ld) for one source
+ *   MMF_TRAJ_PACK_TRANSPOSED  fragments of the transposed block: output o < rows is column col0 + o of W, input
+ *                             k < dim its row k -- the layer the reverse program multiplies by
+ *   MMF_TRAJ_PACK_BIAS        128 floats, the first `rows` from src
+ * written at blob + dst_off in the LINEAR layout above (out_pad = 64 | 128). */
+#define MMF_TRAJ_PACK_LAYER 0
+#define MMF_TRAJ_PACK_TRANSPOSED 1
+#define MMF_TRAJ_PACK_BIAS 2
+typedef struct MmfTrajPackDesc {
+  uint64_t src;          /* device address of the fp32 parameter */
+  int32_t kind, rows, ld, col0, dim, out_pad;
+  int32_t dst_off, reserved;
+} MmfTrajPackDesc;
+int mmf_traj_pack(const MmfTrajPackDesc* desc /* device */, int n_desc, float* blob, void* stream);
+
+/* Parameter gradients of a program's LINEARs from the rows its forward (every LOADed / LINEAR output: `stash`) and
+ * its reverse program (every pre-activation gradient: `dz`) wrote: per descriptor
+ *   grads[grad_off + o * grad_ld + k] = sum_row dz[row][dz_col + o] * stash[row][x_col + k]   o < out_dim, k < x_dim
+ *   grads[bias_off + o]               = sum_row dz[row][dz_col + o]                            (bias_off >= 0)
+ * on v_mfma_f32_16x16x4_f32 with rows as the contraction, in a fixed order (row slices in ascending order: no atomics).
+ * Replaces autograd's Linear backward (one GEMM and one column reduction per nn.Linear).
+ *  desc      (n_desc) on the DEVICE;  stash (R, stash_ld), dz (R, dz_ld) fp32
+ *  grads     flat output, every descriptor's block written (not accumulated)
+ *  partials  (n_slices, n_grads) scratch when n_slices > 1 (rows are cut into n_slices equal runs, <= 64), else null
+ */
+typedef struct MmfTrajGradDesc {
+  int32_t x_col, x_dim, dz_col, out_dim;
+  int32_t grad_off, grad_ld, bias_off, reserved;
+} MmfTrajGradDesc;
+int mmf_traj_weight_grads(const MmfTrajGradDesc* desc, int n_desc, const float* stash, int stash_ld, const float* dz,
+                          int dz_ld, float* grads, int n_grads, float* partials, int n_slices, int R, void* stream);
+
+/* The 8192 -> 64 linear layer behind the convolutions of a training step (door_models/layers.py:59-60, the
+ * nn.Linear(8 * 32 * 32, units) of the image encoder), forward and both backward products in exact fp32 on
+ * v_mfma_f32_16x16x4_f32, fixed summation order; replaces the library GEMMs of torch's Linear forward / backward.
+ *  x (R, K) fp32, w (64, K) row-major = nn.Linear.weight, b (64) or null, K % 128 == 0
+ *   forward:  y (R, 64) = x w^T + b
+ *   backward: dx (R, K) = g w (null: skipped);  dw (64, K) = g^T x;  db (64) = column sums of g (null: skipped) */
+int mmf_fc64_train_forward(const float* x, const float* w, const float* b, float* y, int R, int K, void* stream);
+int mmf_fc64_train_backward(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, int R,
+                            int K, void* stream);
 
 /* ---------------------------------------------------------------- K3: EKF algebra + fusion
  * Replaces torchfilter's EKF predict/update (A S A^T + L L^T; K = S-(S- + R)^-1;

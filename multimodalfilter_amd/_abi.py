@@ -7,7 +7,7 @@ the call raises.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_float, c_int, c_int32, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_float, c_int, c_int32, c_size_t, c_uint64, c_void_p
 
 import torch
 
@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 37
+ABI_VERSION = 38
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16, PREC_F16X3_DUAL = 0, 1, 2, 3
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
@@ -40,6 +40,7 @@ class MmfParticleNetDesc(Structure):
 
 TRAJ_MAX_IO, TRAJ_SLOTS = 8, 8
 TRAJ_LOAD, TRAJ_LINEAR, TRAJ_STORE, TRAJ_STORE_DIAG = 0, 1, 2, 3
+TRAJ_MASK, TRAJ_ADD, TRAJ_ZERO, TRAJ_LOAD_ADD = 4, 5, 6, 7
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SQRT_SQ_PLUS = 0, 1, 2, 3
 
 
@@ -47,7 +48,20 @@ class MmfTrajInstr(Structure):
     _fields_ = [("op", c_int32), ("dst", c_int32), ("src", c_int32 * 4), ("src_off", c_int32 * 4), ("src_dim", c_int32 * 4),
                 ("out_dim", c_int32), ("w_off", c_int32), ("b_off", c_int32), ("res", c_int32),
                 ("act", c_int32), ("io", c_int32), ("io_stride", c_int32), ("io_off", c_int32),
-                ("fparam", c_float)]
+                ("fparam", c_float), ("dst_off", c_int32)]
+
+
+class MmfTrajPackDesc(Structure):
+    _fields_ = [("src", c_uint64), ("kind", c_int32), ("rows", c_int32), ("ld", c_int32), ("col0", c_int32), ("dim", c_int32),
+                ("out_pad", c_int32), ("dst_off", c_int32), ("reserved", c_int32)]
+
+
+TRAJ_PACK_LAYER, TRAJ_PACK_TRANSPOSED, TRAJ_PACK_BIAS = 0, 1, 2
+
+
+class MmfTrajGradDesc(Structure):
+    _fields_ = [("x_col", c_int32), ("x_dim", c_int32), ("dz_col", c_int32), ("out_dim", c_int32),
+                ("grad_off", c_int32), ("grad_ld", c_int32), ("bias_off", c_int32), ("reserved", c_int32)]
 
 
 LOOP_MAX_MEAS = 4
@@ -142,6 +156,10 @@ SIGNATURES = {
     "mmf_philox_uniforms": (c_int, [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _FP, c_int, c_int, c_void_p]),
     "mmf_dynamics_forward_loop": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_traj_program": (c_int, [_FP, c_int, _FP, POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
+    "mmf_traj_pack": (c_int, [c_void_p, c_int, _FP, c_void_p]),
+    "mmf_traj_weight_grads": (c_int, [c_void_p, c_int, _FP, c_int, _FP, c_int, _FP, c_int, _FP, c_int, c_int, c_void_p]),
+    "mmf_fc64_train_forward": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
+    "mmf_fc64_train_backward": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_fuse_virtual_sensors": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_ekf_forward_loop": (c_int, [POINTER(MmfEkfLoopArgs), c_void_p]),
     "mmf_dynamics_jacobian_multi": (c_int, [POINTER(c_void_p), c_int, c_int, _FP, POINTER(c_void_p), _FP, _FP, _FP,
@@ -494,6 +512,33 @@ def traj_program(prog: torch.Tensor, n_instr: int, weights: torch.Tensor, io_ten
     with _on(weights):
         _check(load().mmf_traj_program(ptr(prog, dtype=torch.uint8), n_instr, ptr(weights), arr, R,
                                        n_slots, vec_width, stream_of(weights)), "mmf_traj_program")
+
+
+def traj_pack(desc: torch.Tensor, n_desc: int, blob: torch.Tensor):
+    with _on(blob):
+        _check(load().mmf_traj_pack(ptr(desc, dtype=torch.uint8), n_desc, ptr(blob), stream_of(blob)), "mmf_traj_pack")
+
+
+def traj_weight_grads(desc: torch.Tensor, n_desc: int, stash: torch.Tensor, dz: torch.Tensor, grads: torch.Tensor,
+                      partials, n_slices: int, R: int):
+    """``desc``: uint8 device tensor of ``n_desc`` MmfTrajGradDesc; ``stash`` / ``dz``: ``(R, ld)``; ``grads``: flat."""
+    with _on(grads):
+        _check(load().mmf_traj_weight_grads(ptr(desc, dtype=torch.uint8), n_desc, ptr(stash), stash.shape[1], ptr(dz),
+                                            dz.shape[1], ptr(grads), grads.numel(), ptr(partials), n_slices, R,
+                                            stream_of(grads)), "mmf_traj_weight_grads")
+
+
+def fc64_train_forward(x, w, b, y):
+    R, K = x.shape
+    with _on(x):
+        _check(load().mmf_fc64_train_forward(ptr(x), ptr(w), ptr(b), ptr(y), R, K, stream_of(x)), "mmf_fc64_train_forward")
+
+
+def fc64_train_backward(g, x, w, dx, dw, db):
+    R, K = x.shape
+    with _on(x):
+        _check(load().mmf_fc64_train_backward(ptr(g), ptr(x), ptr(w), ptr(dx), ptr(dw), ptr(db), R, K, stream_of(x)),
+               "mmf_fc64_train_backward")
 
 
 def pf_reweight_backward(logw_out, states, g_estimate, g_logw_out, d_a, d_states):

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmf_hip.so")
-SOURCES = ["abi.hip", "pf_resample.hip", "pf_init.hip", "ekf.hip", "ukf.hip", "particle_net.hip", "particle_net_fused.hip", "image_encoder.hip", "traj_program.hip", "pf_loop.hip", "ekf_loop.hip", "pf_train_loop.hip"]
+SOURCES = ["abi.hip", "pf_resample.hip", "pf_init.hip", "ekf.hip", "ukf.hip", "particle_net.hip", "particle_net_fused.hip", "image_encoder.hip", "traj_program.hip", "traj_train.hip", "pf_loop.hip", "ekf_loop.hip", "pf_train_loop.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # particle_net.hip: with the SLP vectoriser on, the f16x3 operand split (x - float(hi) -> f16)
 # becomes cvt + cvt + v_pk_add_f32 + cvt; without it the same source selects

@@ -86,8 +86,8 @@ __device__ __forceinline__ void linear_mfma(const MmfTrajInstr& I, const float* 
     w += groups * MT * 256;
   }
   // epilogue: (+ residual) activation, written back as 16-byte pieces; every source was read above, so dst may alias
-  const float* res = I.res >= 0 ? slots + I.res * (kRows * ld) + i * ld : nullptr;
-  float* dst = slots + I.dst * (kRows * ld) + i * ld;
+  const float* res = I.res >= 0 ? slots + I.res * (kRows * ld) + i * ld + I.dst_off : nullptr;
+  float* dst = slots + I.dst * (kRows * ld) + i * ld + I.dst_off;
   f32x4 out[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -115,15 +115,36 @@ __global__ __launch_bounds__(kWaves * MMF_WAVE) void traj_program_kernel(
     const int nrows = min(kRows, R - row0);
     for (int ip = 0; ip < n_instr; ++ip) {
       const MmfTrajInstr I = prog[ip];
-      if (I.op == MMF_TRAJ_LOAD) {
+      if (I.op == MMF_TRAJ_LOAD || I.op == MMF_TRAJ_LOAD_ADD || I.op == MMF_TRAJ_MASK) {
+        // LOAD: slot = act(io); LOAD_ADD: slot += io; MASK: slot = io > 0 ? slot : 0 (the backward of a ReLU, from the
+        // stashed output).  Rows past the end repeat the last row: defined values that no STORE writes back.
         const float* src = io.p[I.io];
-        float* dst = slots + I.dst * (kRows * ld);
+        float* dst = slots + I.dst * (kRows * ld) + I.dst_off;
 #pragma unroll 4
         for (int r = 0; r < kRows; ++r) {
           const size_t g = static_cast<size_t>(row0 + min(r, nrows - 1)) * I.io_stride + I.io_off;
-          if (lane < I.out_dim) dst[r * ld + lane] = src[g + lane];
-          if (lane + 64 < I.out_dim) dst[r * ld + 64 + lane] = src[g + 64 + lane];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int c = lane + 64 * h;
+            if (c < I.out_dim) {
+              const float v = src[g + c];
+              float* d = dst + r * ld + c;
+              if (I.op == MMF_TRAJ_LOAD) *d = activate(v, I.act, I.fparam);
+              else if (I.op == MMF_TRAJ_LOAD_ADD) *d = __fadd_rn(*d, v);
+              else *d = v > 0.f ? *d : 0.f;
+            }
+          }
         }
+      } else if (I.op == MMF_TRAJ_ADD || I.op == MMF_TRAJ_ZERO) {
+        float* dst = slots + I.dst * (kRows * ld) + I.dst_off;
+        const float* src = I.op == MMF_TRAJ_ADD ? slots + I.src[0] * (kRows * ld) + I.src_off[0] : nullptr;
+#pragma unroll 4
+        for (int r = 0; r < kRows; ++r)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int c = lane + 64 * h;
+            if (c < I.out_dim) dst[r * ld + c] = src ? __fadd_rn(dst[r * ld + c], src[r * ld + c]) : 0.f;
+          }
       } else if (I.op == MMF_TRAJ_LINEAR) {
         if (I.out_dim > 64) linear_mfma<8>(I, weights, slots, ld, lane);
         else linear_mfma<4>(I, weights, slots, ld, lane);
@@ -148,7 +169,36 @@ __global__ __launch_bounds__(kWaves * MMF_WAVE) void traj_program_kernel(
   }
 }
 
+// Weight blob of a program from the nn.Module parameters where they lie: one workgroup per part.
+__global__ __launch_bounds__(256) void traj_pack_kernel(const MmfTrajPackDesc* __restrict__ desc, float* __restrict__ blob) {
+  const MmfTrajPackDesc d = desc[blockIdx.x];
+  const float* src = reinterpret_cast<const float*>(d.src);
+  float* dst = blob + d.dst_off;
+  if (d.kind == MMF_TRAJ_PACK_BIAS) {
+    for (int j = threadIdx.x; j < 128; j += blockDim.x) dst[j] = j < d.rows ? src[j] : 0.f;
+    return;
+  }
+  const int MT = d.out_pad >> 4, groups = (d.dim + 15) >> 4;
+  const int n = groups * MT * 256;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    const int ks = e & 3, i = (e >> 2) & 15, q = (e >> 6) & 3, mt = (e >> 8) % MT, g = (e >> 8) / MT;
+    const int o = 16 * mt + i, k = 16 * g + 4 * ks + q;
+    float v = 0.f;
+    if (k < d.dim && o < d.rows)
+      v = d.kind == MMF_TRAJ_PACK_LAYER ? src[static_cast<size_t>(o) * d.ld + d.col0 + k]
+                                        : src[static_cast<size_t>(k) * d.ld + d.col0 + o];  // transposed block
+    dst[e] = v;
+  }
+}
+
 }  // namespace
+
+extern "C" int mmf_traj_pack(const MmfTrajPackDesc* desc, int n_desc, float* blob, void* stream) {
+  if (!desc || !blob || n_desc < 1) return MMF_EINVAL;
+  traj_pack_kernel<<<n_desc, 256, 0, static_cast<hipStream_t>(stream)>>>(desc, blob);
+  MMF_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int mmf_traj_program(const MmfTrajInstr* prog, int n_instr, const float* weights,
                                 float* const* io, int R, int n_slots, int vec_width, void* stream) {

@@ -964,18 +964,68 @@ class ImageConvsFunction(torch.autograd.Function):
         return (None, None, gw1, gw2a, gw2b, gw3, gw4, gb[0], gb[1], gb[2], gb[3, :16], gb[4, :8])
 
 
-def image_features_autograd(seq, images: torch.Tensor) -> torch.Tensor:
+class Fc64Function(torch.autograd.Function):
+    """K6 for the image encoder's ``nn.Linear(8 * 32 * 32, 64)`` (``door_models/layers.py:59-60``): ``x w^T + b``
+    forward, ``g w`` / ``g^T x`` / column sums backward, exact fp32 on the matrix cores in a fixed order
+    (``mmf_fc64_train_forward`` / ``_backward``, ``csrc/traj_train.hip``) -- no library GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        require_device(x, "Fc64Function")
+        x = x.detach().to(torch.float32).contiguous()
+        y = torch.empty((x.shape[0], 64), dtype=torch.float32, device=x.device)
+        _abi.fc64_train_forward(x, w.detach().contiguous(), b.detach().contiguous(), y)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw, db = torch.empty_like(w), torch.empty(64, dtype=torch.float32, device=x.device)
+        _abi.fc64_train_backward(g.to(torch.float32).contiguous(), x, w.detach().contiguous(), dx, dw, db)
+        return dx, dw, db
+
+
+# round 5: the per-trajectory networks of a training step (vector encoders, weight model, hoisted join halves, the linear
+# tail of the image encoder) run forward AND backward in HIP (trajprog.TrajProgram.run_autograd, Fc64Function) under the
+# "hip" training backend.  MMF_TRAIN_TRAJ_PROGRAMS=0: torch modules + autograd (library GEMMs), the round-4 path, kept as
+# the cross-check of tests/test_gpu_training.py.
+TRAIN_TRAJ_PROGRAMS = os.environ.get("MMF_TRAIN_TRAJ_PROGRAMS", "1") != "0"
+
+
+def use_traj_program_backward(*tensors) -> bool:
+    return TRAINING_BACKEND == "hip" and TRAIN_TRAJ_PROGRAMS and all(t.is_cuda for t in tensors)
+
+
+def image_features_autograd(seq, images: torch.Tensor, pre_activation: bool = False) -> torch.Tensor:
     """Differentiable ``observation_image_layers(images[:, None])``: with the "hip" training backend
-    and a default stack the convolutions run forward and backward in HIP (``ImageConvsFunction``),
-    the linear tail in torch; otherwise the torch module as it stands."""
+    and a default stack the convolutions and the 8192 -> 64 linear layer run forward and backward in HIP
+    (``ImageConvsFunction``, ``Fc64Function``); otherwise the torch module as it stands.  ``pre_activation``: stop behind
+    the linear layer (the caller's K7 program applies the ReLU and the ResLinear; default stacks on the device only)."""
     if use_hip_backward() and images.is_cuda and _image_encoder_variant(seq) == _abi.ENCODER_DEFAULT:
         params = PackedImageEncoder(seq)._sources()[:10] if not hasattr(seq, "_mmf_packed") else seq._mmf_packed._sources()[:10]
         a4 = ImageConvsFunction.apply(seq, images, *params)
         x = a4.flatten(1)
+        if TRAIN_TRAJ_PROGRAMS and seq[7].weight.dtype == torch.float32 and seq[7].out_features == 64:
+            x = Fc64Function.apply(x, seq[7].weight, seq[7].bias)
+            if pre_activation:
+                return x
+            for layer in list(seq)[8:]:
+                x = layer(x)
+            return x
+        assert not pre_activation
         for layer in list(seq)[7:]:
             x = layer(x)
         return x
+    assert not pre_activation
     return seq(images[:, None, :, :])
+
+
+def image_tail_in_program(seq, images: torch.Tensor) -> bool:
+    """Whether ``image_features_autograd(seq, images, pre_activation=True)`` is available for this encoder."""
+    return (use_traj_program_backward(images) and _image_encoder_variant(seq) == _abi.ENCODER_DEFAULT
+            and seq[7].weight.dtype == torch.float32 and seq[7].out_features == 64)
 
 
 _IMAGE_WORKSPACES = {}

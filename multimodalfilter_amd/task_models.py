@@ -82,12 +82,17 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             if "sensors" in self.modalities:
                 self.observation_sensors_layers = layers.vector_encoder(task.obs_sensors_dim, units)
 
-        def _emit_observation_sources(self, prog: TrajProgram):
+        def _emit_observation_sources(self, prog: TrajProgram, image_tail: bool = False):
             """LOAD + encode every modality; returns the ``(slot, offset, width)`` list in the
-            reference's concatenation order (image, pos, sensors)."""
+            reference's concatenation order (image, pos, sensors).  ``image_tail`` (training): the image enters as the
+            output of the encoder's linear layer and the program applies the ReLU + ResLinear behind it."""
             srcs = []
             if "image" in self.modalities:
-                srcs.append((prog.load("image_feat", 64), 0, 64))
+                if image_tail:
+                    f = prog.load("image_fc", 64, act=_abi.ACT_RELU)
+                    srcs.append((prog.res_linear(self.observation_image_layers[9], f, 64), 0, 64))
+                else:
+                    srcs.append((prog.load("image_feat", 64), 0, 64))
             if "pos" in self.modalities:
                 raw = prog.load("gripper_pos", task.obs_pos_dim)
                 srcs.append((prog.vector_encoder(self.observation_pos_layers, raw, task.obs_pos_dim), 0, 64))
@@ -97,6 +102,27 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
                 srcs.append((prog.vector_encoder(self.observation_sensors_layers, raw, task.obs_sensors_dim), 0, 64))
                 prog.free(raw)
             return srcs
+
+        def _train_program(self, observations, build):
+            """K7 program of this model for a training step (cached per image-input kind) and its differentiable
+            inputs; ``build(prog, sources)`` emits the model's own layers and STOREs."""
+            tail = "image" in self.modalities and engine.image_tail_in_program(self.observation_image_layers, observations["image"])
+            cache = self.__dict__.setdefault("_train_progs", {})
+            if tail not in cache:
+                p = TrajProgram()
+                build(p, self._emit_observation_sources(p, image_tail=tail))
+                cache[tail] = p
+            t = {}
+            if "image" in self.modalities:
+                if tail:
+                    t["image_fc"] = engine.image_features_autograd(self.observation_image_layers, observations["image"], pre_activation=True)
+                else:
+                    t["image_feat"] = engine.image_features_autograd(self.observation_image_layers, observations["image"])
+            if "pos" in self.modalities:
+                t["gripper_pos"] = observations["gripper_pos"]
+            if "sensors" in self.modalities:
+                t["gripper_sensors"] = observations["gripper_sensors"]
+            return cache[tail], t
 
         def observation_features_autograd(self, observations) -> torch.Tensor:
             """Differentiable torch evaluation of the encoders (training backend "autograd")."""
@@ -180,7 +206,12 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             return mu_pred, A, self.scale_tril().contiguous()
 
         def encode_controls_autograd(self, controls):
-            """Differentiable hoisted control term ``(R, 64)`` (torch ops on ``R`` rows)."""
+            """Differentiable hoisted control term ``(R, 64)``: the K7 program forward and backward in HIP
+            (``TrajProgram.run_autograd``), or torch ops on ``R`` rows."""
+            if engine.use_traj_program_backward(controls):
+                if self._ctrl_prog is None:
+                    self.encode_controls(controls.detach())
+                return self._ctrl_prog.run_autograd({"controls": controls}, {"bias": self.units}, controls.shape[0])["bias"]
             join = self.shared_layers[0]
             return self.control_layers(controls) @ join.weight[:, :self.units].t() + join.bias
 
@@ -287,6 +318,12 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
         def encode_observations_autograd(self, observations):
             """Differentiable hoisted observation term: encoders and the observation half of the
             join layer as torch ops on ``R`` rows -> ``{"bias": (R, 64)}``."""
+            if engine.use_traj_program_backward(observations["gripper_pos"]):
+                def build(p, srcs):
+                    b = p.linear(srcs, self.shared_layers[0], cols=(0, self.units * len(self.modalities)))
+                    p.store("bias", b, self.units)
+                prog, t = self._train_program(observations, build)
+                return prog.run_autograd(t, {"bias": self.units}, observations["gripper_pos"].shape[0])
             obs = self.observation_features_autograd(observations)
             join = self.shared_layers[0]
             return {"bias": obs @ join.weight[:, :obs.shape[1]].t() + join.bias}
@@ -350,22 +387,28 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
                 nn.Linear(units, modality_count),
             )
 
+        def _emit_fusion(self, p: TrajProgram, srcs):
+            x = p.linear(srcs, self.fusion_layers[0], _abi.ACT_RELU)
+            for blk in list(self.fusion_layers)[2:-1]:
+                p.res_linear(blk, x, blk.block1.in_features)
+            p.store("out", p.linear([(x, 0, self.fusion_layers[0].out_features)], self.fusion_layers[-1]),
+                    self.modality_count)
+
         def forward(self, *, observations, image_feat=None):
             N, _ = observations["gripper_pos"].shape
             if engine.use_autograd(self):
-                output = self.fusion_layers(self.observation_features_autograd(observations))
+                if engine.use_traj_program_backward(observations["gripper_pos"]):
+                    prog, t = self._train_program(observations, self._emit_fusion)
+                    output = prog.run_autograd(t, {"out": self.modality_count}, N)["out"]
+                else:
+                    output = self.fusion_layers(self.observation_features_autograd(observations))
                 if self.know_image_blackout:
                     output = output.clone()
                     output[blackout_rows(observations["image"]), 0] -= np.inf
                 return output
             if self._prog is None:
                 p = TrajProgram()
-                srcs = self._emit_observation_sources(p)
-                x = p.linear(srcs, self.fusion_layers[0], _abi.ACT_RELU)
-                for blk in list(self.fusion_layers)[2:-1]:
-                    p.res_linear(blk, x, blk.block1.in_features)
-                p.store("out", p.linear([(x, 0, self.fusion_layers[0].out_features)], self.fusion_layers[-1]),
-                        self.modality_count)
+                self._emit_fusion(p, self._emit_observation_sources(p))
                 self._prog = p
             t = self._program_inputs(observations, image_feat)
             output = torch.empty((N, self.modality_count), dtype=torch.float32,
