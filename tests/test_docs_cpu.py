@@ -1,4 +1,4 @@
-"""DESIGN.md quotes measured numbers; the measurements live under ``profiles/r04`` (rocprofv3 CSVs, bench JSON
+"""DESIGN.md quotes measured numbers; the measurements live under ``profiles/r05`` (rocprofv3 CSVs, bench JSON
 lines, ``SUMMARY.md`` generated from them by ``scripts/profiles_summary.py``).  Round 2's verdict found three
 numbers in the docs that no committed file held.  These tests tie the headline figures of DESIGN.md section 5 to
 the committed files mechanically: a re-profile that is not followed by a doc update fails here."""
@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PROF = os.path.join(ROOT, "profiles", "r04")
+PROF = os.path.join(ROOT, "profiles", "r05")
 
 
 def _line(name):
@@ -54,19 +54,32 @@ def test_headline_numbers_in_design_are_the_committed_bench_lines():
     assert {"C2", "C3", "C4", "C5"} <= {k[:2] for k in pf["configs"]} and sum(k.startswith("blackout") for k in pf["configs"]) == 2
     c5 = next(v for k, v in pf["configs"].items() if k.startswith("C5"))
     assert f"{c5['ms_per_step']:.1f}" in text, "C5 training step (configs of bench_door_pf_n1.json)"
+    # round 5: the oracle's own reproducibility floor sits beside the engine's numbers, in the line and in the text
+    floor = pf["parity_vs_oracle"]["oracle_self"]
+    assert floor["fp32_one_thread"]["teacher_forced"]["resample_index_mismatch_fraction"] == 0.0
+    assert f"{floor['fp64']['teacher_forced']['resample_index_mismatch_fraction']:.2e}" in text
+    assert f"{pf['parity_vs_oracle']['teacher_forced']['resample_index_mismatch_fraction']:.2e}" in text
+    train = _line("bench_push_train_n1.json")
+    assert f"{train['ms_per_step']:.1f}" in text and train["config"]["world_size_seen"] == 1
+
+
+def test_design_is_one_tracked_file():
+    """Round 4's verdict: track the text or its template, not both."""
+    assert not os.path.exists(os.path.join(ROOT, "DESIGN.md.in")) and not os.path.exists(os.path.join(ROOT, "scripts", "fill_design_numbers.py"))
+    assert "@@" not in _design()
 
 
 def test_kernel_durations_in_design_are_the_committed_rocprof_averages():
     text = _design()
-    for csv_name, prefix in (("door_pf_kernel_stats.csv", "particle_net_kernel<3, 2, 1, 2, 1, 2, true, false>"),
-                             ("door_pf_kernel_stats.csv", "particle_net_kernel<3, 3, 0, 2, 1, 2, true, false>"),
+    for csv_name, prefix in (("door_pf_kernel_stats.csv", "particle_net_kernel<3, 2, 1, 2, 1, 2, true>"),
+                             ("door_pf_kernel_stats.csv", "particle_net_kernel<3, 3, 0, 2, 1, 2, true>"),
                              ("door_pf_kernel_stats.csv", "pf_resample_systematic_kernel<3, true>"),
                              ("door_ekf_kernel_stats.csv", "conv2b_conv3_kernel<false, 2, true>"),
                              ("door_ekf_kernel_stats.csv", "stem_conv2a_kernel<false>")):
         us = _avg_us(csv_name, prefix)
         assert f"{us:.1f}" in text, f"{prefix}: {us:.1f} us ({csv_name}) is not what DESIGN.md quotes"
     # the roofline fraction follows from the measurement kernel's average: 6.067e10 FLOP per launch
-    us = _avg_us("door_pf_kernel_stats.csv", "particle_net_kernel<3, 2, 1, 2, 1, 2, true, false>")
+    us = _avg_us("door_pf_kernel_stats.csv", "particle_net_kernel<3, 2, 1, 2, 1, 2, true>")
     frac = 6.067e10 / (us * 1e-6) / 2.5e15
     assert f"{frac:.3f}" in text
 
@@ -74,17 +87,7 @@ def test_kernel_durations_in_design_are_the_committed_rocprof_averages():
 def test_summary_is_what_the_script_generates_from_the_committed_files():
     with open(os.path.join(PROF, "SUMMARY.md")) as fh:
         committed = fh.read()
-    out = subprocess.run([sys.executable, os.path.join("scripts", "profiles_summary.py"), os.path.join("profiles", "r04"), "--stdout"],
+    out = subprocess.run([sys.executable, os.path.join("scripts", "profiles_summary.py"), os.path.join("profiles", "r05"), "--stdout"],
                          capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-1000:]
     assert out.stdout.strip() == committed.strip()
-
-
-def test_design_is_generated_from_its_template_and_the_committed_files():
-    """``DESIGN.md.in`` holds the text, ``scripts/fill_design_numbers.py`` fills its @@NAME@@ placeholders from
-    ``profiles/r04``: an edit of DESIGN.md itself, or a re-profile without regenerating, fails here."""
-    out = subprocess.run([sys.executable, os.path.join("scripts", "fill_design_numbers.py"), os.path.join("profiles", "r04"),
-                          "DESIGN.md.in", "--stdout"], capture_output=True, text=True, timeout=120, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-1000:]
-    assert "@@" not in out.stdout
-    assert out.stdout == _design()
