@@ -606,7 +606,7 @@ int mmf_pf_train_backward(const MmfPfTrainArgs* args /* host */, void* stream);
  * The N-row networks around the filters (vector encoders layers.py:11-40,66-95; PF weight
  * model crossmodal_pf.py:74-106; virtual sensor kf.py:81-126; EKF weight model
  * crossmodal_kf.py:134-167; hoisted join-layer halves) as ONE launch per model: a list of
- * instructions interpreted per row.  Vectors (<= 128 wide) live in MMF_TRAJ_SLOTS per-wave
+ * instructions interpreted per 16 rows by a workgroup.  Vectors (<= 128 wide) live in MMF_TRAJ_SLOTS
  * LDS slots.
  *   LOAD        slot[dst][0:out_dim] = io[io][row*io_stride + io_off + 0:out_dim]
  *   LINEAR      slot[dst] = act(W cat(slot[src[s]][src_off[s] : src_off[s]+src_dim[s]] ..) + b (+ slot[res]));  W is stored
@@ -662,7 +662,7 @@ typedef struct MmfTrajInstr {
  *  R        rows
  *  n_slots  LDS vector slots the program uses (1 + its largest slot index, <= MMF_TRAJ_SLOTS)
  *  vec_width  64 when no vector of the program is wider, else 128: the launch sizes its LDS for
- *           n_slots x vec_width (32 .. 128 KiB per workgroup -> 4 .. 1 workgroups per CU)
+ *           n_slots x 16 rows x vec_width (4 .. 66 KiB per workgroup of four waves, one 16-row task at a time)
  */
 int mmf_traj_program(const MmfTrajInstr* prog, int n_instr, const float* weights,
                      float* const* io, int R, int n_slots, int vec_width, void* stream);
@@ -704,7 +704,7 @@ int mmf_traj_weight_grads(const MmfTrajGradDesc* desc, int n_desc, const float* 
 /* The 8192 -> 64 linear layer behind the convolutions of a training step (door_models/layers.py:59-60, the
  * nn.Linear(8 * 32 * 32, units) of the image encoder), forward and both backward products in exact fp32 on
  * v_mfma_f32_16x16x4_f32, fixed summation order; replaces the library GEMMs of torch's Linear forward / backward.
- *  x (R, K) fp32, w (64, K) row-major = nn.Linear.weight, b (64) or null, K % 128 == 0
+ *  x (R, K) fp32, w (64, K) row-major = nn.Linear.weight, b (64) or null, K % 256 == 0
  *   forward:  y (R, 64) = x w^T + b
  *   backward: dx (R, K) = g w (null: skipped);  dw (64, K) = g^T x;  db (64) = column sums of g (null: skipped) */
 int mmf_fc64_train_forward(const float* x, const float* w, const float* b, float* y, int R, int K, void* stream);

@@ -8,7 +8,7 @@
 //   /root/reference/crossmodal/door_models/kf.py:81-126               (virtual sensor)
 //   /root/reference/crossmodal/door_models/crossmodal_kf.py:134-167   (EKF weight model)
 // Here a whole model is ONE launch: a short instruction list (LOAD / LINEAR / STORE) is
-// interpreted by each wave for 16 rows at a time.  Vectors (<= 128 wide) live in per-wave LDS
+// interpreted by each workgroup for 16 rows at a time.  Vectors (<= 128 wide) live in LDS
 // slots; a LINEAR runs on v_mfma_f32_16x16x4_f32 (outputs x rows tiles, exact fp32, the same fma
 // chains as a scalar evaluation) with its weights streamed from L2 as pre-arranged fragments.
 // Rows are few (N or T*N) and the work is ~50 kMAC per row: the point is to keep library
@@ -19,13 +19,13 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kRows = 16;    // rows per wave: the N dimension of v_mfma_f32_16x16x4_f32
+constexpr int kRows = 16;    // rows per task: the N dimension of v_mfma_f32_16x16x4_f32
 constexpr int kMaxSlots = MMF_TRAJ_SLOTS;
 constexpr int kMaxVec = 128; // max vector width
 constexpr int kPad = 4;      // LDS row stride = width + 4 floats: the 16 rows x 4 k of a B fragment hit 64 banks
-constexpr int kWaves = 4;    // waves per workgroup
-// The launch sizes the slot file for what the program uses (n_slots, vector width 64 or 128): a 4-slot,
-// 64-wide program takes 17 KiB per wave, so two workgroups (8 waves) share a CU.
+constexpr int kWaves = 4;    // waves per workgroup = per task: one 16-output tile of a 64-wide layer each
+// The launch sizes the slot file for what the program uses (n_slots, vector width 64 or 128): a 5-slot,
+// 64-wide program takes 21 KiB per workgroup, so seven workgroups (28 waves) share a CU.
 
 struct IoPtrs {
   float* p[MMF_TRAJ_MAX_IO];
@@ -47,17 +47,23 @@ __device__ __forceinline__ float activate(float v, int act, float fparam) {
 // steps ascending), and the accumulators start at the bias: every row's outputs are the same fma chains in
 // the same order as the VALU formulation this replaces (and as oracle/strict restates them), whatever the
 // row's position in the batch.  Weights arrive pre-arranged per (source, group of 4 steps, tile) as one
-// 16-byte fragment per lane (trajprog.py), so a wave fetches 1 KB per load and a 64 x 64 layer costs
-// 16 loads per 16 rows -- half the L2 traffic per row of the 8-row VALU kernel.
-template <int MT>
+// 16-byte fragment per lane (trajprog.py / mmf_traj_pack).
+// Round 5: the four waves of a workgroup share ONE task of 16 rows -- wave w owns output tiles w (and w + 4 of a
+// 128-wide layer) -- so a 64 x 64 layer is 16 MFMAs per wave behind ONE round of fragment loads (all groups of a
+// source requested before the first MFMA) instead of 64 behind four dependent rounds: a program is a chain of L2
+// round trips, and at the T*N = 512 rows of a training step there is one task per CU and nothing else to hide them.
+// Which wave computes a tile does not change its chain: results are bit-identical to the one-wave form.
+template <int TPW>  // tiles per wave: 1 (out_dim <= 64) or 2
 __device__ __forceinline__ void linear_mfma(const MmfTrajInstr& I, const float* __restrict__ weights, float* slots, int ld,
-                                            int lane) {
+                                            int lane, int wave) {
+  constexpr int TT = 4 * TPW;  // tiles of the layer
   const int i = lane & 15, q = lane >> 4;
-  f32x4 acc[MT];
+  f32x4 acc[TPW];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    if (I.b_off >= 0) acc[mt] = *reinterpret_cast<const f32x4*>(weights + I.b_off + 16 * mt + 4 * q);
-    else acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < TPW; ++t) {
+    const int mt = wave + 4 * t;
+    if (I.b_off >= 0) acc[t] = *reinterpret_cast<const f32x4*>(weights + I.b_off + 16 * mt + 4 * q);
+    else acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float* w = weights + I.w_off + lane * 4;
 #pragma unroll 1
@@ -67,37 +73,50 @@ __device__ __forceinline__ void linear_mfma(const MmfTrajInstr& I, const float* 
     const int dim = I.src_dim[s];
     const int groups = (dim + 15) >> 4;
 #pragma unroll 1
-    for (int g = 0; g < groups; ++g) {
-      f32x4 a[MT];
+    for (int g0 = 0; g0 < groups; g0 += 4) {  // four groups (64 inputs) per round of loads
+      f32x4 a[4][TPW];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(w + (g * MT + mt) * 256);
-      float b[4];
+      for (int gg = 0; gg < 4; ++gg)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int k = 16 * g + 4 * ks + q;
-        b[ks] = k < dim ? xs[16 * g + 4 * ks] : 0.f;   // padded k: zero weight times a DEFINED zero
-      }
+        for (int t = 0; t < TPW; ++t) {
+          const int g = min(g0 + gg, groups - 1);  // a clamped duplicate is never multiplied
+          a[gg][t] = *reinterpret_cast<const f32x4*>(w + (g * TT + wave + 4 * t) * 256);
+        }
+      float b[4][4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int gg = 0; gg < 4; ++gg)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][ks], b[ks], acc[mt], 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks) {
+          const int k = 16 * (g0 + gg) + 4 * ks + q;
+          b[gg][ks] = k < dim ? xs[16 * (g0 + gg) + 4 * ks] : 0.f;   // padded k: zero weight times a DEFINED zero
+        }
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg)
+        if (g0 + gg < groups) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gg][t][ks], b[gg][ks], acc[t], 0, 0, 0);
+        }
     }
-    w += groups * MT * 256;
+    w += groups * TT * 256;
   }
-  // epilogue: (+ residual) activation, written back as 16-byte pieces; every source was read above, so dst may alias
+  // epilogue: (+ residual) activation, written back as 16-byte pieces.  dst may alias a source: every wave has read
+  // its sources before any wave writes
+  __syncthreads();
   const float* res = I.res >= 0 ? slots + I.res * (kRows * ld) + i * ld + I.dst_off : nullptr;
   float* dst = slots + I.dst * (kRows * ld) + i * ld + I.dst_off;
-  f32x4 out[MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+  for (int t = 0; t < TPW; ++t) {
+    const int mt = wave + 4 * t;
     f32x4 r = {0.f, 0.f, 0.f, 0.f};
     if (res) r = *reinterpret_cast<const f32x4*>(res + 16 * mt + 4 * q);
+    f32x4 out;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) out[mt][e] = activate(__fadd_rn(acc[mt][e], r[e]), I.act, I.fparam);
+    for (int e = 0; e < 4; ++e) out[e] = activate(__fadd_rn(acc[t][e], r[e]), I.act, I.fparam);
+    *reinterpret_cast<f32x4*>(dst + 16 * mt + 4 * q) = out;
   }
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(dst + 16 * mt + 4 * q) = out[mt];
 }
 
 __global__ __launch_bounds__(kWaves * MMF_WAVE) void traj_program_kernel(
@@ -106,11 +125,9 @@ __global__ __launch_bounds__(kWaves * MMF_WAVE) void traj_program_kernel(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ld = kVec + kPad;
-  const int waves = blockDim.x >> 6;  // 4, fewer when a wide program's slot file would not fit otherwise
-  float* slots = lds + wave * (n_slots * kRows * ld);  // [slot][row][ld]
-  const int wave_global = blockIdx.x * waves + wave, waves_total = gridDim.x * waves;
+  float* slots = lds;  // [slot][row][ld]: one task of 16 rows per workgroup
 
-  for (int task = wave_global; task * kRows < R; task += waves_total) {
+  for (int task = blockIdx.x; task * kRows < R; task += gridDim.x) {
     const int row0 = task * kRows;
     const int nrows = min(kRows, R - row0);
     for (int ip = 0; ip < n_instr; ++ip) {
@@ -120,8 +137,8 @@ __global__ __launch_bounds__(kWaves * MMF_WAVE) void traj_program_kernel(
         // stashed output).  Rows past the end repeat the last row: defined values that no STORE writes back.
         const float* src = io.p[I.io];
         float* dst = slots + I.dst * (kRows * ld) + I.dst_off;
-#pragma unroll 4
-        for (int r = 0; r < kRows; ++r) {
+#pragma unroll
+        for (int r = wave; r < kRows; r += kWaves) {
           const size_t g = static_cast<size_t>(row0 + min(r, nrows - 1)) * I.io_stride + I.io_off;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
@@ -138,20 +155,20 @@ __global__ __launch_bounds__(kWaves * MMF_WAVE) void traj_program_kernel(
       } else if (I.op == MMF_TRAJ_ADD || I.op == MMF_TRAJ_ZERO) {
         float* dst = slots + I.dst * (kRows * ld) + I.dst_off;
         const float* src = I.op == MMF_TRAJ_ADD ? slots + I.src[0] * (kRows * ld) + I.src_off[0] : nullptr;
-#pragma unroll 4
-        for (int r = 0; r < kRows; ++r)
+#pragma unroll
+        for (int r = wave; r < kRows; r += kWaves)
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const int c = lane + 64 * h;
             if (c < I.out_dim) dst[r * ld + c] = src ? __fadd_rn(dst[r * ld + c], src[r * ld + c]) : 0.f;
           }
       } else if (I.op == MMF_TRAJ_LINEAR) {
-        if (I.out_dim > 64) linear_mfma<8>(I, weights, slots, ld, lane);
-        else linear_mfma<4>(I, weights, slots, ld, lane);
+        if (I.out_dim > 64) linear_mfma<2>(I, weights, slots, ld, lane, wave);
+        else linear_mfma<1>(I, weights, slots, ld, lane, wave);
       } else {  // STORE / STORE_DIAG
         float* out = io.p[I.io];
         const float* src = slots + I.src[0] * (kRows * ld) + I.src_off[0];
-        for (int r = 0; r < nrows; ++r) {
+        for (int r = wave; r < nrows; r += kWaves) {
           const size_t g = static_cast<size_t>(row0 + r) * I.io_stride + I.io_off;
           if (I.op == MMF_TRAJ_STORE) {
             if (lane < I.out_dim) out[g + lane] = activate(src[r * ld + lane], I.act, I.fparam);
@@ -165,6 +182,7 @@ __global__ __launch_bounds__(kWaves * MMF_WAVE) void traj_program_kernel(
           }
         }
       }
+      __syncthreads();  // the next instruction reads what any wave of this one wrote (and the next task reuses the slots)
     }
   }
 }
@@ -207,25 +225,17 @@ extern "C" int mmf_traj_program(const MmfTrajInstr* prog, int n_instr, const flo
   if (R == 0) return 0;
   IoPtrs p{};
   for (int i = 0; i < MMF_TRAJ_MAX_IO; ++i) p.p[i] = io[i];
-  const size_t per_wave = static_cast<size_t>(n_slots) * kRows * (vec_width + kPad) * sizeof(float);
-  if (per_wave > 160 * 1024) return MMF_ETOOLARGE;
-  // waves per workgroup: whatever puts the most waves on a CU (the kernel is a chain of L2 round trips: what
-  // it needs is waves to switch to).  A 5-slot, 64-wide program takes 21 KB per wave: as a 4-wave workgroup
-  // one fits a CU (4 waves), as 1-wave workgroups seven do.
-  int waves = 1, best = 0;
-  for (int w = kWaves; w >= 1; w >>= 1) {
-    const int on_cu = w * static_cast<int>((160 * 1024) / (w * per_wave));
-    if (on_cu > best) { best = on_cu; waves = w; }
-  }
-  const size_t lds = per_wave * waves;
+  const size_t lds = static_cast<size_t>(n_slots) * kRows * (vec_width + kPad) * sizeof(float);  // one task's slot file
+  if (lds > 160 * 1024) return MMF_ETOOLARGE;
   auto k = traj_program_kernel;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
   if (e != hipSuccess) return static_cast<int>(e);
   const int tasks = (R + kRows - 1) / kRows;
-  int grid = (tasks + waves - 1) / waves;
-  const int per_cu = static_cast<int>((160 * 1024) / lds) < 16 ? static_cast<int>((160 * 1024) / lds) : 16;
-  if (grid > 256 * per_cu) grid = 256 * per_cu;
+  // a 5-slot, 64-wide program takes 21 KB per task: seven workgroups (28 waves) share a CU
+  const int per_cu = static_cast<int>((160 * 1024) / lds) < 8 ? static_cast<int>((160 * 1024) / lds) : 8;
+  int grid = tasks < 256 * per_cu ? tasks : 256 * per_cu;
+  const int waves = kWaves;
   k<<<grid, waves * MMF_WAVE, lds, static_cast<hipStream_t>(stream)>>>(prog, n_instr, weights, p, R, n_slots, vec_width);
   MMF_CHECK_LAUNCH();
   return 0;

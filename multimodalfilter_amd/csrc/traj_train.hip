@@ -79,12 +79,12 @@ __global__ void sum_slices_kernel(const float* __restrict__ partials, float* __r
 // y (R, 64) = x (R, K) w^T + b.  A workgroup owns 16 rows; its waves split K and meet in LDS in wave order.  M = outputs,
 // N = rows, contraction over k: lane (i, q) loads the 16 bytes x[row i][16 g + 4 q ..] and w[16 mt + i][16 g + 4 q ..]
 // and feeds them to four MFMA steps element by element (any bijection of k onto steps is the same dot product).
-constexpr int kFcWaves = 8;
+constexpr int kFcWaves = 16;
 
 __global__ __launch_bounds__(kFcWaves * MMF_WAVE) void fc64_forward_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                          const float* __restrict__ bias, float* __restrict__ y,
                                                                          int R, int K) {
-  __shared__ f32x4 red[kFcWaves][4][64];
+  __shared__ f32x4 red[kFcWaves - 1][4][64];   // 60 KB
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
   const int row0 = blockIdx.x * 16;
   const int row = min(row0 + i, R - 1);
@@ -105,13 +105,19 @@ __global__ __launch_bounds__(kFcWaves * MMF_WAVE) void fc64_forward_kernel(const
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma4(a[mt][e], b[e], acc[mt]);
   }
+  // wave mt sums output tile mt over the K slices in slice order; slice 0's tile 0 never leaves wave 0's registers
+  __shared__ f32x4 first[3][64];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) red[wave][mt][lane] = acc[mt];
+  for (int mt = 0; mt < 4; ++mt) {
+    if (wave > 0) red[wave - 1][mt][lane] = acc[mt];
+    else if (mt > 0) first[mt - 1][lane] = acc[mt];
+  }
   __syncthreads();
-  if (wave < 4) {  // wave mt sums output tile mt over the K slices, in order
+  if (wave < 4) {
     const int mt = wave;
-    f32x4 s = red[0][mt][lane];
-    for (int k = 1; k < kFcWaves; ++k) {
+    f32x4 s = acc[0];
+    if (mt > 0) s = first[mt - 1][lane];
+    for (int k = 0; k < kFcWaves - 1; ++k) {
       const f32x4 v = red[k][mt][lane];
 #pragma unroll
       for (int e = 0; e < 4; ++e) s[e] = __fadd_rn(s[e], v[e]);
@@ -149,50 +155,52 @@ __global__ __launch_bounds__(256) void fc64_backward_data_kernel(const float* __
 }
 
 // dw (64, K) = g^T x.  M = outputs, N = columns, contraction over rows: lane (i, q) supplies A = g[row 4 s + q][16 mt + i]
-// and B = x[row 4 s + q][16 ct + i].  A workgroup owns 64 columns (256 contiguous bytes of every row of x); its four
-// waves split the rows into four runs and meet in LDS in wave order.  Block 0 also writes db.
-__global__ __launch_bounds__(256) void fc64_backward_weights_kernel(const float* __restrict__ g, const float* __restrict__ x,
-                                                                   float* __restrict__ dw, float* __restrict__ db, int R,
-                                                                   int K) {
-  __shared__ f32x4 red[3][16][64];
+// and B = x[row 4 s + q][16 ct + i].  A workgroup owns 32 columns (128 contiguous bytes of every row of x); its eight
+// waves split the rows into eight runs and meet in LDS in wave order.  Block 0 also writes db.
+constexpr int kFcwWaves = 8;
+
+__global__ __launch_bounds__(kFcwWaves * MMF_WAVE) void fc64_backward_weights_kernel(const float* __restrict__ g,
+                                                                                   const float* __restrict__ x,
+                                                                                   float* __restrict__ dw, float* __restrict__ db,
+                                                                                   int R, int K) {
+  __shared__ f32x4 red[kFcwWaves - 1][8][64];   // 56 KB
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
-  const int col0 = blockIdx.x * 64;
-  const int run = ((R + 15) / 16) * 4;  // rows per wave, a multiple of 4
+  const int col0 = blockIdx.x * 32;
+  const int run = ((R + 4 * kFcwWaves - 1) / (4 * kFcwWaves)) * 4;  // rows per wave, a multiple of 4
   const int r0 = wave * run, r1 = min(R, r0 + run);
-  f32x4 acc[4][4];  // [mt][ct]
+  f32x4 acc[4][2];  // [mt][ct]
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) acc[mt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+    for (int ct = 0; ct < 2; ++ct) acc[mt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
   for (int r = r0; r < r1; r += 4) {
     const int row = r + q;
     const bool ok = row < r1;
-    float a[4], b[4];
+    float a[4], b[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      a[t] = ok ? g[static_cast<size_t>(row) * 64 + 16 * t + i] : 0.f;
-      b[t] = ok ? x[static_cast<size_t>(row) * K + col0 + 16 * t + i] : 0.f;
-    }
+    for (int t = 0; t < 4; ++t) a[t] = ok ? g[static_cast<size_t>(row) * 64 + 16 * t + i] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) b[t] = ok ? x[static_cast<size_t>(row) * K + col0 + 16 * t + i] : 0.f;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) acc[mt][ct] = mfma4(a[mt], b[ct], acc[mt][ct]);
+      for (int ct = 0; ct < 2; ++ct) acc[mt][ct] = mfma4(a[mt], b[ct], acc[mt][ct]);
   }
   if (wave > 0)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) red[wave - 1][4 * mt + ct][lane] = acc[mt][ct];
+      for (int ct = 0; ct < 2; ++ct) red[wave - 1][2 * mt + ct][lane] = acc[mt][ct];
   __syncthreads();
   if (wave == 0) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
+      for (int ct = 0; ct < 2; ++ct) {
         f32x4 s = acc[mt][ct];
-        for (int k = 0; k < 3; ++k) {
-          const f32x4 v = red[k][4 * mt + ct][lane];
+        for (int k = 0; k < kFcwWaves - 1; ++k) {
+          const f32x4 v = red[k][2 * mt + ct][lane];
 #pragma unroll
           for (int e = 0; e < 4; ++e) s[e] = __fadd_rn(s[e], v[e]);
         }
@@ -200,10 +208,10 @@ __global__ __launch_bounds__(256) void fc64_backward_weights_kernel(const float*
         for (int e = 0; e < 4; ++e) dw[static_cast<size_t>(16 * mt + 4 * q + e) * K + col0 + 16 * ct + i] = s[e];
       }
   }
-  if (db && blockIdx.x == 0 && threadIdx.x < 64) {  // after the products: one thread per output, rows in order
+  if (db && blockIdx.x == gridDim.x - 1 && wave == 1) {  // a wave with nothing left to do: one lane per output, rows in order
     float s = 0.f;
-    for (int r = 0; r < R; ++r) s = __fadd_rn(s, g[static_cast<size_t>(r) * 64 + threadIdx.x]);
-    db[threadIdx.x] = s;
+    for (int r = 0; r < R; ++r) s = __fadd_rn(s, g[static_cast<size_t>(r) * 64 + lane]);
+    db[lane] = s;
   }
 }
 
@@ -227,7 +235,7 @@ extern "C" int mmf_traj_weight_grads(const MmfTrajGradDesc* desc, int n_desc, co
 }
 
 extern "C" int mmf_fc64_train_forward(const float* x, const float* w, const float* b, float* y, int R, int K, void* stream) {
-  if (!x || !w || !y || R < 0 || K < 128 || K % 128) return MMF_EINVAL;
+  if (!x || !w || !y || R < 0 || K < 256 || K % 256) return MMF_EINVAL;
   if (R == 0) return 0;
   fc64_forward_kernel<<<(R + 15) / 16, kFcWaves * MMF_WAVE, 0, static_cast<hipStream_t>(stream)>>>(x, w, b, y, R, K);
   MMF_CHECK_LAUNCH();
@@ -236,7 +244,7 @@ extern "C" int mmf_fc64_train_forward(const float* x, const float* w, const floa
 
 extern "C" int mmf_fc64_train_backward(const float* g, const float* x, const float* w, float* dx, float* dw, float* db,
                                        int R, int K, void* stream) {
-  if (!g || !x || !w || !dw || R < 0 || K < 128 || K % 128) return MMF_EINVAL;
+  if (!g || !x || !w || !dw || R < 0 || K < 256 || K % 256) return MMF_EINVAL;
   auto s = static_cast<hipStream_t>(stream);
   if (R == 0) {
     hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * 64 * static_cast<size_t>(K), s);
@@ -249,7 +257,7 @@ extern "C" int mmf_fc64_train_backward(const float* g, const float* x, const flo
     fc64_backward_data_kernel<<<dim3((R + 15) / 16, (K + cols - 1) / cols), 256, 0, s>>>(g, w, dx, R, K, cols);
     MMF_CHECK_LAUNCH();
   }
-  fc64_backward_weights_kernel<<<K / 64, 256, 0, s>>>(g, x, dw, db, R, K);
+  fc64_backward_weights_kernel<<<K / 32, kFcwWaves * MMF_WAVE, 0, s>>>(g, x, dw, db, R, K);
   MMF_CHECK_LAUNCH();
   return 0;
 }

@@ -155,11 +155,15 @@ class TrajProgram:
         if self._blob is not None and stamp == self._stamp:
             return
         device = torch.device(device)
-        addr = tuple((p.data_ptr(), str(p.device)) for p in params)
+        # parameters that do not live on the device as contiguous fp32 (a host-resident user model) are staged: the table
+        # then follows the copies' addresses and is rebuilt with them
+        srcs = [p if (p.dtype == torch.float32 and p.is_contiguous() and p.device == device)
+                else p.detach().to(device=device, dtype=torch.float32).contiguous() for p in params]
+        self._pack_keep = srcs
+        addr = tuple((p.data_ptr(), str(p.device)) for p in srcs)
         if self._pack is None or self._pack[0] != addr:
             descs, off = [], 0
-            for kind, p, cols, out_pad in self._blob_parts:
-                assert p.dtype == torch.float32 and p.is_contiguous() and p.device == device, "fp32 parameters on the device"
+            for (kind, _p, cols, out_pad), p in zip(self._blob_parts, srcs):
                 if kind == "wT":
                     c0, _c1, dims = cols
                     col = c0
@@ -463,8 +467,9 @@ class TrajProgramFunction(torch.autograd.Function):
                 io[plan.bwd_io["g:" + n]] = d_in[n]
         _abi.traj_program(bwd, len(plan.bwd), plan.transposed_blob(dev), io, R, *_footprint_of(plan.bwd))
         grads = torch.zeros(plan.n_grads, dtype=torch.float32, device=dev)
-        n_slices = 1 if R <= 2048 else min(64, -(-R // 1024))
-        partials = torch.empty((n_slices, plan.n_grads), dtype=torch.float32, device=dev) if n_slices > 1 else None
+        n_slices = 1 if R <= 64 else min(64, -(-R // 64))   # the kernel is a chain of loads per 4 rows: short runs, summed in order
+        # zeros: the columns of a layer that the program does not multiply (the per-particle half of a join layer) are summed too
+        partials = torch.zeros((n_slices, plan.n_grads), dtype=torch.float32, device=dev) if n_slices > 1 else None
         _abi.traj_weight_grads(desc, len(plan.desc), stash, dz, grads, partials, n_slices, R)
         per_param = []
         for p in plan.params:

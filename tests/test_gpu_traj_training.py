@@ -111,6 +111,9 @@ def _check(model, inputs, out_names, R, tol_param):
         w = torch.randn(ref_out[name].shape, generator=g)
         loss_e = loss_e + (outs[name] * w.to(dev)).sum()
         loss_r = loss_r + (ref_out[name] * w.double()).sum()
+    for n in (1 << 12, 1 << 16, 1 << 20, 1 << 22):   # whatever block the allocator hands the backward has held NaNs
+        junk = torch.full((n,), float("nan"), device=dev)
+        del junk
     loss_e.backward()
     loss_r.backward()
     assert _rel(dev_in["feat"].grad, ref_in["feat"].grad) < 1e-5, "d feat"
@@ -165,7 +168,7 @@ def test_traj_program_weights_follow_in_place_parameter_updates():
     assert float((b - ref).abs().max()) < 1e-5 and float((a - b).abs().max()) > 1e-4
 
 
-@pytest.mark.parametrize("R,K", [(1, 128), (16, 8192), (37, 8192), (512, 8192), (100, 1024)])
+@pytest.mark.parametrize("R,K", [(1, 256), (16, 8192), (37, 8192), (512, 8192), (100, 1024)])
 def test_fc64_training_kernels_match_fp64(R, K):
     from multimodalfilter_amd import _abi
 
