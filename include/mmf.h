@@ -602,6 +602,23 @@ typedef struct MmfPfTrainArgs {
 int mmf_pf_train_forward(const MmfPfTrainArgs* args /* host */, void* stream);
 int mmf_pf_train_backward(const MmfPfTrainArgs* args /* host */, void* stream);
 
+/* After mmf_pf_train_backward: one network's partial sums -> its parameter gradients in the order and layout of the
+ * nn.Module parameters the reference's optimiser walks (train_helpers.py:124-162: torch autograd produces them per
+ * parameter), plus the gradient of its hoisted per-trajectory term and of its modality log-weight column.
+ *  grads      flat: w_in (64, d) | b_in (64) | encoder block1 w (64, 64), b | block2 w, b | join w (64, join_in: columns
+ *             outside [join_state_off, +64) are zero) | per residual block: block1 w, b, block2 w, b | head w (n_out, 64) |
+ *             head b (n_out)
+ *  bias_grad  (T N, 64);  d_beta (T N, beta_stride) or null: column beta_col is written
+ *  pw (NL + 1, S, 64, 64), pb (NL + 1, S, 64), p_first (T, N SL, 64, 4), p_head (T, N SL, 4, 64), p_dout (T, N SL, 4),
+ *  p_traj (T, N SL, 64): MmfTrainNet's buffers (NL = 3 + 2 n_res); fused: the first-layer bias is column d of p_first
+ *  scratch    32 x 516 floats */
+typedef struct MmfPfTrainFinalizeArgs {
+  int32_t T, N, SL, S, n_res, d, n_out, join_in, join_state_off, fused, beta_stride, beta_col;
+  const float *pw, *pb, *p_first, *p_head, *p_dout, *p_traj;
+  float *grads, *bias_grad, *d_beta, *scratch;
+} MmfPfTrainFinalizeArgs;
+int mmf_pf_train_finalize(const MmfPfTrainFinalizeArgs* args /* host */, void* stream);
+
 /* ---------------------------------------------------------------- K7: per-trajectory MLP programs
  * The N-row networks around the filters (vector encoders layers.py:11-40,66-95; PF weight
  * model crossmodal_pf.py:74-106; virtual sensor kf.py:81-126; EKF weight model
@@ -704,10 +721,11 @@ int mmf_traj_weight_grads(const MmfTrajGradDesc* desc, int n_desc, const float* 
 /* The 8192 -> 64 linear layer behind the convolutions of a training step (door_models/layers.py:59-60, the
  * nn.Linear(8 * 32 * 32, units) of the image encoder), forward and both backward products in exact fp32 on
  * v_mfma_f32_16x16x4_f32, fixed summation order; replaces the library GEMMs of torch's Linear forward / backward.
- *  x (R, K) fp32, w (64, K) row-major = nn.Linear.weight, b (64) or null, K % 256 == 0
- *   forward:  y (R, 64) = x w^T + b
+ *  x (R, K) fp32, w (64, K) row-major = nn.Linear.weight, b (64) or null, K % 512 == 0
+ *   forward:  y (R, 64) = x w^T + b; partial: scratch (K / 512, R, 64) -- the K chunks meet in ascending order
  *   backward: dx (R, K) = g w (null: skipped);  dw (64, K) = g^T x;  db (64) = column sums of g (null: skipped) */
-int mmf_fc64_train_forward(const float* x, const float* w, const float* b, float* y, int R, int K, void* stream);
+int mmf_fc64_train_forward(const float* x, const float* w, const float* b, float* y, float* partial, int R, int K,
+                           void* stream);
 int mmf_fc64_train_backward(const float* g, const float* x, const float* w, float* dx, float* dw, float* db, int R,
                             int K, void* stream);
 

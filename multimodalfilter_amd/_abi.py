@@ -51,6 +51,12 @@ class MmfTrajInstr(Structure):
                 ("fparam", c_float), ("dst_off", c_int32)]
 
 
+class MmfPfTrainFinalizeArgs(Structure):
+    _fields_ = [(n, c_int32) for n in ("T", "N", "SL", "S", "n_res", "d", "n_out", "join_in", "join_state_off", "fused",
+                                       "beta_stride", "beta_col")] + \
+               [(n, c_void_p) for n in ("pw", "pb", "p_first", "p_head", "p_dout", "p_traj", "grads", "bias_grad", "d_beta", "scratch")]
+
+
 class MmfTrajPackDesc(Structure):
     _fields_ = [("src", c_uint64), ("kind", c_int32), ("rows", c_int32), ("ld", c_int32), ("col0", c_int32), ("dim", c_int32),
                 ("out_pad", c_int32), ("dst_off", c_int32), ("reserved", c_int32)]
@@ -156,9 +162,10 @@ SIGNATURES = {
     "mmf_philox_uniforms": (c_int, [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _FP, c_int, c_int, c_void_p]),
     "mmf_dynamics_forward_loop": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_traj_program": (c_int, [_FP, c_int, _FP, POINTER(c_void_p), c_int, c_int, c_int, c_void_p]),
+    "mmf_pf_train_finalize": (c_int, [POINTER(MmfPfTrainFinalizeArgs), c_void_p]),
     "mmf_traj_pack": (c_int, [c_void_p, c_int, _FP, c_void_p]),
     "mmf_traj_weight_grads": (c_int, [c_void_p, c_int, _FP, c_int, _FP, c_int, _FP, c_int, _FP, c_int, c_int, c_void_p]),
-    "mmf_fc64_train_forward": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
+    "mmf_fc64_train_forward": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_fc64_train_backward": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_fuse_virtual_sensors": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_ekf_forward_loop": (c_int, [POINTER(MmfEkfLoopArgs), c_void_p]),
@@ -514,6 +521,11 @@ def traj_program(prog: torch.Tensor, n_instr: int, weights: torch.Tensor, io_ten
                                        n_slots, vec_width, stream_of(weights)), "mmf_traj_program")
 
 
+def pf_train_finalize(args: MmfPfTrainFinalizeArgs, like: torch.Tensor):
+    with _on(like):
+        _check(load().mmf_pf_train_finalize(ctypes.byref(args), stream_of(like)), "mmf_pf_train_finalize")
+
+
 def traj_pack(desc: torch.Tensor, n_desc: int, blob: torch.Tensor):
     with _on(blob):
         _check(load().mmf_traj_pack(ptr(desc, dtype=torch.uint8), n_desc, ptr(blob), stream_of(blob)), "mmf_traj_pack")
@@ -530,8 +542,10 @@ def traj_weight_grads(desc: torch.Tensor, n_desc: int, stash: torch.Tensor, dz: 
 
 def fc64_train_forward(x, w, b, y):
     R, K = x.shape
+    partial = torch.empty((max(1, K // 512), R, 64), dtype=torch.float32, device=x.device)
     with _on(x):
-        _check(load().mmf_fc64_train_forward(ptr(x), ptr(w), ptr(b), ptr(y), R, K, stream_of(x)), "mmf_fc64_train_forward")
+        _check(load().mmf_fc64_train_forward(ptr(x), ptr(w), ptr(b), ptr(y), ptr(partial), R, K, stream_of(x)),
+               "mmf_fc64_train_forward")
 
 
 def fc64_train_backward(g, x, w, dx, dw, db):

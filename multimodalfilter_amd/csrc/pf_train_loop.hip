@@ -309,3 +309,104 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
   }
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// What is left after the recursion: the partial sums of one network -- a weight-gradient slot per workgroup (pw, pb), the
+// narrow reductions per (step, trajectory, slice) (p_first, p_head, p_dout, p_traj) -- become the network's parameter
+// gradients in the order and layout of its nn.Module parameters, the gradient of its hoisted per-trajectory term and of
+// its modality log-weight column.  Round 4 left this to ~20 torch reductions / copies per network and step.  Every sum runs
+// in ascending index order: reproducible run to run.
+namespace {
+
+constexpr int kFinChunks = 32;
+constexpr int kFinSmall = 2 * MMF_UNITS * 4 + 4;  // first (64 x 4) | head (4 x 64) | d out (4)
+
+// stage 1: the long sums (T * N * SL terms each), cut into kFinChunks runs
+__global__ __launch_bounds__(256) void train_finalize_partial_kernel(MmfPfTrainFinalizeArgs a, float* __restrict__ partial) {
+  const int terms = a.T * a.N * a.SL;
+  const int per = (terms + kFinChunks - 1) / kFinChunks;
+  const int t0 = blockIdx.x * per, t1 = min(terms, t0 + per);
+  for (int e = threadIdx.x; e < kFinSmall; e += blockDim.x) {
+    float s = 0.f;
+    if (e < 256) {
+      for (int t = t0; t < t1; ++t) s = __fadd_rn(s, a.p_first[static_cast<size_t>(t) * 256 + e]);
+    } else if (e < 512) {
+      for (int t = t0; t < t1; ++t) s = __fadd_rn(s, a.p_head[static_cast<size_t>(t) * 256 + (e - 256)]);
+    } else {
+      for (int t = t0; t < t1; ++t) s = __fadd_rn(s, a.p_dout[static_cast<size_t>(t) * 4 + (e - 512)]);
+    }
+    partial[blockIdx.x * kFinSmall + e] = s;
+  }
+}
+
+__device__ __forceinline__ float sum_strided(const float* p, int n, size_t stride) {
+  float s = 0.f;
+  for (int k = 0; k < n; ++k) s = __fadd_rn(s, p[k * stride]);
+  return s;
+}
+
+// stage 2: one thread per output value
+__global__ __launch_bounds__(256) void train_finalize_kernel(MmfPfTrainFinalizeArgs a, const float* __restrict__ partial) {
+  const int U = MMF_UNITS, UU = U * U;
+  const int NL = 3 + 2 * a.n_res;
+  // flat layout of grads = the parameters' order: w_in (U x d) | b_in (U) | enc block1 w, b | enc block2 w, b |
+  // join w (U x join_in) | per residual block: block1 w, b, block2 w, b | head w (n_out x U) | head b (n_out)
+  const int o_win = 0, o_bin = o_win + U * a.d, o_enc = o_bin + U, o_join = o_enc + 2 * (UU + U);
+  const int o_res = o_join + U * a.join_in, o_head = o_res + a.n_res * 2 * (UU + U), o_hb = o_head + a.n_out * U;
+  const int n_param = o_hb + a.n_out;
+  const int TN = a.T * a.N;
+  const int n_traj = TN * U;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n_param) {
+    float v;
+    if (e < o_bin) {                       // first-layer weights
+      const int u = e / a.d, c = e % a.d;
+      v = sum_strided(partial + u * 4 + c, kFinChunks, kFinSmall);
+    } else if (e < o_enc) {                // first-layer bias: column d of the narrow reduction (fused) or slot NL of pb
+      const int u = e - o_bin;
+      v = a.fused ? sum_strided(partial + u * 4 + a.d, kFinChunks, kFinSmall)
+                  : sum_strided(a.pb + static_cast<size_t>(NL) * a.S * U + u, a.S, U);
+    } else if (e < o_join || (e >= o_res && e < o_head)) {   // a 64 x 64 layer's weights or bias
+      int r = e < o_join ? e - o_enc : e - o_res;
+      const int blk = r / (UU + U);
+      r -= blk * (UU + U);
+      const int layer = (e < o_join ? 0 : 3) + blk;
+      v = r < UU ? sum_strided(a.pw + static_cast<size_t>(layer) * a.S * UU + r, a.S, UU)
+                 : sum_strided(a.pb + static_cast<size_t>(layer) * a.S * U + (r - UU), a.S, U);
+    } else if (e < o_res) {                // join layer: only the state columns belong to this network
+      const int u = (e - o_join) / a.join_in, c = (e - o_join) % a.join_in - a.join_state_off;
+      v = (c >= 0 && c < U) ? sum_strided(a.pw + static_cast<size_t>(2) * a.S * UU + u * U + c, a.S, UU) : 0.f;
+    } else if (e < o_hb) {                 // head weights
+      v = sum_strided(partial + 256 + (e - o_head), kFinChunks, kFinSmall);
+    } else {
+      v = sum_strided(partial + 512 + (e - o_hb), kFinChunks, kFinSmall);
+    }
+    a.grads[e] = v;
+  } else if (e < n_param + n_traj) {       // gradient of the hoisted per-trajectory term
+    const int j = e - n_param, tn = j / U, u = j % U;
+    a.bias_grad[j] = sum_strided(a.p_traj + (static_cast<size_t>(tn) * a.SL) * U + u, a.SL, U);
+  } else if (e < n_param + n_traj + TN) {  // gradient of the modality log-weight column
+    const int tn = e - n_param - n_traj;
+    if (a.d_beta) a.d_beta[static_cast<size_t>(tn) * a.beta_stride + a.beta_col] =
+        sum_strided(a.p_dout + (static_cast<size_t>(tn) * a.SL) * 4, a.SL, 4);
+  }
+}
+
+}  // namespace
+
+extern "C" int mmf_pf_train_finalize(const MmfPfTrainFinalizeArgs* a, void* stream) {
+  if (!a || !a->pw || !a->pb || !a->p_first || !a->p_head || !a->p_dout || !a->p_traj || !a->grads || !a->bias_grad || !a->scratch)
+    return MMF_EINVAL;
+  if (a->d < 1 || a->d > 3 || a->n_out < 1 || a->n_out > 4 || a->n_res < 0 || a->S < 1 || a->SL < 1 || a->T < 1 || a->N < 1)
+    return MMF_EINVAL;
+  if (a->join_state_off < 0 || a->join_state_off + MMF_UNITS > a->join_in) return MMF_EINVAL;
+  auto s = static_cast<hipStream_t>(stream);
+  train_finalize_partial_kernel<<<kFinChunks, 256, 0, s>>>(*a, a->scratch);
+  MMF_CHECK_LAUNCH();
+  const int U = MMF_UNITS;
+  const int n_param = U * a->d + U + (2 + 2 * a->n_res) * (U * U + U) + U * a->join_in + a->n_out * U + a->n_out;
+  const int n = n_param + a->T * a->N * U + a->T * a->N;
+  train_finalize_kernel<<<(n + 255) / 256, 256, 0, s>>>(*a, a->scratch);
+  MMF_CHECK_LAUNCH();
+  return 0;
+}

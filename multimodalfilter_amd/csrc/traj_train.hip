@@ -76,59 +76,68 @@ __global__ void sum_slices_kernel(const float* __restrict__ partials, float* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// y (R, 64) = x (R, K) w^T + b.  A workgroup owns 16 rows; its waves split K and meet in LDS in wave order.  M = outputs,
-// N = rows, contraction over k: lane (i, q) loads the 16 bytes x[row i][16 g + 4 q ..] and w[16 mt + i][16 g + 4 q ..]
-// and feeds them to four MFMA steps element by element (any bijection of k onto steps is the same dot product).
-constexpr int kFcWaves = 16;
+// y (R, 64) = x (R, K) w^T + b.  grid = (16-row tiles, K chunks): a workgroup's four waves split its chunk, meet in LDS in
+// wave order and write ONE partial; fc64_sum_kernel adds the chunks in order and the bias.  M = outputs, N = rows,
+// contraction over k: lane (i, q) loads the 16 bytes x[row i][16 g + 4 q ..] and w[16 mt + i][16 g + 4 q ..] and feeds
+// them to four MFMA steps element by element (any bijection of k onto steps is the same dot product).  With R = 512 the
+// product is 0.5 GFLOP on 16 MB of x: what matters is that no wave walks a long chain of dependent round trips.
+constexpr int kFcWaves = 4;
+constexpr int kFcChunk = 512;      // k per workgroup
+constexpr int kFcGroups = kFcChunk / kFcWaves / 16;  // 16-k groups per wave: 8, all requested up front
 
 __global__ __launch_bounds__(kFcWaves * MMF_WAVE) void fc64_forward_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                         const float* __restrict__ bias, float* __restrict__ y,
-                                                                         int R, int K) {
-  __shared__ f32x4 red[kFcWaves - 1][4][64];   // 60 KB
+                                                                         float* __restrict__ partial, int R, int K) {
+  __shared__ f32x4 red[kFcWaves - 1][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
   const int row0 = blockIdx.x * 16;
   const int row = min(row0 + i, R - 1);
-  const int kw = K / kFcWaves;
-  const float* px = x + static_cast<size_t>(row) * K + wave * kw + 4 * q;
-  const float* pw = w + static_cast<size_t>(i) * K + wave * kw + 4 * q;
+  const int k0 = blockIdx.y * kFcChunk + wave * (kFcChunk / kFcWaves) + 4 * q;
+  const float* px = x + static_cast<size_t>(row) * K + k0;
+  const float* pw = w + static_cast<size_t>(i) * K + k0;
+  f32x4 b[kFcGroups], a[kFcGroups][4];
+#pragma unroll
+  for (int g = 0; g < kFcGroups; ++g) {
+    b[g] = *reinterpret_cast<const f32x4*>(px + 16 * g);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) a[g][mt] = *reinterpret_cast<const f32x4*>(pw + static_cast<size_t>(16 * mt) * K + 16 * g);
+  }
   f32x4 acc[4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-  for (int g = 0; g < kw; g += 16) {
-    const f32x4 b = *reinterpret_cast<const f32x4*>(px + g);
-    f32x4 a[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(pw + static_cast<size_t>(16 * mt) * K + g);
+  for (int g = 0; g < kFcGroups; ++g)
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma4(a[mt][e], b[e], acc[mt]);
-  }
-  // wave mt sums output tile mt over the K slices in slice order; slice 0's tile 0 never leaves wave 0's registers
-  __shared__ f32x4 first[3][64];
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma4(a[g][mt][e], b[g][e], acc[mt]);
+  if (wave > 0)
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    if (wave > 0) red[wave - 1][mt][lane] = acc[mt];
-    else if (mt > 0) first[mt - 1][lane] = acc[mt];
-  }
+    for (int mt = 0; mt < 4; ++mt) red[wave - 1][mt][lane] = acc[mt];
   __syncthreads();
-  if (wave < 4) {
-    const int mt = wave;
-    f32x4 s = acc[0];
-    if (mt > 0) s = first[mt - 1][lane];
-    for (int k = 0; k < kFcWaves - 1; ++k) {
-      const f32x4 v = red[k][mt][lane];
+  if (wave == 0 && row0 + i < R) {
+    float* dst = partial + (static_cast<size_t>(blockIdx.y) * R + row0 + i) * 64;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s[e] = __fadd_rn(s[e], v[e]);
-    }
-    if (bias) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 16 * mt + 4 * q);
+    for (int mt = 0; mt < 4; ++mt) {
+      f32x4 s = acc[mt];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s[e] = __fadd_rn(s[e], bv[e]);
+      for (int k = 0; k < kFcWaves - 1; ++k) {
+        const f32x4 v = red[k][mt][lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = __fadd_rn(s[e], v[e]);
+      }
+      *reinterpret_cast<f32x4*>(dst + 16 * mt + 4 * q) = s;
     }
-    if (row0 + i < R) *reinterpret_cast<f32x4*>(y + static_cast<size_t>(row0 + i) * 64 + 16 * mt + 4 * q) = s;
   }
+}
+
+// y[j] = sum over chunks (ascending) of partial[chunk][j] + bias[j & 63]
+__global__ void fc64_sum_kernel(const float* __restrict__ partial, const float* __restrict__ bias, float* __restrict__ y, int n,
+                                int chunks) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  float s = partial[j];
+  for (int k = 1; k < chunks; ++k) s = __fadd_rn(s, partial[static_cast<size_t>(k) * n + j]);
+  y[j] = bias ? __fadd_rn(s, bias[j & 63]) : s;
 }
 
 // dx (R, K) = g (R, 64) w (64, K).  M = columns of dx, N = rows, contraction over the 64 outputs: lane (i, q) holds
@@ -208,10 +217,19 @@ __global__ __launch_bounds__(kFcwWaves * MMF_WAVE) void fc64_backward_weights_ke
         for (int e = 0; e < 4; ++e) dw[static_cast<size_t>(16 * mt + 4 * q + e) * K + col0 + 16 * ct + i] = s[e];
       }
   }
-  if (db && blockIdx.x == gridDim.x - 1 && wave == 1) {  // a wave with nothing left to do: one lane per output, rows in order
+  if (db && blockIdx.x == gridDim.x - 1) {  // column sums of g: wave v adds rows v, v + 8, ..; the eight meet in order
+    __syncthreads();
     float s = 0.f;
-    for (int r = 0; r < R; ++r) s = __fadd_rn(s, g[static_cast<size_t>(r) * 64 + lane]);
-    db[lane] = s;
+#pragma unroll 8
+    for (int r = wave; r < R; r += kFcwWaves) s = __fadd_rn(s, g[static_cast<size_t>(r) * 64 + lane]);
+    float* part = reinterpret_cast<float*>(red);
+    part[wave * 64 + lane] = s;
+    __syncthreads();
+    if (wave == 0) {
+      float t = part[lane];
+      for (int v = 1; v < kFcwWaves; ++v) t = __fadd_rn(t, part[v * 64 + lane]);
+      db[lane] = t;
+    }
   }
 }
 
@@ -234,17 +252,22 @@ extern "C" int mmf_traj_weight_grads(const MmfTrajGradDesc* desc, int n_desc, co
   return 0;
 }
 
-extern "C" int mmf_fc64_train_forward(const float* x, const float* w, const float* b, float* y, int R, int K, void* stream) {
-  if (!x || !w || !y || R < 0 || K < 256 || K % 256) return MMF_EINVAL;
+extern "C" int mmf_fc64_train_forward(const float* x, const float* w, const float* b, float* y, float* partial, int R, int K,
+                                      void* stream) {
+  if (!x || !w || !y || !partial || R < 0 || K < kFcChunk || K % kFcChunk) return MMF_EINVAL;
   if (R == 0) return 0;
-  fc64_forward_kernel<<<(R + 15) / 16, kFcWaves * MMF_WAVE, 0, static_cast<hipStream_t>(stream)>>>(x, w, b, y, R, K);
+  auto s = static_cast<hipStream_t>(stream);
+  const int chunks = K / kFcChunk;
+  fc64_forward_kernel<<<dim3((R + 15) / 16, chunks), kFcWaves * MMF_WAVE, 0, s>>>(x, w, partial, R, K);
+  MMF_CHECK_LAUNCH();
+  fc64_sum_kernel<<<(R * 64 + 255) / 256, 256, 0, s>>>(partial, b, y, R * 64, chunks);
   MMF_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int mmf_fc64_train_backward(const float* g, const float* x, const float* w, float* dx, float* dw, float* db,
                                        int R, int K, void* stream) {
-  if (!g || !x || !w || !dw || R < 0 || K < 256 || K % 256) return MMF_EINVAL;
+  if (!g || !x || !w || !dw || R < 0 || K < kFcChunk || K % kFcChunk) return MMF_EINVAL;
   auto s = static_cast<hipStream_t>(stream);
   if (R == 0) {
     hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * 64 * static_cast<size_t>(K), s);

@@ -479,29 +479,6 @@ class ParticleNetFunction(torch.autograd.Function):
         return (None, None, None, None, d_states, d_traj_bias, *grads)
 
 
-def _assemble_param_grads(net: PackedParticleNet, params, dW, db, g_first, g_head, g_head_b):
-    """Gradients in the order of ``net._sources()`` from the kernels' reductions: ``dW`` / ``db``
-    ``(NL + 1, 64, 64)`` / ``(NL + 1, 64)`` per 64x64 layer (slot NL of ``db`` = first-layer bias)."""
-    U = _abi.MMF_UNITS
-    NL = 3 + 2 * net.n_res
-    grads = [None] * len(params)
-    grads[0] = g_first
-    grads[1] = db[NL]
-    grads[2], grads[3], grads[4], grads[5] = dW[0], db[0], dW[1], db[1]
-    gj = torch.zeros_like(params[6], dtype=torch.float32)  # join: only the state columns are this network's
-    off = net.join_state_off
-    gj[:, off:off + U] = dW[2]
-    grads[6] = gj
-    for i in range(net.n_res):
-        for k in range(2):
-            layer = 3 + 2 * i + k
-            grads[7 + 4 * i + 2 * k] = dW[layer]
-            grads[8 + 4 * i + 2 * k] = db[layer]
-    grads[-2] = g_head
-    grads[-1] = g_head_b
-    return grads
-
-
 # Rows of one backward chunk of the native training recursion (whole trajectories): bounds the two
 # recompute buffers (stash + dz: 2 x (NL + 1) x rows x 256 B = 1.3 GB at the default) whatever N, M, T.
 # Measured at 32 x 8192 x 16 (push unimodal PF, ms per optimiser step): 16,384 rows 113, 32,768 (both
@@ -672,26 +649,30 @@ class PfTrainLoopFunction(torch.autograd.Function):
         a.g_states_a, a.g_states_b, a.g_logw_a, a.g_logw_b = P(scratch["ga"]), P(scratch["gb"]), P(scratch["la"]), P(scratch["lb"])
         a.d_states0, a.d_logw0 = P(scratch["d_states0"]), P(scratch["d_logw0"])
         _abi.pf_train_backward(a, g_est)
-        # slices / steps of the narrow reductions, and the param gradients in _sources() order
+        # the partial sums -> parameter gradients in _sources() order, d hoisted terms, d modality log-weights: two launches
+        # per network (mmf_pf_train_finalize)
         param_grads, bias_grads, d_beta = [], [], None
         if keep["beta"] is not None:
             d_beta = torch.zeros((T * N, K_all), dtype=torch.float32, device=dev)
         for i, net in enumerate(nets):
             b = bufs[i]
-            dW, db = b["pw"].sum(1), b["pb"].sum(1)
-            n_out = net.n_out
-            g_first_all = b["p_first"].sum((0, 1))
-            g_first = g_first_all[:, :d]
-            if fused:  # the fused kernel leaves no dz rows of the first layer to sum: column d of the narrow reduction is its bias gradient
-                db = db.clone()
-                db[3 + 2 * net.n_res] = g_first_all[:, d]
-            g_head = b["p_head"].sum((0, 1))[:n_out]
-            per_traj_dout = b["p_dout"].view(T * N, SL, 4).sum(1)
-            g_head_b = per_traj_dout.sum(0)[:n_out]
-            bias_grads.append(b["p_traj"].view(T * N, SL, U).sum(1))
-            if i > 0 and d_beta is not None and meas[i - 1][1] is not None:
-                d_beta[:, meas[i - 1][1]] = per_traj_dout[:, 0]
-            param_grads += _assemble_param_grads(net, params[offs[i]:offs[i + 1]], dW, db, g_first, g_head, g_head_b)
+            own = params[offs[i]:offs[i + 1]]
+            flat = torch.empty(sum(p.numel() for p in own), dtype=torch.float32, device=dev)
+            bias_grads.append(E(T * N, U))
+            fa = _abi.MmfPfTrainFinalizeArgs()
+            fa.T, fa.N, fa.SL, fa.S, fa.n_res, fa.d, fa.n_out = T, N, SL, int(a.n_splits), net.n_res, d, net.n_out
+            fa.join_in, fa.join_state_off, fa.fused = net.join.in_features, net.join_state_off, int(fused)
+            col = meas[i - 1][1] if i > 0 else None
+            fa.beta_stride, fa.beta_col = K_all, (col if col is not None else 0)
+            fa.pw, fa.pb, fa.p_first, fa.p_head, fa.p_dout, fa.p_traj = (P(b[k]) for k in ("pw", "pb", "p_first", "p_head", "p_dout", "p_traj"))
+            fin_scratch = E(32 * 516)
+            fa.grads, fa.bias_grad, fa.scratch = P(flat), P(bias_grads[-1]), P(fin_scratch)
+            fa.d_beta = P(d_beta) if (d_beta is not None and col is not None) else None
+            _abi.pf_train_finalize(fa, flat)
+            o = 0
+            for p_ in own:
+                param_grads.append(flat[o:o + p_.numel()].view(p_.shape))
+                o += p_.numel()
         none7 = (None, None, None, None)
         return (*none7, scratch["d_states0"], scratch["d_logw0"], None, None, bias_grads[0],
                 d_beta if d_beta is not None else None, *bias_grads[1:], *param_grads)

@@ -168,7 +168,7 @@ def test_traj_program_weights_follow_in_place_parameter_updates():
     assert float((b - ref).abs().max()) < 1e-5 and float((a - b).abs().max()) > 1e-4
 
 
-@pytest.mark.parametrize("R,K", [(1, 256), (16, 8192), (37, 8192), (512, 8192), (100, 1024)])
+@pytest.mark.parametrize("R,K", [(1, 512), (16, 8192), (37, 8192), (512, 8192), (100, 1024)])
 def test_fc64_training_kernels_match_fp64(R, K):
     from multimodalfilter_amd import _abi
 
