@@ -326,7 +326,9 @@ int mmf_image_encoder(const float* const* packed, int n_nets, const float* image
  *                                  caller (one slot per workgroup; a workgroup walks half-images, so
  *                                  n_blocks <= 2N, 256 fills the chip).
  *                                  (co,ci) = (32,1): the 5x5 stem, act = images (N,32,32); the head of each
- *                                  partial slot holds dW1 as [co 32][tap 32] (25 taps live)
+ *                                  partial slot holds dW1 as [co 32][tap 32] (25 taps live).
+ *                                  dw (co, ci, k, k) / db (co), when given: the slots summed in ascending order into
+ *                                  nn.Conv2d's own layout by a second launch (round 5; null: the caller sums)
  */
 size_t mmf_image_convs_backward_floats(void);
 int mmf_pack_image_convs_backward(const MmfImageEncoderDesc* desc, float* packed_bwd, void* stream);
@@ -337,7 +339,7 @@ int mmf_image_convs_train_backward(const float* packed_bwd, const float* a1, con
                                    const float* a2, const float* a3, const float* g_a4, float* g1,
                                    float* gh, float* g2, float* g3, int N, void* stream);
 int mmf_conv_weight_grads(const float* g, const float* act, float* partial, float* partial_b, int N, int co,
-                          int ci, int n_blocks, void* stream);
+                          int ci, int n_blocks, float* dw, float* db, void* stream);
 
 /* ---------------------------------------------------------------- particle-filter step loop
  * Replaces the Python loop of torchfilter's Filter.forward_loop (call site

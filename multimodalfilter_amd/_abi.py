@@ -186,7 +186,7 @@ SIGNATURES = {
     "mmf_pack_image_convs_backward": (c_int, [POINTER(MmfImageEncoderDesc), _FP, c_void_p]),
     "mmf_image_convs_train_forward": (c_int, [_FP] * 8 + [c_int, c_int, c_void_p]),
     "mmf_image_convs_train_backward": (c_int, [_FP] * 10 + [c_int, c_void_p]),
-    "mmf_conv_weight_grads": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmf_conv_weight_grads": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, _FP, _FP, c_void_p]),
     "mmf_image_encoder": (c_int, [POINTER(c_void_p), c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
 }
 
@@ -378,12 +378,13 @@ def image_convs_train_backward(packed_bwd, a1, h, a2, a3, g_a4, g1, gh, g2, g3):
                "mmf_image_convs_train_backward")
 
 
-def conv_weight_grads(g, act, partial, partial_b, n_blocks: int):
-    """``partial (n_blocks, 9, 32, 32)``, ``partial_b (n_blocks, 32)``: one slot per workgroup."""
+def conv_weight_grads(g, act, partial, partial_b, n_blocks: int, dw=None, db=None):
+    """``partial (n_blocks, 9, 32, 32)``, ``partial_b (n_blocks, 32)``: one slot per workgroup; ``dw (co, ci, k, k)`` /
+    ``db (co)``: the slots summed into ``nn.Conv2d``'s layout by a second launch."""
     assert partial.numel() >= n_blocks * 9 * 32 * 32 and partial_b.numel() >= n_blocks * 32
     with _on(g):
         _check(load().mmf_conv_weight_grads(ptr(g), ptr(act), ptr(partial), ptr(partial_b), g.shape[0], g.shape[1],
-                                            act.shape[1], n_blocks, stream_of(g)), "mmf_conv_weight_grads")
+                                            act.shape[1], n_blocks, ptr(dw), ptr(db), stream_of(g)), "mmf_conv_weight_grads")
 
 
 def image_convs_backward_floats() -> int:

@@ -1188,8 +1188,39 @@ static int launch_wgrad(WgradKernel k, const float* g, const float* act, float* 
   return 0;
 }
 
+// partial slots -> the layer's gradients in nn.Conv2d layout, slots in ascending order.  One thread per value of a slot,
+// in the SLOT's order (neighbouring threads read neighbouring words of every slot); the permutation is in the store.
+__global__ __launch_bounds__(256) void conv_wgrad_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ partial_b,
+                                                                int n_blocks, int co, int ci, float* __restrict__ dw,
+                                                                float* __restrict__ db) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_slot = ci == 1 ? 1024 : 9216;
+  if (e < n_slot) {
+    int dst;
+    if (ci == 1) {                                   // [co 32][tap 32], 25 taps live
+      const int o = e >> 5, tap = e & 31;
+      if (tap >= 25) return;
+      dst = o * 25 + tap;
+    } else {                                         // [tap 9][co 32][ci 32]
+      const int tap = e >> 10, o = (e >> 5) & 31, c = e & 31;
+      if (o >= co || c >= ci) return;
+      dst = (o * ci + c) * 9 + tap;
+    }
+    float s = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < n_blocks; ++b) s = __fadd_rn(s, partial[static_cast<size_t>(b) * 9216 + e]);
+    dw[dst] = s;
+  } else if (e < n_slot + co && db) {
+    const int o = e - n_slot;
+    float s = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < n_blocks; ++b) s = __fadd_rn(s, partial_b[b * 32 + o]);
+    db[o] = s;
+  }
+}
+
 extern "C" int mmf_conv_weight_grads(const float* g, const float* act, float* partial, float* partial_b, int N, int co,
-                                     int ci, int n_blocks, void* stream) {
+                                     int ci, int n_blocks, float* dw, float* db, void* stream) {
   if (!g || !act || !partial || !partial_b || N < 0 || n_blocks < 1) return MMF_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   WgradKernel k = nullptr;
@@ -1198,5 +1229,10 @@ extern "C" int mmf_conv_weight_grads(const float* g, const float* act, float* pa
   else if (co == 8 && ci == 16) k = conv_wgrad_kernel<8, 16>;
   else if (co == 32 && ci == 1) k = conv_wgrad_stem_kernel;
   else return MMF_EINVAL;
-  return launch_wgrad(k, g, act, partial, partial_b, N, n_blocks, s);
+  const int rc = launch_wgrad(k, g, act, partial, partial_b, N, n_blocks, s);
+  if (rc || !dw) return rc;
+  const int n = (ci == 1 ? 1024 : 9216) + co;
+  conv_wgrad_finalize_kernel<<<(n + 255) / 256, 256, 0, s>>>(partial, partial_b, n_blocks, co, ci, dw, db);
+  MMF_CHECK_LAUNCH();
+  return 0;
 }

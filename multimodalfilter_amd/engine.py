@@ -931,18 +931,18 @@ class ImageConvsFunction(torch.autograd.Function):
         _abi.image_convs_train_backward(cached[1], a1, h, a2, a3, g_a4, g1, gh, g2, g3)
         blocks = max(1, min(2 * N, 256))  # a workgroup walks half-images; one partial per workgroup
         partial = torch.empty((blocks, 9, 32, 32), dtype=torch.float32, device=img.device)
-        partial_b = torch.empty((5, blocks, 32), dtype=torch.float32, device=img.device)
+        partial_b = torch.empty((blocks, 32), dtype=torch.float32, device=img.device)
+        E = lambda *shape: torch.empty(shape, dtype=torch.float32, device=img.device)
 
-        def wgrad(g, act, slot):
+        def wgrad(g, act, k=3):  # partial slots, then their sum in nn.Conv2d's layout: two launches per layer
             co, ci = g.shape[1], act.shape[1]
-            _abi.conv_weight_grads(g, act, partial, partial_b[slot], blocks)
-            return partial.sum(0)[:, :co, :ci].permute(1, 2, 0).reshape(co, ci, 3, 3).contiguous()
+            dw, db = E(co, ci, k, k), E(co)
+            _abi.conv_weight_grads(g, act, partial, partial_b, blocks, dw, db)
+            return dw, db
 
-        gw4, gw3, gw2b, gw2a = wgrad(g_a4, a3, 4), wgrad(g3, a2, 3), wgrad(g2, h, 2), wgrad(gh, a1, 1)
-        _abi.conv_weight_grads(g1, img[:, None], partial, partial_b[0], blocks)          # the 5x5 stem: [co][tap]
-        gw1 = partial.view(blocks, -1)[:, :1024].sum(0).view(32, 32)[:, :25].reshape(32, 1, 5, 5).contiguous()
-        gb = partial_b.sum(1)                                                            # (5, 32): b1 b2a b2b b3 b4
-        return (None, None, gw1, gw2a, gw2b, gw3, gw4, gb[0], gb[1], gb[2], gb[3, :16], gb[4, :8])
+        (gw4, gb4), (gw3, gb3), (gw2b, gb2b), (gw2a, gb2a) = wgrad(g_a4, a3), wgrad(g3, a2), wgrad(g2, h), wgrad(gh, a1)
+        gw1, gb1 = wgrad(g1, img[:, None], 5)                                            # the 5x5 stem
+        return (None, None, gw1, gw2a, gw2b, gw3, gw4, gb1, gb2a, gb2b, gb3, gb4)
 
 
 class Fc64Function(torch.autograd.Function):
