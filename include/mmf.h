@@ -187,6 +187,14 @@ int mmf_pf_measure(const float* packed, int n_res, int precision, const float* s
                    const float* modality_logw, int logw_stride, float* loglik, int combine,
                    int32_t* range_flag, int N, int M, int d, void* stream);
 
+/* `count` modalities' own log-likelihoods (combine 0 each) of the SAME particles in one launch (blockIdx.y = modality):
+ * the training forward keeps every modality's log-likelihood for the backward's softmax over modalities
+ * (base_models/crossmodal_pf.py:106-139), and at the reference's training size a launch is one tile per wave.
+ *  packed, traj_bias, modality_logw (entries may be null), loglik: HOST arrays of `count` device pointers */
+int mmf_pf_measure_multi(const float* const* packed, int count, int n_res, int precision, const float* states,
+                         const float* const* traj_bias, const float* const* modality_logw, int logw_stride,
+                         float* const* loglik, int32_t* range_flag, int N, int M, int d, void* stream);
+
 /* Forward-mode Jacobian of the dynamics network (replaces torchfilter's default autograd
  * DynamicsModel.jacobian: batch replicated d times + one autograd.grad):
  *  states_in (N, d), traj_bias (N, 64) -> states_out (N, d), jac (N, d, d), jac[n][i][j] = d x'_i / d x_j
@@ -491,6 +499,10 @@ typedef struct MmfTrainFusedArgs {
 } MmfTrainFusedArgs;
 
 int mmf_particle_net_train_fused(const MmfTrainFusedArgs* args /* host */, void* stream);
+/* The same for several MEASUREMENT networks of one step in ONE launch (blockIdx.y = network; they differentiate
+ * independently of each other): same d, rows, depth and n_slots, each with its own outputs and row slots.  At the
+ * reference's training size (960 rows) a call is one tile per wave -- its latency -- whatever runs beside it. */
+int mmf_particle_net_train_fused_multi(const MmfTrainFusedArgs* nets /* host, n */, int n, void* stream);
 
 /* ---------------------------------------------------------------- K6: the particle filter's training recursion
  * One C call for the forward recursion of a train-mode (no resampling) particle filter over T steps and
@@ -599,6 +611,10 @@ typedef struct MmfPfTrainArgs {
                                 reductions read (layer slots 2 and NL).  fused_act, fused_g_act: scratch (chunk_traj M, 64) fp32 */
   float* fused_act;
   float* fused_g_act;
+  int32_t fused_sets;        /* ABI 38.  >= n_meas > 1: stash / dz / dz_scale / d_tmp hold one set of row slots per
+                                measurement network -- (sets, C, 64), (sets, 2, C, 64), (sets, 2, C), (sets, C, d) with
+                                C = chunk_traj M -- and a step's measurement networks run as ONE launch
+                                (mmf_particle_net_train_fused_multi).  0 / 1: one launch per network */
 } MmfPfTrainArgs;
 
 int mmf_pf_train_forward(const MmfPfTrainArgs* args /* host */, void* stream);

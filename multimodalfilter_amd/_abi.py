@@ -107,7 +107,7 @@ class MmfPfTrainArgs(Structure):
                 ("stash", _FP), ("mask", _FP), ("dz", _FP), ("raw", _FP), ("d_raw", _FP), ("loglik", _FP), ("ll_steps", _FP),
                 ("g_states_a", _FP), ("g_states_b", _FP), ("g_logw_a", _FP), ("g_logw_b", _FP), ("d_tmp", _FP),
                 ("range_flag", _FP), ("compact", c_int32), ("dz_scale", _FP), ("recompute_f16x3", c_int32), ("backward_f16x3", c_int32),
-                ("fused", c_int32), ("fused_act", _FP), ("fused_g_act", _FP)]
+                ("fused", c_int32), ("fused_act", _FP), ("fused_g_act", _FP), ("fused_sets", c_int32)]
 
 
 class MmfTrainFusedArgs(Structure):
@@ -143,6 +143,8 @@ SIGNATURES = {
     "mmf_pack_particle_net": (c_int, [POINTER(MmfParticleNetDesc), _FP, c_int, c_void_p]),
     "mmf_pf_dynamics": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_measure": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, c_int, _FP, c_int, _FP, c_int, c_int, c_int, c_void_p]),
+    "mmf_pf_measure_multi": (c_int, [POINTER(c_void_p), c_int, c_int, c_int, _FP, POINTER(c_void_p), POINTER(c_void_p), c_int,
+                                     POINTER(c_void_p), _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_dynamics_jacobian": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_ekf_step": (c_int, [_FP] * 10 + [c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_ekf_step_gated": (c_int, [_FP] * 10 + [c_int, c_int, c_int, c_int, c_int, _FP, c_void_p]),
@@ -178,6 +180,7 @@ SIGNATURES = {
     "mmf_pf_train_forward": (c_int, [POINTER(MmfPfTrainArgs), c_void_p]),
     "mmf_pf_train_backward": (c_int, [POINTER(MmfPfTrainArgs), c_void_p]),
     "mmf_particle_net_train_fused": (c_int, [POINTER(MmfTrainFusedArgs), c_void_p]),
+    "mmf_particle_net_train_fused_multi": (c_int, [POINTER(MmfTrainFusedArgs), c_int, c_void_p]),
     "mmf_particle_net_train_backward": (c_int, [_FP, _FP, c_int, c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_image_encoder_floats": (c_size_t, []),
     "mmf_image_encoder_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -465,6 +468,25 @@ def particle_net_train_fused(args: MmfTrainFusedArgs, like: torch.Tensor):
     """One fused network call of the training backward (see include/mmf.h)."""
     with _on(like):
         _check(load().mmf_particle_net_train_fused(ctypes.byref(args), stream_of(like)), "mmf_particle_net_train_fused")
+
+
+def pf_measure_multi(packed, n_res: int, precision: int, states, traj_bias, modality_logw, logw_stride: int, loglik, range_flag_t):
+    """Every modality's own log-likelihood of the same ``(N, M, d)`` particles in one launch; lists of tensors (``modality_logw``
+    entries may be ``None``)."""
+    n = len(packed)
+    arr = lambda ts: (c_void_p * n)(*[ptr(t) for t in ts])
+    N, M, d = states.shape
+    with _on(states):
+        _check(load().mmf_pf_measure_multi(arr(packed), n, n_res, precision, ptr(states), arr(traj_bias), arr(modality_logw), logw_stride,
+                                           arr(loglik), ptr(range_flag_t, dtype=torch.int32), N, M, d, stream_of(states)),
+               "mmf_pf_measure_multi")
+
+
+def particle_net_train_fused_multi(args_list, like: torch.Tensor):
+    """Several measurement networks' fused calls of one step as one launch (see include/mmf.h)."""
+    arr = (MmfTrainFusedArgs * len(args_list))(*args_list)
+    with _on(like):
+        _check(load().mmf_particle_net_train_fused_multi(arr, len(args_list), stream_of(like)), "mmf_particle_net_train_fused_multi")
 
 
 def fuse_virtual_sensors(z, tril, w, z_out, tril_out, mode: int):

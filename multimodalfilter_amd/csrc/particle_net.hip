@@ -820,6 +820,24 @@ extern "C" int mmf_pf_measure(const float* packed, int n_res, int precision, con
   return launch<kMeasure>(a, d, n_res, precision, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int mmf_pf_measure_multi(const float* const* packed, int count, int n_res, int precision, const float* states,
+                                    const float* const* traj_bias, const float* const* modality_logw, int logw_stride,
+                                    float* const* loglik, int* range_flag, int N, int M, int d, void* stream) {
+  if (!packed || !states || !traj_bias || !modality_logw || !loglik || count < 1 || count > MMF_LOOP_MAX_MEAS) return MMF_EINVAL;
+  if (N < 0 || M < 1) return MMF_EINVAL;
+  if (static_cast<long long>(N) * M > 0x7fffffffLL / 8) return MMF_ETOOLARGE;
+  if (N == 0) return 0;
+  NetArgsMulti m{};
+  for (int k = 0; k < count; ++k) {
+    if (!packed[k] || !traj_bias[k] || !loglik[k]) return MMF_EINVAL;
+    NetArgs& a = m.a[k];
+    a.packed = packed[k]; a.states_in = states; a.traj_bias = traj_bias[k]; a.mod_logw = modality_logw[k];
+    a.logw_stride = logw_stride; a.loglik = loglik[k]; a.combine = 0; a.R = N * M; a.M = M;
+    a.range_flag = range_flag;
+  }
+  return launch_multi<kMeasure>(m, count, d, n_res, precision, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int mmf_dynamics_jacobian(const float* packed, int n_res, int precision, const float* states_in,
                                      const float* traj_bias, float* states_out, float* jac,
                                      int* range_flag, int N, int d, void* stream) {

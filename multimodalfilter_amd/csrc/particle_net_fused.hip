@@ -275,8 +275,14 @@ __device__ __forceinline__ void load_rows_f32(const float* __restrict__ base, Ac
     }
 }
 
+// blockIdx.y = network of the call (several measurement networks of one step differentiate independently: one launch)
+struct FusedArgsMulti {
+  FusedArgs net[MMF_LOOP_MAX_MEAS];
+};
+
 template <int D, int NRES, int KIND, int PART>
-__global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedArgs a) {
+__global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedArgsMulti multi) {
+  const FusedArgs& a = multi.net[blockIdx.y];
   using LY = FusedLayout<NRES, PART>;
   constexpr int NL = LY::NL, L0 = LY::L0, NLAY = LY::NLAY;
   constexpr bool FIRST = PART != kTrunk, HEAD = PART == kFull || PART == kTrunk, BWD = PART != kEncFwd;
@@ -794,8 +800,9 @@ __global__ __launch_bounds__(256, 1) void particle_net_train_fused_kernel(FusedA
 }
 
 template <int D, int NRES, int KIND, int PART>
-int launch_fused(const FusedArgs& a, hipStream_t s) {
+int launch_fused(const FusedArgs* nets, int n, hipStream_t s) {
   using LY = FusedLayout<NRES, PART>;
+  const FusedArgs& a = nets[0];  // every network of a launch has the same rows and slots
   const int ntiles = (a.R + 31) / 32;
   int grid = (ntiles + 3) / 4;
   const int cap = PART == kEncFwd ? 256 : (a.slots < 256 ? a.slots : 256);
@@ -803,9 +810,16 @@ int launch_fused(const FusedArgs& a, hipStream_t s) {
   auto k = particle_net_train_fused_kernel<D, NRES, KIND, PART>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LY::kBytes);
   if (e != hipSuccess) return static_cast<int>(e);
-  k<<<grid, 256, LY::kBytes, s>>>(a);
+  FusedArgsMulti m{};
+  for (int i = 0; i < n; ++i) m.net[i] = nets[i];
+  k<<<dim3(grid, n), 256, LY::kBytes, s>>>(m);
   MMF_CHECK_LAUNCH();
   return 0;
+}
+
+template <int D, int NRES, int KIND, int PART>
+int launch_fused(const FusedArgs& a, hipStream_t s) {
+  return launch_fused<D, NRES, KIND, PART>(&a, 1, s);
 }
 
 template <int D>
@@ -832,7 +846,9 @@ int launch_fused_net(const MmfTrainFusedArgs* c, FusedArgs a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int mmf_particle_net_train_fused(const MmfTrainFusedArgs* c, void* stream) {
+namespace {
+
+int fill_fused_args(const MmfTrainFusedArgs* c, FusedArgs& a) {
   if (!c || !c->packed_dual || !c->states || !c->traj_bias || !c->d_states || !c->dz_first_h || !c->sc_first ||
       !c->dz_join_h || !c->sc_join || !c->h_last_h || !c->pw || !c->pb)
     return MMF_EINVAL;
@@ -841,14 +857,41 @@ extern "C" int mmf_particle_net_train_fused(const MmfTrainFusedArgs* c, void* st
   if (c->kind == kMeasure && !c->d_out) return MMF_EINVAL;
   if (c->kind == kDynamics && (!c->g_next || !c->d_raw || !c->act || !c->g_act)) return MMF_EINVAL;
   if (static_cast<long long>(c->N) * c->M > 0x7fffffffLL / 64) return MMF_ETOOLARGE;
-  if (c->N == 0) return 0;
-  FusedArgs a{};
+  a = FusedArgs{};
   a.blob = c->packed_dual; a.states = c->states; a.traj_bias = c->traj_bias; a.d_out = c->d_out; a.g_next = c->g_next;
   a.d_raw = c->d_raw; a.d_states = c->d_states; a.d_states_base = c->d_states_base;
   a.dz_first_h = static_cast<_Float16*>(c->dz_first_h); a.sc_first = c->sc_first;
   a.dz_join_h = static_cast<_Float16*>(c->dz_join_h); a.sc_join = c->sc_join;
   a.h_last_h = static_cast<_Float16*>(c->h_last_h);
   a.pw = c->pw; a.pb = c->pb; a.R = c->N * c->M; a.M = c->M; a.slots = c->n_slots;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mmf_particle_net_train_fused(const MmfTrainFusedArgs* c, void* stream) {
+  FusedArgs a;
+  const int rc = fill_fused_args(c, a);
+  if (rc) return rc;
+  if (c->N == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   return c->d == 2 ? launch_fused_net<2>(c, a, s) : launch_fused_net<3>(c, a, s);
+}
+
+extern "C" int mmf_particle_net_train_fused_multi(const MmfTrainFusedArgs* nets, int n, void* stream) {
+  if (!nets || n < 1 || n > MMF_LOOP_MAX_MEAS) return MMF_EINVAL;
+  FusedArgs a[MMF_LOOP_MAX_MEAS];
+  for (int i = 0; i < n; ++i) {
+    const int rc = fill_fused_args(nets + i, a[i]);
+    if (rc) return rc;
+    // one grid for all: measurement networks of the same depth over the same rows, each with its own outputs
+    if (nets[i].kind != kMeasure || nets[i].n_res != 2 || nets[i].d != nets[0].d || nets[i].N != nets[0].N || nets[i].M != nets[0].M ||
+        nets[i].n_slots != nets[0].n_slots)
+      return MMF_EINVAL;
+    for (int j = 0; j < i; ++j)
+      if (nets[j].d_states == nets[i].d_states || nets[j].pw == nets[i].pw || nets[j].dz_first_h == nets[i].dz_first_h) return MMF_EINVAL;
+  }
+  if (nets[0].N == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return nets[0].d == 2 ? launch_fused<2, 2, kMeasure, kFull>(a, n, s) : launch_fused<3, 2, kMeasure, kFull>(a, n, s);
 }

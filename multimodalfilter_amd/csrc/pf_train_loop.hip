@@ -111,10 +111,17 @@ extern "C" int mmf_pf_train_forward(const MmfPfTrainArgs* a, void* stream) {
                          a->noise + t * R * a->d, a->scale_tril, xn, a->range_flag, a->N, a->M, a->d, stream);
     if (rc) return rc;
     float* ll = a->ll_steps + static_cast<size_t>(t) * K * R;  // (K, R): kept for the backward's softmax over modalities
-    for (int k = 0; k < K; ++k) {
-      const float* lw = a->meas_logw[k] ? a->meas_logw[k] + t * row * a->logw_stride : nullptr;
-      rc = mmf_pf_measure(a->meas[k].packed, a->n_res_meas, a->precision, xn, a->meas_bias[k] + t * row * MMF_UNITS, lw,
-                          a->logw_stride, ll + k * R, 0, a->range_flag, a->N, a->M, a->d, hs);
+    {  // every modality's own log-likelihood: one launch, blockIdx.y = modality
+      const float *pk[MMF_LOOP_MAX_MEAS], *bias[MMF_LOOP_MAX_MEAS], *lw[MMF_LOOP_MAX_MEAS];
+      float* out[MMF_LOOP_MAX_MEAS];
+      for (int k = 0; k < K; ++k) {
+        pk[k] = a->meas[k].packed;
+        bias[k] = a->meas_bias[k] + t * row * MMF_UNITS;
+        lw[k] = a->meas_logw[k] ? a->meas_logw[k] + t * row * a->logw_stride : nullptr;
+        out[k] = ll + k * R;
+      }
+      rc = mmf_pf_measure_multi(pk, K, a->n_res_meas, a->precision, xn, bias, lw, a->logw_stride, out, a->range_flag, a->N, a->M,
+                                a->d, hs);
       if (rc) return rc;
     }
     const float* loglik = ll;
@@ -189,25 +196,37 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
                                               reinterpret_cast<const float*>(stash + oL), xs, d_out, pf, ph, pd, pt, Nc, M, d, n_out, SL, s);
   };
   // fused: one launch (dynamics: three) per network call, then the narrow reductions on the rows it left
-  auto net_fused = [&](const MmfTrainNet& net, int n_res, int kind, const float* xs, const float* bias, const float* d_out,
-                       const float* g_next, float* d_raw, float* d_states, const float* d_states_base, int NL, size_t C,
-                       size_t slot0, int Nc, int n_out) {
-    if (!net.packed_dual) return static_cast<int>(MMF_EINVAL);
-    char *stash = stash_of(0), *dz = dz_of(0);
-    float* sc = scale_of(0);
+  // row slots of one fused network call (set k of the caller's scratch when the step's networks share a launch)
+  const bool merged = fused && K > 1 && a->fused_sets >= K;
+  auto fused_args = [&](const MmfTrainNet& net, int set, int n_res, int kind, const float* xs, const float* bias, const float* d_out,
+                        const float* g_next, float* d_raw, float* d_states, const float* d_states_base, size_t C, int Nc) {
+    char* stash = reinterpret_cast<char*>(a->stash) + static_cast<size_t>(set) * Cmax * MMF_UNITS * 2;
+    char* dz = reinterpret_cast<char*>(a->dz) + static_cast<size_t>(set) * 2 * Cmax * MMF_UNITS * 2;
+    float* sc = a->dz_scale + static_cast<size_t>(set) * 2 * Cmax;
     MmfTrainFusedArgs f{};
     f.packed_dual = net.packed_dual; f.n_res = n_res; f.kind = kind; f.d = d; f.N = Nc; f.M = M; f.n_slots = S;
     f.states = xs; f.traj_bias = bias; f.d_out = d_out; f.g_next = g_next; f.d_raw = d_raw; f.act = a->fused_act;
     f.g_act = a->fused_g_act; f.d_states = d_states; f.d_states_base = d_states_base;
     f.dz_first_h = dz; f.sc_first = sc; f.dz_join_h = dz + C * MMF_UNITS * 2; f.sc_join = sc + C; f.h_last_h = stash;
     f.pw = net.pw; f.pb = net.pb;
-    int r = mmf_particle_net_train_fused(&f, stream);
-    if (r) return r;
+    return f;
+  };
+  auto fused_small_grads = [&](const MmfTrainNet& net, const MmfTrainFusedArgs& f, const float* d_out_used, size_t slot0, int Nc, int n_out) {
     float *pf = net.p_first + slot0 * MMF_UNITS * 4, *ph = net.p_head + slot0 * 4 * MMF_UNITS, *pd = net.p_dout + slot0 * 4,
           *pt = net.p_traj + slot0 * MMF_UNITS;
-    (void)NL;
-    return mmf_internal_small_grads_h(f.dz_first_h, f.sc_first, f.dz_join_h, f.sc_join, f.h_last_h, xs, kind == 1 ? d_out : d_raw, pf, ph,
+    return mmf_internal_small_grads_h(f.dz_first_h, f.sc_first, f.dz_join_h, f.sc_join, f.h_last_h, f.states, d_out_used, pf, ph,
                                       pd, pt, Nc, M, d, n_out, SL, stream);
+  };
+  // fused: one launch (dynamics: three) per network call, then the narrow reductions on the rows it left
+  auto net_fused = [&](const MmfTrainNet& net, int n_res, int kind, const float* xs, const float* bias, const float* d_out,
+                       const float* g_next, float* d_raw, float* d_states, const float* d_states_base, int NL, size_t C,
+                       size_t slot0, int Nc, int n_out) {
+    if (!net.packed_dual) return static_cast<int>(MMF_EINVAL);
+    (void)NL;
+    const MmfTrainFusedArgs f = fused_args(net, 0, n_res, kind, xs, bias, d_out, g_next, d_raw, d_states, d_states_base, C, Nc);
+    int r = mmf_particle_net_train_fused(&f, stream);
+    if (r) return r;
+    return fused_small_grads(net, f, kind == 1 ? d_out : d_raw, slot0, Nc, n_out);
   };
   auto mask_of = [&](int set) { return a->mask + 0; };
   auto raw_of = [&](int set) { return a->raw + 0; };
@@ -244,7 +263,29 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
         combine_bwd_kernel<<<blocks(C), kThreads, 0, hs>>>(ll, d_a, a->d_raw, K, R, r0, C);
         MMF_CHECK_LAUNCH();
       }
-      for (int k = 0; k < K; ++k) {
+      if (merged) {
+        // the step's measurement networks differentiate independently: ONE launch (blockIdx.y = network).  Network 0 adds
+        // its d states to the running gradient in its own store, the others leave theirs to be added in network order --
+        // the sums and their order are those of one launch per network
+        MmfTrainFusedArgs f[MMF_LOOP_MAX_MEAS];
+        for (int k = 0; k < K; ++k) {
+          if (!a->meas[k].packed_dual) return MMF_EINVAL;
+          float* ds = k == 0 ? g_tot + r0 * d : a->d_tmp + static_cast<size_t>(k) * Cmax * d;
+          f[k] = fused_args(a->meas[k], k, a->n_res_meas, 1, xn + r0 * d, a->meas_bias[k] + (t * row + n0) * MMF_UNITS, a->d_raw + k * C,
+                            nullptr, nullptr, ds, k == 0 ? ds : nullptr, C, Nc);
+        }
+        rc = mmf_particle_net_train_fused_multi(f, K, stream);
+        if (rc) return rc;
+        for (int k = 0; k < K; ++k) {
+          if (k > 0) {
+            add_kernel<<<blocks(C * d), kThreads, 0, hs>>>(g_tot + r0 * d, a->d_tmp + static_cast<size_t>(k) * Cmax * d, C * d);
+            MMF_CHECK_LAUNCH();
+          }
+          rc = fused_small_grads(a->meas[k], f[k], a->d_raw + k * C, slot0, Nc, 1);
+          if (rc) return rc;
+        }
+      }
+      for (int k = 0; k < K && !merged; ++k) {
         const MmfTrainNet& net = a->meas[k];
         const float* d_out = K > 1 ? a->d_raw + k * C : d_a + r0;
         hipStream_t sk = hs;

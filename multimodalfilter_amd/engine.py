@@ -512,6 +512,8 @@ TRAIN_BACKWARD_F16X3 = os.environ.get("MMF_TRAIN_BACKWARD_F16X3", "1") != "0"
 # over the compact buffers (round 4), kept as the cross-check of tests/test_gpu_training.py.
 TRAIN_FUSED = os.environ.get("MMF_TRAIN_FUSED", "1") != "0"
 TRAIN_FUSED_SLOTS = 256  # weight-gradient partials per layer = the largest grid of the fused kernel
+# the measurement networks of a step in one launch (MmfPfTrainArgs.fused_sets); MMF_TRAIN_FUSED_MERGE=0: one launch each
+TRAIN_FUSED_MERGE = os.environ.get("MMF_TRAIN_FUSED_MERGE", "1") != "0"
 
 
 class PfTrainLoopFunction(torch.autograd.Function):
@@ -634,9 +636,10 @@ class PfTrainLoopFunction(torch.autograd.Function):
         a.compact = int(TRAIN_COMPACT_STASH)
         A = (lambda *shape: torch.empty(shape, dtype=torch.float16, device=dev)) if a.compact else E
         if fused:  # only the three (C, 64) row slots of the narrow reductions + the dynamics' encoder hand-offs
-            scratch = dict(stash=A(1, C, U), mask=None, dz=A(2, C, U), dz_scale=E(2, C), raw=None, d_raw=E(K + 8, C), ga=E(N, M, d), gb=E(N, M, d),
-                           la=E(N, M), lb=E(N, M), d_tmp=E(1, C, d), d_states0=E(N, M, d), d_logw0=E(N, M), act=E(C, U), g_act=E(C, U))
-            a.fused_act, a.fused_g_act = P(scratch["act"]), P(scratch["g_act"])
+            fs = max(1, K)  # one set of row slots per measurement network: a step's networks share a launch
+            scratch = dict(stash=A(fs, C, U), mask=None, dz=A(fs, 2, C, U), dz_scale=E(fs, 2, C), raw=None, d_raw=E(K + 8, C), ga=E(N, M, d), gb=E(N, M, d),
+                           la=E(N, M), lb=E(N, M), d_tmp=E(fs, C, d), d_states0=E(N, M, d), d_logw0=E(N, M), act=E(C, U), g_act=E(C, U))
+            a.fused_act, a.fused_g_act, a.fused_sets = P(scratch["act"]), P(scratch["g_act"]), (fs if TRAIN_FUSED_MERGE else 1)
         else:
             scratch = dict(stash=A(sets, NLmax + 1, C, U), mask=torch.empty((sets, NLmax + 1, C, 2), dtype=torch.int32, device=dev),
                            dz=A(sets, NLmax + 1, C, U), dz_scale=E(sets, NLmax + 1, C) if a.compact else None, raw=E(sets, C, 8), d_raw=E(K + 8, C), ga=E(N, M, d), gb=E(N, M, d),

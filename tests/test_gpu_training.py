@@ -1019,6 +1019,60 @@ def test_fused_network_calls_track_the_three_pass_backward(tname, cls, N, M, T, 
     assert all(bool(torch.isfinite(v).all()) for v in g1.values())
 
 
+@pytest.mark.parametrize("tname,cls,N,M,T,chunk_rows", [
+    ("door", "DoorCrossmodalParticleFilter", 32, 30, 6, 262144),  # the reference's training shape
+    ("door", "DoorCrossmodalParticleFilter", 5, 300, 3, 600),     # ragged chunks
+    ("push", "PushUnimodalParticleFilter", 4, 2048, 3, 262144),
+])
+def test_measurement_networks_of_a_step_in_one_launch_equal_one_launch_each(tname, cls, N, M, T, chunk_rows):
+    """``MmfPfTrainArgs.fused_sets`` (round 5): the measurement networks of a step differentiate independently, so their
+    fused calls share ONE launch (``mmf_particle_net_train_fused_multi``, blockIdx.y = network; at the reference's
+    training size a call is one tile per wave, i.e. its latency).  Network 0 adds its ``d states`` to the running gradient
+    in its own store, the others are added behind it in network order: the same sums in the same order as one launch
+    per network -- every gradient bit for bit."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine
+
+    dev = torch.device("cuda:0")
+    task = om.TASKS[tname]
+    d = task.state_dim
+    obs, ctrl, x0, target, g = _data(task, T, N, 43)
+    eps0 = torch.randn((N, M, d), generator=g)
+    eps = [torch.randn((N, M, d), generator=g) for _ in range(T)]
+    cov = (torch.eye(d) * 0.1)[None].expand(N, d, d)
+    torch.manual_seed(8)
+    f = mmf.model_types(tname)[cls]().to(dev).train()
+    f.num_particles = M
+    engine.set_training_backend("hip")
+    old_chunk, old_merge, old_prec = engine.TRAIN_CHUNK_ROWS, engine.TRAIN_FUSED_MERGE, engine.DEFAULT_PRECISION
+    engine.TRAIN_CHUNK_ROWS = chunk_rows
+    engine.set_default_precision("f16x3")
+    seen = []
+    real = mmf._abi.pf_train_backward
+    mmf._abi.pf_train_backward = lambda a, *rest: (seen.append((int(a.fused), int(a.fused_sets), int(a.n_meas))), real(a, *rest))[1]
+    results = []
+    try:
+        for merge in (False, True):
+            engine.TRAIN_FUSED_MERGE = merge
+            f.zero_grad(set_to_none=True)
+            f.noise = mmf.ReplayNoise([eps0] + eps, [])
+            f.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
+            pred = f.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
+            torch.mean((pred - target.to(dev)) ** 2).backward()
+            torch.cuda.synchronize()
+            results.append({n: p.grad.detach().clone() for n, p in f.named_parameters() if p.grad is not None})
+    finally:
+        mmf._abi.pf_train_backward = real
+        engine.set_training_backend(None)
+        engine.TRAIN_CHUNK_ROWS, engine.TRAIN_FUSED_MERGE = old_chunk, old_merge
+        engine.set_default_precision(old_prec)
+    assert seen[0][0] == 1 and seen[0][1] == 1 and seen[1][1] == seen[1][2] == 2
+    g0, g1 = results
+    assert set(g0) == set(g1) and len(g0) > 20
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+
+
 @pytest.mark.parametrize("task,kind", [("door", "dynamics"), ("door", "measure"), ("push", "dynamics"), ("push", "measure")])
 @pytest.mark.parametrize("N,M", [(3, 40), (2, 64), (5, 7), (32, 30), (7, 300)])
 def test_k6_fused_network_call_matches_the_exact_fp32_step_kernels(task, kind, N, M):
