@@ -15,6 +15,8 @@ HIPCC=/opt/rocm/bin/hipcc
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -I$R/include -I$R/multimodalfilter_amd/csrc -o $R/scripts/ubench/k1_phases $R/scripts/ubench/k1_phases.hip > $OUT/ubench_build.log 2>&1
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form=1 -Wno-unused-value -I$R/include -I$R/multimodalfilter_amd/csrc -o $R/scripts/ubench/fused_phases $R/scripts/ubench/fused_phases.hip >> $OUT/ubench_build.log 2>&1
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form=1 -Wno-unused-value -DNO_PHASE_CLOCKS -I$R/include -I$R/multimodalfilter_amd/csrc -o $R/scripts/ubench/fused_phases_noclk $R/scripts/ubench/fused_phases.hip >> $OUT/ubench_build.log 2>&1
+$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -Wno-unused-value -I$R/include -I$R/multimodalfilter_amd/csrc -o $R/scripts/ubench/k4_wg_spread $R/scripts/ubench/k4_wg_spread.hip >> $OUT/ubench_build.log 2>&1
+$HIPCC --offload-arch=gfx950 -O3 -Wno-unused-value -o $R/scripts/ubench/handoff_latency $R/scripts/ubench/handoff_latency.hip >> $OUT/ubench_build.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 LEAN="--no-cpu-baseline --no-precision-study --no-reference-sizes --no-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -- python3 $R/bench.py --steps 32 --warmup 4 $LEAN --no-f32-mode > $OUT/bench_under_rocprof.json 2> $P/stats.err
@@ -68,6 +70,16 @@ python scripts/debug/fused_check.py --sizes 3x40,5x7,32x30,7x300,32x8192 --quiet
 bash scripts/pmc_k4_r04.sh final > /dev/null 2>&1
 cp gpurun_out/pmc_k4_r04/final.json $OUT/pmc_k4_sq_counters.json
 ./scripts/ubench/mfma_shape > $OUT/ubench_mfma_shape.txt 2>&1
+{ for sh in 16 17 18 19 20 16 19; do ./scripts/ubench/k4_wg_spread 4096 2 $sh b | grep "rep 3 conv2b"; done
+  for sh in 16 19 16 19; do ./scripts/ubench/k4_wg_spread 4096 3 $sh b | grep "rep 3 conv2b"; done
+  for sh in 16 19; do ./scripts/ubench/k4_wg_spread 1024 2 $sh b | grep "rep 3 conv2b"; done
+  ./scripts/ubench/k4_wg_spread 4096 2 16 | grep -A12 "rep 3"; ./scripts/ubench/k4_wg_spread 4096 2 19 | grep -A12 "rep 3"; } > $OUT/ubench_k4_wg_spread.txt 2>&1
+./scripts/ubench/handoff_latency > $OUT/ubench_handoff_latency.txt 2>&1
+python scripts/debug/k4_two_streams.py 4096 2 2>&1 | grep -v amdgpu.ids > $OUT/bench_k4_two_streams.txt; python scripts/debug/k4_two_streams.py 3072 3 2>&1 | grep -v amdgpu.ids >> $OUT/bench_k4_two_streams.txt
+{ echo "# default: K7 programs' reverse mode + fc64 kernels + finalize (MMF_TRAIN_TRAJ_PROGRAMS=1), merged measurement launches"; python scripts/bench_reference_sizes.py --only train --backends hip --no-cpu 2>&1 | grep "^{";
+  echo "# MMF_TRAIN_FUSED_MERGE=0"; MMF_TRAIN_FUSED_MERGE=0 python scripts/bench_reference_sizes.py --only train --backends hip --no-cpu 2>&1 | grep "^{";
+  echo "# MMF_TRAIN_TRAJ_PROGRAMS=0 (torch autograd + rocBLAS for the per-trajectory networks: round 4)"; MMF_TRAIN_TRAJ_PROGRAMS=0 python scripts/bench_reference_sizes.py --only train --backends hip --no-cpu 2>&1 | grep "^{";
+  echo "# default again"; python scripts/bench_reference_sizes.py --only train --backends hip --no-cpu 2>&1 | grep "^{"; } > $OUT/bench_train_refsize_ab.txt
 # plain bench lines (un-profiled)
 python bench.py > $OUT/bench_door_pf_n1.json 2> $OUT/bench.err
 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_flags_door_pf.json 2>> $OUT/bench.err
@@ -82,7 +94,7 @@ python bench.py --workload door_pf --batch 1024 --steps 32 $LEAN --no-f32-mode >
 python bench.py --workload door_ekf --global-batch 8192 --steps 32 --warmup 4 $LEAN > $OUT/bench_c4_door_ekf_n8192_one_gpu.json 2>> $OUT/bench.err
 python bench.py --workload door_pf --steps 800 $LEAN --no-f32-mode > $OUT/bench_door_pf_800_steps.json 2>> $OUT/bench.err
 MMF_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 32 --warmup 8 2>> $OUT/bench.err | grep "^{" > $OUT/bench_gpus2_gloo_one_gpu.json
-python bench.py --workload push_train --steps 6 --warmup 2 2>> $OUT/bench.err | grep "^{" > $OUT/bench_push_train_n1.json
+python bench.py --workload push_train --steps 20 --warmup 5 2>> $OUT/bench.err | grep "^{" > $OUT/bench_push_train_n1.json
 MMF_DIST_BACKEND=gloo python bench.py --workload push_train --gpus 2 --steps 4 --warmup 1 --batch 16 2>> $OUT/bench.err | grep "^{" > $OUT/bench_push_train_gpus2_gloo_one_gpu.json
 python scripts/debug/rccl_probe.py 2>&1 | grep -E "^rank|^world|Duplicate GPU" | sort -u > $OUT/bench_rccl_probe.txt
 python scripts/bench_k4.py > $OUT/bench_k4.txt 2>> $OUT/bench.err
