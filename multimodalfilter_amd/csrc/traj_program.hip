@@ -53,54 +53,112 @@ __device__ __forceinline__ float activate(float v, int act, float fparam) {
 // source requested before the first MFMA) instead of 64 behind four dependent rounds: a program is a chain of L2
 // round trips, and at the T*N = 512 rows of a training step there is one task per CU and nothing else to hide them.
 // Which wave computes a tile does not change its chain: results are bit-identical to the one-wave form.
+// What the NEXT instruction needs from memory, requested while the current one runs (an instruction's addresses depend on
+// the program and the task only, never on data): without it every instruction starts with its own L2 / HBM round trip.
+struct Pre {
+  f32x4 a[4][2];   // LINEAR: the fragments of its first chunk (source 0, groups 0 .. 3) for this wave's tiles
+  f32x4 bias[2];   // LINEAR: its bias (zeros without one)
+  float io[4][2];  // LOAD / LOAD_ADD / MASK: rows wave, wave + 4, .. of the task, columns lane and lane + 64
+};
+
+__device__ __forceinline__ void prefetch(const MmfTrajInstr& I, const float* __restrict__ weights, const IoPtrs& io, int row0,
+                                         int nrows, int lane, int wave, Pre& p) {
+  if (I.op == MMF_TRAJ_LINEAR) {
+    const int q = lane >> 4;
+    const int tpw = I.out_dim > 64 ? 2 : 1, TT = 4 * tpw;
+    const int groups = (I.src_dim[0] + 15) >> 4;
+    const float* w = weights + I.w_off + lane * 4;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (t < tpw) {
+        const int mt = wave + 4 * t;
+        p.bias[t] = I.b_off >= 0 ? *reinterpret_cast<const f32x4*>(weights + I.b_off + 16 * mt + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+          const int g = min(gg, groups - 1);  // a clamped duplicate is never multiplied
+          p.a[gg][t] = *reinterpret_cast<const f32x4*>(w + (g * TT + mt) * 256);
+        }
+      }
+  } else if (I.op == MMF_TRAJ_LOAD || I.op == MMF_TRAJ_LOAD_ADD || I.op == MMF_TRAJ_MASK) {
+    const float* src = io.p[I.io];
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr) {
+      const size_t g = static_cast<size_t>(row0 + min(wave + kWaves * jr, nrows - 1)) * I.io_stride + I.io_off;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = lane + 64 * h;
+        p.io[jr][h] = c < I.out_dim ? src[g + c] : 0.f;
+      }
+    }
+  }
+}
+
 template <int TPW>  // tiles per wave: 1 (out_dim <= 64) or 2
 __device__ __forceinline__ void linear_mfma(const MmfTrajInstr& I, const float* __restrict__ weights, float* slots, int ld,
-                                            int lane, int wave) {
+                                            int lane, int wave, const Pre& pre) {
   constexpr int TT = 4 * TPW;  // tiles of the layer
   const int i = lane & 15, q = lane >> 4;
-  f32x4 acc[TPW];
+  f32x4 acc[TPW], cur[4][TPW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
-    const int mt = wave + 4 * t;
-    if (I.b_off >= 0) acc[t] = *reinterpret_cast<const f32x4*>(weights + I.b_off + 16 * mt + 4 * q);
-    else acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[t] = pre.bias[t];
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) cur[gg][t] = pre.a[gg][t];
   }
-  const float* w = weights + I.w_off + lane * 4;
+  // chunks of four groups (64 inputs) over the sources in order; the next chunk's fragments are requested before this
+  // chunk's MFMAs (the first came with `pre`)
+  const float* w = weights + I.w_off + lane * 4;  // fragments of the current source
+  // (selects, not run-time indices: the instruction stays in registers)
+  auto sel = [](const int32_t (&v)[4], int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : (k == 2 ? v[2] : v[3])); };
+  int s = 0, g0 = 0;
+  int dim = I.src_dim[0], groups = (dim + 15) >> 4;
 #pragma unroll 1
-  for (int s = 0; s < 4; ++s) {
-    if (I.src[s] < 0) break;
-    const float* xs = slots + I.src[s] * (kRows * ld) + I.src_off[s] + i * ld + q;
-    const int dim = I.src_dim[s];
-    const int groups = (dim + 15) >> 4;
-#pragma unroll 1
-    for (int g0 = 0; g0 < groups; g0 += 4) {  // four groups (64 inputs) per round of loads
-      f32x4 a[4][TPW];
+  for (;;) {
+    int ns = s, ng0 = g0 + 4;
+    const float* nw = w;
+    int ndim = dim, ngroups = groups;
+    if (ng0 >= groups) {
+      ns = s + 1;
+      ng0 = 0;
+      nw = w + groups * TT * 256;
+      const bool more = ns < 4 && sel(I.src, ns) >= 0;
+      if (more) { ndim = sel(I.src_dim, ns); ngroups = (ndim + 15) >> 4; }
+      else ns = -1;
+    }
+    f32x4 nxt[4][TPW];
+    if (ns >= 0) {
 #pragma unroll
       for (int gg = 0; gg < 4; ++gg)
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-          const int g = min(g0 + gg, groups - 1);  // a clamped duplicate is never multiplied
-          a[gg][t] = *reinterpret_cast<const f32x4*>(w + (g * TT + wave + 4 * t) * 256);
-        }
-      float b[4][4];
-#pragma unroll
-      for (int gg = 0; gg < 4; ++gg)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int k = 16 * (g0 + gg) + 4 * ks + q;
-          b[gg][ks] = k < dim ? xs[16 * (g0 + gg) + 4 * ks] : 0.f;   // padded k: zero weight times a DEFINED zero
-        }
-#pragma unroll
-      for (int gg = 0; gg < 4; ++gg)
-        if (g0 + gg < groups) {
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int t = 0; t < TPW; ++t)
-              acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gg][t][ks], b[gg][ks], acc[t], 0, 0, 0);
+          const int g = min(ng0 + gg, ngroups - 1);
+          nxt[gg][t] = *reinterpret_cast<const f32x4*>(nw + (g * TT + wave + 4 * t) * 256);
         }
     }
-    w += groups * TT * 256;
+    const float* xs = slots + sel(I.src, s) * (kRows * ld) + sel(I.src_off, s) + i * ld + q;
+    float b[4][4];
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int k = 16 * (g0 + gg) + 4 * ks + q;
+        b[gg][ks] = k < dim ? xs[16 * (g0 + gg) + 4 * ks] : 0.f;   // padded k: zero weight times a DEFINED zero
+      }
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg)
+      if (g0 + gg < groups) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int t = 0; t < TPW; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[gg][t][ks], b[gg][ks], acc[t], 0, 0, 0);
+      }
+    if (ns < 0) break;
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) cur[gg][t] = nxt[gg][t];
+    s = ns; g0 = ng0; w = nw; dim = ndim; groups = ngroups;
   }
   // epilogue: (+ residual) activation, written back as 16-byte pieces.  dst may alias a source: every wave has read
   // its sources before any wave writes
@@ -130,21 +188,26 @@ __global__ __launch_bounds__(kWaves * MMF_WAVE) void traj_program_kernel(
   for (int task = blockIdx.x; task * kRows < R; task += gridDim.x) {
     const int row0 = task * kRows;
     const int nrows = min(kRows, R - row0);
+    MmfTrajInstr I = prog[0];
+    Pre pre;
+    prefetch(I, weights, io, row0, nrows, lane, wave, pre);
     for (int ip = 0; ip < n_instr; ++ip) {
-      const MmfTrajInstr I = prog[ip];
+      const MmfTrajInstr In = prog[ip + 1 < n_instr ? ip + 1 : ip];
+      Pre nxt;
+      if (ip + 1 < n_instr) prefetch(In, weights, io, row0, nrows, lane, wave, nxt);
+      __builtin_amdgcn_sched_barrier(0);  // the requests stay ahead of this instruction's work
       if (I.op == MMF_TRAJ_LOAD || I.op == MMF_TRAJ_LOAD_ADD || I.op == MMF_TRAJ_MASK) {
         // LOAD: slot = act(io); LOAD_ADD: slot += io; MASK: slot = io > 0 ? slot : 0 (the backward of a ReLU, from the
         // stashed output).  Rows past the end repeat the last row: defined values that no STORE writes back.
-        const float* src = io.p[I.io];
         float* dst = slots + I.dst * (kRows * ld) + I.dst_off;
 #pragma unroll
-        for (int r = wave; r < kRows; r += kWaves) {
-          const size_t g = static_cast<size_t>(row0 + min(r, nrows - 1)) * I.io_stride + I.io_off;
+        for (int jr = 0; jr < 4; ++jr) {
+          const int r = wave + kWaves * jr;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const int c = lane + 64 * h;
             if (c < I.out_dim) {
-              const float v = src[g + c];
+              const float v = pre.io[jr][h];
               float* d = dst + r * ld + c;
               if (I.op == MMF_TRAJ_LOAD) *d = activate(v, I.act, I.fparam);
               else if (I.op == MMF_TRAJ_LOAD_ADD) *d = __fadd_rn(*d, v);
@@ -163,8 +226,8 @@ __global__ __launch_bounds__(kWaves * MMF_WAVE) void traj_program_kernel(
             if (c < I.out_dim) dst[r * ld + c] = src ? __fadd_rn(dst[r * ld + c], src[r * ld + c]) : 0.f;
           }
       } else if (I.op == MMF_TRAJ_LINEAR) {
-        if (I.out_dim > 64) linear_mfma<2>(I, weights, slots, ld, lane, wave);
-        else linear_mfma<1>(I, weights, slots, ld, lane, wave);
+        if (I.out_dim > 64) linear_mfma<2>(I, weights, slots, ld, lane, wave, pre);
+        else linear_mfma<1>(I, weights, slots, ld, lane, wave, pre);
       } else {  // STORE / STORE_DIAG
         float* out = io.p[I.io];
         const float* src = slots + I.src[0] * (kRows * ld) + I.src_off[0];
@@ -183,6 +246,8 @@ __global__ __launch_bounds__(kWaves * MMF_WAVE) void traj_program_kernel(
         }
       }
       __syncthreads();  // the next instruction reads what any wave of this one wrote (and the next task reuses the slots)
+      I = In;
+      pre = nxt;
     }
   }
 }
