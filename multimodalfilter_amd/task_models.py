@@ -498,9 +498,35 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             assert type(observations) == dict
             N, _ = observations["gripper_pos"].shape
             if engine.use_autograd(self):
-                shared = self.shared_layers(self.observation_features_autograd(observations))
-                z = self.z_layer(shared[:, : self.units])
-                lt_hat = self.r_layer(shared[:, self.units:]) if self.noise_R_tril is None else self.noise_R_tril
+                if engine.use_traj_program_backward(observations["gripper_pos"]):
+                    # the K7 program forward and backward in HIP, both heads stored as they are; the few element-wise
+                    # operations behind the r head (kf.py:117-126) stay torch ops on (N, d, d)
+                    d_, U_ = self.state_dim, self.units
+                    with_r = self.noise_R_tril is None
+
+                    def build(p, srcs):
+                        sh = p.linear(srcs, self.shared_layers[0], _abi.ACT_RELU)
+                        for (slot, _o, _w) in srcs:
+                            p.free(slot)
+                        p.res_linear(self.shared_layers[2], sh, 2 * U_)
+                        p.res_linear(self.shared_layers[3], sh, 2 * U_)
+                        for layer, off, name in ((self.z_layer, 0, "z"), (self.r_layer, U_, "r")):
+                            if name == "r" and not with_r:
+                                continue
+                            a = p.linear([(sh, off, U_)], layer[0], _abi.ACT_RELU)
+                            p.res_linear(layer[2], a, d_)
+                            o = p.linear([(a, 0, d_)], layer[3])
+                            p.store(name, o, d_)
+                            p.free(a)
+                            p.free(o)
+
+                    prog, t = self._train_program(observations, build)
+                    outs = prog.run_autograd(t, {"z": d_, "r": d_} if with_r else {"z": d_}, N)
+                    z, lt_hat = outs["z"], (outs["r"] if with_r else self.noise_R_tril)
+                else:
+                    shared = self.shared_layers(self.observation_features_autograd(observations))
+                    z = self.z_layer(shared[:, : self.units])
+                    lt_hat = self.r_layer(shared[:, self.units:]) if self.noise_R_tril is None else self.noise_R_tril
                 cov = torch.diag_embed(lt_hat) ** 2
                 if self.add_R_noise[0] > 0:
                     cov = cov + torch.diag(self.add_R_noise).to(cov.device)
@@ -586,6 +612,14 @@ def make_task_models(task: TaskSpec) -> SimpleNamespace:
             N, _ = observations["gripper_pos"].shape
             out_dim = self.modality_count * self.state_dim
             if engine.use_autograd(self):
+                if engine.use_traj_program_backward(observations["gripper_pos"]) and isinstance(self.fusion_layers[-1], nn.Sigmoid) \
+                        and len(self.fusion_layers) == 5:
+                    def build(p, srcs):  # the sigmoid behind the last layer stays a torch op on (R, 2 d)
+                        x = p.linear(srcs, self.fusion_layers[0], _abi.ACT_RELU)
+                        p.res_linear(self.fusion_layers[2], x, self.fusion_layers[0].out_features)
+                        p.store("out", p.linear([(x, 0, self.fusion_layers[0].out_features)], self.fusion_layers[3]), out_dim)
+                    prog, t = self._train_program(observations, build)
+                    return torch.sigmoid(prog.run_autograd(t, {"out": out_dim}, N)["out"])
                 return self.fusion_layers(self.observation_features_autograd(observations))
             if self._prog is None:
                 p = TrajProgram()

@@ -1121,3 +1121,58 @@ def test_compact_training_arguments_are_validated_at_the_boundary():
     finally:
         mmf._abi.pf_train_backward = real
         engine.set_training_backend(None)
+
+
+@pytest.mark.parametrize("tname,cls,expected", [
+    ("door", "DoorCrossmodalParticleFilter", 4),   # control term, two measurement networks' observation terms, weight model
+    ("push", "PushUnimodalParticleFilter", 3),
+    ("door", "DoorCrossmodalKalmanFilter", 15),    # per step (T = 3; the EKF's training loop is step by step): two virtual sensors, the EKF weight model, each sub-filter's control term
+])
+def test_hip_backend_differentiates_the_per_trajectory_networks_through_their_programs(tname, cls, expected):
+    """Round 5: under the "hip" training backend every N-row network of a training step -- hoisted control / observation
+    terms, PF and EKF weight models, virtual sensors -- runs forward and backward as its K7 program
+    (``TrajProgram.run_autograd``), not as torch modules; ``engine.TRAIN_TRAJ_PROGRAMS = False`` restores the torch path
+    (the cross-check), with gradients within the file's fp32-vs-fp32 tolerance of each other."""
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine, trajprog
+
+    dev = torch.device("cuda:0")
+    task = om.TASKS[tname]
+    d, T, N, M = task.state_dim, 3, 6, 40
+    obs, ctrl, x0, target, g = _data(task, T, N, 71)
+    torch.manual_seed(9)
+    f = mmf.model_types(tname)[cls]().to(dev).train()
+    is_pf = hasattr(f, "num_particles")
+    if is_pf:
+        f.num_particles = M
+    eps0 = torch.randn((N, M, d), generator=g)
+    eps = [torch.randn((N, M, d), generator=g) for _ in range(T)]
+    cov = (torch.eye(d) * 0.1)[None].expand(N, d, d)
+    engine.set_training_backend("hip")
+    old = engine.TRAIN_TRAJ_PROGRAMS
+    calls = []
+    real = trajprog.TrajProgram.run_autograd
+    trajprog.TrajProgram.run_autograd = lambda self, *a, **k: (calls.append(1), real(self, *a, **k))[1]
+    grads = []
+    try:
+        for on in (True, False):
+            engine.TRAIN_TRAJ_PROGRAMS = on
+            calls.clear()
+            f.zero_grad(set_to_none=True)
+            if is_pf:
+                f.noise = mmf.ReplayNoise([eps0] + eps, [])
+            f.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
+            pred = f.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
+            torch.mean((pred - target.to(dev)) ** 2).backward()
+            torch.cuda.synchronize()
+            assert len(calls) == (expected if on else 0), (on, len(calls))
+            grads.append({n: p.grad.detach().clone() for n, p in f.named_parameters() if p.grad is not None})
+    finally:
+        trajprog.TrajProgram.run_autograd = real
+        engine.TRAIN_TRAJ_PROGRAMS = old
+        engine.set_training_backend(None)
+    g1, g0 = grads
+    assert set(g0) == set(g1) and len(g0) > 20
+    top = max(float(v.abs().max()) for v in g0.values())
+    worst = max((float((g0[k] - g1[k]).abs().max()) / max(1e-3 * top, float(g0[k].abs().max())), k) for k in g0)
+    assert worst[0] < GRAD_TOL, worst
