@@ -290,6 +290,24 @@ struct NetArgs {
   int noise_mode;           // 0: `noise` tensor or none, 2: philox
 };
 
+// Per-workgroup start / end stamps + XCD of the LAST launch (scripts/debug/k2_wg_spread.py builds a library of its own with
+// -DMMF_K2_WG_STAMPS; compiled out of the product).
+#ifdef MMF_K2_WG_STAMPS
+__device__ long long g_k2_stamp[2][512];
+__device__ int g_k2_xcc[512];
+#define K2_WG_STAMP(which)                                                                          \
+  do {                                                                                              \
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 512) {                                  \
+      unsigned x_;                                                                                  \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x_));                             \
+      g_k2_stamp[which][blockIdx.x] = wall_clock64();                                               \
+      g_k2_xcc[blockIdx.x] = x_ & 0xf;                                                              \
+    }                                                                                               \
+  } while (0)
+#else
+#define K2_WG_STAMP(which)
+#endif
+
 // blockIdx.y selects one of up to MMF_LOOP_MAX_MEAS independent problems of the same shape (the
 // sub-filters of a fused EKF evaluate their Jacobians in one launch).
 struct NetArgsMulti {
@@ -299,6 +317,7 @@ struct NetArgsMulti {
 template <int D, int NRES, int KIND, int CT, int PREC, int WPS, bool PIPE = false>
 __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMulti multi) {
   const NetArgs a = multi.a[blockIdx.y];
+  K2_WG_STAMP(0);
   static_assert(!PIPE || (CT == 2 && PREC == MMF_PREC_F16X3 && KIND != kJacobian), "pipelined halves: f16x3, 64-particle tiles");
   constexpr int kThreads = WPS * 256;           // WPS waves per SIMD, one workgroup per CU (LDS)
   constexpr int kWavesPerBlock = kThreads / MMF_WAVE;
@@ -675,6 +694,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
     }
     tile = tile_next;
   }
+  K2_WG_STAMP(1);
 }
 
 template <int D, int NRES, int KIND, int PREC, int CT, int WPS, bool PIPE = false>
@@ -738,6 +758,14 @@ int launch_multi(const NetArgsMulti& m, int count, int d, int n_res, int precisi
 }
 
 }  // namespace
+
+#ifdef MMF_K2_WG_STAMPS
+extern "C" int mmf_debug_k2_stamps(long long* stamps /* [2][512] */, int* xcc /* [512] */) {
+  if (hipDeviceSynchronize() != hipSuccess) return MMF_EINVAL;
+  if (hipMemcpyFromSymbol(stamps, HIP_SYMBOL(g_k2_stamp), sizeof(long long) * 1024) != hipSuccess) return MMF_EINVAL;
+  return hipMemcpyFromSymbol(xcc, HIP_SYMBOL(g_k2_xcc), sizeof(int) * 512) == hipSuccess ? 0 : MMF_EINVAL;
+}
+#endif
 
 extern "C" size_t mmf_particle_net_floats(int n_res) {
   if (n_res < 0 || n_res > MMF_MAX_RES) return 0;
