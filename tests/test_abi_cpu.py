@@ -134,6 +134,26 @@ def test_size_limits_and_empty_batches_at_the_boundary():
     assert lib.mmf_dynamics_jacobian(P[0], 3, F32, P[1], P[2], P[3], P[4], None, 0, 3, None) == 0
     assert lib.mmf_image_encoder((ctypes.c_void_p * 1)(P[0]), 1, P[1], P[2], P[3], None, F32, 0, 0, None) == 0
     assert lib.mmf_traj_program(P[0], 1, P[1], (ctypes.c_void_p * 8)(), 0, 1, 64, None) == 0
+    # round 5's entry points: contraction length of the 8192 -> 64 layer, row slices, networks per launch, state dimension
+    assert lib.mmf_fc64_train_forward(P[0], P[1], P[2], P[3], P[4], 4, 8192 + 256, None) == EINVAL      # K % 512
+    assert lib.mmf_fc64_train_forward(P[0], P[1], P[2], P[3], P[4], 0, 8192, None) == 0               # no rows
+    assert lib.mmf_fc64_train_backward(P[0], P[1], P[2], P[3], P[4], P[5], 4, 100, None) == EINVAL
+    assert lib.mmf_traj_weight_grads(P[0], 1, P[1], 8, P[2], 8, P[3], 16, P[4], 65, 4, None) == EINVAL  # > 64 row slices
+    assert lib.mmf_traj_weight_grads(P[0], 1, P[1], 8, P[2], 8, P[3], 16, None, 2, 4, None) == EINVAL   # slices without scratch
+    assert lib.mmf_traj_pack(P[0], 0, P[1], None) == EINVAL
+    nets = (_abi.MmfTrainFusedArgs * 5)()
+    assert lib.mmf_particle_net_train_fused_multi(nets, 5, None) == EINVAL                               # > MMF_LOOP_MAX_MEAS
+    assert lib.mmf_particle_net_train_fused_multi(nets, 2, None) == EINVAL                               # null fields
+    four = (ctypes.c_void_p * 5)(*[P[0]] * 5)
+    assert lib.mmf_pf_measure_multi(four, 5, 2, F32, P[1], four, four, 0, four, None, 4, 64, 3, None) == EINVAL
+    assert lib.mmf_pf_measure_multi(four, 2, 2, F32, P[1], four, four, 0, four, None, 0, 64, 3, None) == 0  # empty batch
+    fa = _abi.MmfPfTrainFinalizeArgs()
+    for k in ("pw", "pb", "p_first", "p_head", "p_dout", "p_traj", "grads", "bias_grad", "scratch"):
+        setattr(fa, k, P[0])
+    fa.T, fa.N, fa.SL, fa.S, fa.n_res, fa.d, fa.n_out, fa.join_in, fa.join_state_off = 2, 2, 1, 1, 2, 4, 1, 128, 64
+    assert lib.mmf_pf_train_finalize(ctypes.byref(fa), None) == EINVAL                                   # d > 3
+    fa.d, fa.join_state_off = 3, 100
+    assert lib.mmf_pf_train_finalize(ctypes.byref(fa), None) == EINVAL                                   # state columns outside the join layer
 
 
 def test_every_host_struct_of_the_binding_matches_the_header_field_by_field(tmp_path):
