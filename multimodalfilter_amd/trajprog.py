@@ -2,8 +2,16 @@
 
 A model describes its N-row network once as a list of LOAD / LINEAR / STORE instructions
 over LDS vector slots; ``run`` is then ONE HIP launch, whatever the number of layers.
-Weights are gathered (transposed, padded) from the owning ``nn.Module`` parameters into one
-device blob that is rebuilt lazily when a parameter changes.
+Weights are gathered (transposed, padded) on the DEVICE from the owning ``nn.Module`` parameters
+where they lie (``mmf_traj_pack``: one launch whenever a parameter has changed).
+
+The reference evaluates these networks as chains of ``nn.Linear`` / ReLU / add launches
+(``door_models/layers.py:11-40,66-95``, ``crossmodal_pf.py:74-106``, ``kf.py:81-126``,
+``crossmodal_kf.py:134-167``) and differentiates them with torch autograd inside
+``torchfilter.train.train_filter`` (``train_helpers.py:124-162``).  Round 5: ``run_autograd`` is that
+differentiation in HIP -- the forward program stashes every vector it forms, ``_TrainPlan`` derives a
+REVERSE program from the instruction list (same kernel, same slot file), ``mmf_traj_weight_grads`` forms
+the parameter gradients from the two stashes.
 """
 from typing import Dict, List, Optional, Sequence, Tuple
 
