@@ -126,7 +126,7 @@ def pmc_traffic_k4_ekf():
         total, found = 0.0, 0
         for prefix in ("stem_conv2a_kernel<false", "conv2b_conv3_kernel<false", "conv4_kernel", "fc_partial_f16x3_kernel", "fc_tail_kernel<false"):
             hits = [v for name, v in k.items() if name.startswith(prefix)]
-            if hits:  # conv4_kernel only with MMF_K4_CONV4_KERNEL=1: conv 16->8 runs inside conv2b_conv3
+            if hits:  # (conv 16->8 runs inside conv2b_conv3)
                 total += hits[0]["hbm_bytes_corrected"]
                 found += 1
         return total if found >= 4 else None

@@ -393,9 +393,6 @@ typedef struct MmfPfLoopArgs {
   uint32_t noise_step0;      /* noise_mode 2: step t of the loop draws counter step noise_step0 + t          */
   uint32_t noise_traj0;      /* noise_mode 2: global index of this shard's first trajectory                  */
   int32_t noise_mode;        /* 0: `noise` tensor; 2: generated inside the dynamics kernel (`noise` may be null) */
-  int32_t use_graph;         /* != 0 (and events == null): capture the loop's launches on `stream` into a   */
-                             /* hipGraph and launch that instead (A/B switch; the executable graph is kept  */
-                             /* by the library until its launch has completed -- mmf_loop_graphs_release)   */
   float soft_alpha;          /* 0 or 1: plain resampling; 0 < alpha < 1 (resample_mode != 0): torchfilter's soft      */
                              /* resampling (mmf_pf_reweight_resample_soft) -- the survivors carry importance weights, */
                              /* so every step reads and writes the log-weights                                        */
@@ -444,8 +441,6 @@ int mmf_philox_normals(unsigned long long seed, unsigned step, unsigned traj0, f
 int mmf_philox_uniforms(unsigned long long seed, unsigned step0, unsigned traj0, float* out, int T, int N,
                         void* stream);
 
-/* Waits for and frees every executable graph a use_graph loop left behind (process shutdown, tests). */
-void mmf_loop_graphs_release(void);
 
 /* Open-loop rollout of the dynamics model: replaces torchfilter's DynamicsModel.forward_loop (external
  * dependency; call sites crossmodal/eval_helpers.py:135-137, scripts/door_task/eval_dynamics.py:36-38):

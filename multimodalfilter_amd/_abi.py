@@ -86,7 +86,7 @@ class MmfPfLoopArgs(Structure):
                 ("final_location", POINTER(c_int32)), ("events", POINTER(c_void_p)),
                 ("event_stride", c_int32), ("loglik_steps", _FP), ("indices_steps", _FP),
                 ("noise_seed", ctypes.c_uint64), ("noise_step0", ctypes.c_uint32), ("noise_traj0", ctypes.c_uint32),
-                ("noise_mode", c_int32), ("use_graph", c_int32),
+                ("noise_mode", c_int32),
                 ("soft_alpha", ctypes.c_float), ("estimate_argmax", c_int32), ("estimate_scratch", _FP),
                 ("persistent", c_int32), ("n_sync_words", c_int32), ("sync_words", _FP)]
 
@@ -157,7 +157,6 @@ SIGNATURES = {
     "mmf_pf_argmax_estimate": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_pf_persistent_plan": (c_int, [c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "mmf_pf_persistent_sync_words": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "mmf_loop_graphs_release": (None, []),
     "mmf_pf_dynamics_philox": (c_int, [_FP, c_int, c_int, _FP, _FP, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
                                        _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
     "mmf_philox_normals": (c_int, [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _FP, c_int, c_int, c_int, c_void_p]),

@@ -5,8 +5,6 @@
 // fused models: no interpreter work, tensor allocation or pointer marshalling between steps,
 // so small problems (the reference's own evaluation: a few dozen trajectories x 300
 // particles) are bound by kernel time instead of ~0.15 ms/step of host overhead.
-#include <mutex>
-#include <vector>
 
 #include "mmf_common.h"
 
@@ -106,59 +104,6 @@ static int pf_enqueue_steps(const MmfPfLoopArgs* a, void* stream, bool with_even
 }
 
 
-// ---- optional hipGraph replay of a whole loop (MmfPfLoopArgs.use_graph): the T x (2 + n_meas) launches are
-// captured on the caller's stream, instantiated and launched as ONE graph.  An executable graph has to
-// outlive its launch, so finished ones are reaped at the next call (an event marks completion).
-namespace {
-struct PendingGraph { hipGraphExec_t exec; hipGraph_t graph; hipEvent_t done; };
-std::vector<PendingGraph>& pending_graphs() { static std::vector<PendingGraph> v; return v; }
-std::mutex& pending_mutex() { static std::mutex m; return m; }
-
-void reap_graphs(bool wait) {
-  std::lock_guard<std::mutex> lock(pending_mutex());
-  auto& v = pending_graphs();
-  for (size_t i = 0; i < v.size();) {
-    if (wait) (void)hipEventSynchronize(v[i].done);
-    if (hipEventQuery(v[i].done) == hipSuccess) {
-      (void)hipGraphExecDestroy(v[i].exec);
-      (void)hipGraphDestroy(v[i].graph);
-      (void)hipEventDestroy(v[i].done);
-      v[i] = v.back();
-      v.pop_back();
-    } else {
-      ++i;
-    }
-  }
-}
-
-// The caller's stream is usually the legacy default stream, which cannot be captured
-// (hipErrorStreamCaptureUnsupported): the launches are captured on a private non-blocking stream and the
-// instantiated graph is launched on the caller's stream, in order with everything already enqueued there.
-template <class F>
-int run_as_graph(hipStream_t hs, F&& enqueue) {
-  reap_graphs(false);
-  static thread_local hipStream_t capture_stream = nullptr;  // one per calling thread
-  hipError_t e;
-  if (!capture_stream && (e = hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking)) != hipSuccess)
-    return static_cast<int>(e);
-  if ((e = hipStreamBeginCapture(capture_stream, hipStreamCaptureModeThreadLocal)) != hipSuccess) return static_cast<int>(e);
-  const int rc = enqueue(static_cast<void*>(capture_stream));
-  hipGraph_t graph = nullptr;
-  e = hipStreamEndCapture(capture_stream, &graph);
-  if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-  if (e != hipSuccess) return static_cast<int>(e);
-  PendingGraph p{};
-  p.graph = graph;
-  if ((e = hipGraphInstantiate(&p.exec, graph, nullptr, nullptr, 0)) != hipSuccess) { (void)hipGraphDestroy(graph); return static_cast<int>(e); }
-  if ((e = hipGraphLaunch(p.exec, hs)) != hipSuccess) return static_cast<int>(e);
-  if ((e = hipEventCreateWithFlags(&p.done, hipEventDisableTiming)) != hipSuccess) return static_cast<int>(e);
-  if ((e = hipEventRecord(p.done, hs)) != hipSuccess) return static_cast<int>(e);
-  std::lock_guard<std::mutex> lock(pending_mutex());
-  pending_graphs().push_back(p);
-  return 0;
-}
-}  // namespace
-
 extern "C" int mmf_pf_forward_loop(const MmfPfLoopArgs* a, void* stream) {
   MmfPfLoopArgs launches;
   if (a && a->persistent) {  // ONE launch for all T steps (small problems)
@@ -170,12 +115,8 @@ extern "C" int mmf_pf_forward_loop(const MmfPfLoopArgs* a, void* stream) {
     launches.persistent = 0;
     a = &launches;
   }
-  if (a && a->use_graph && !a->events)
-    return run_as_graph(static_cast<hipStream_t>(stream), [&](void* cs) { return pf_enqueue_steps(a, cs, false); });
   return pf_enqueue_steps(a, stream, true);
 }
-
-extern "C" void mmf_loop_graphs_release(void) { reap_graphs(true); }
 
 // Open-loop rollout x_t = f(x_{t-1}, u_t): replaces torchfilter's DynamicsModel.forward_loop (call
 // sites /root/reference/crossmodal/eval_helpers.py:135-137, scripts/door_task/eval_dynamics.py:36-38).

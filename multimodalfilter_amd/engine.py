@@ -135,9 +135,6 @@ def image_encoder_precision_code() -> int:
     return _abi.IMAGE_PRECISIONS[IMAGE_ENCODER_PRECISION or DEFAULT_PRECISION]
 
 
-# hipGraph replay of the native particle-filter step loop (A/B switch, off by default: at the reference's
-# evaluation size the launches enqueued from C already keep the GPU 93 % busy -- DESIGN.md, T3)
-LOOP_GRAPH = os.environ.get("MMF_LOOP_GRAPH", "0") not in ("", "0")
 # Small particle-filter loops (mmf_pf_persistent_plan > 0: e.g. the reference's 32 x 300 evaluation) as ONE persistent
 # launch per forward_loop: role-specialised workgroups keep one network's weights in LDS for all T steps and hand the
 # particles over through L2 (csrc/pf_persistent.inc); bit-identical to the launch-per-step loop.  "0": A/B, off.

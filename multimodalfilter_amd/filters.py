@@ -331,7 +331,6 @@ class ParticleFilter(base.Filter):
                 self.last_resample_indices = torch.empty((T, N, M), dtype=torch.int32, device=dev)
                 a.indices_steps = ctypes.c_void_p(_abi.ptr(self.last_resample_indices, dtype=torch.int32))
         a.range_flag = ctypes.c_void_p(engine.range_flag(dev).data_ptr())
-        a.use_graph = int(engine.LOOP_GRAPH)
         if do_resample and self.soft_resample_alpha < 1.0:
             a.soft_alpha = float(self.soft_resample_alpha)  # survivors carry importance weights (mmf_pf_reweight_resample_soft)
         if self.estimation_method == "argmax":
@@ -339,7 +338,7 @@ class ParticleFilter(base.Filter):
             keep.append(est_scratch)
             a.estimate_argmax, a.estimate_scratch = 1, P(est_scratch)
         timer = engine.kernel_timer()
-        if (engine.PF_PERSISTENT and mode == 1 and timer is None and not self.record_indices and not engine.LOOP_GRAPH
+        if (engine.PF_PERSISTENT and mode == 1 and timer is None and not self.record_indices
                 and a.soft_alpha == 0.0 and not a.estimate_argmax and d in (2, 3)
                 and dyn._net.n_res == 3 and all(net.n_res == 2 for net, _b, _l in nets)
                 and _abi.pf_persistent_plan(N, M, len(nets)) > 0):

@@ -50,7 +50,7 @@ def eval_regime(args, dev):
     out = {"regime": "eval", "filter": "DoorCrossmodalParticleFilter", "batch": N, "particles": M, "steps": T,
            "ms_per_step": 1e3 * best / T, "particle_steps_per_s": N * M * T / best,
            "ms_per_forward_loop": 1e3 * best, "encoders_ms_per_step": enc_ms / T, "recursion_ms_per_step": (1e3 * best - enc_ms) / T,
-           "persistent": os.environ.get("MMF_PF_PERSISTENT", "1"), "graph": os.environ.get("MMF_LOOP_GRAPH", "0")}
+           "persistent": os.environ.get("MMF_PF_PERSISTENT", "1")}
     if not args.no_cpu:
         torch.set_num_threads(min(16, os.cpu_count() or 1))
         Tc = 24

@@ -1,4 +1,4 @@
-"""Copy the judged summaries of a `scripts/profile_round.sh` run from gpurun_out/ into profiles/<round>/.
+"""Copy the judged summaries of a `scripts/profile_round_r05.sh` run from gpurun_out/ into profiles/<round>/.
 
     python scripts/collect_profiles.py gpurun_out/prof_final profiles/r01
 

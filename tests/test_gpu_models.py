@@ -746,45 +746,6 @@ def test_full_size_crossmodal_ekf_matches_oracle_on_a_shard():
     assert rel_err(cov_loop.cpu()[sel], wc) < REL_TOL, rel_err(cov_loop.cpu()[sel], wc)
 
 
-def test_native_step_loop_as_hip_graph_equals_direct_launches():
-    """``MmfPfLoopArgs.use_graph``: the same T x 4 launches captured into one hipGraph and replayed --
-    estimates and belief identical to the directly enqueued loop, twice in a row (the executable graph
-    of the first call is reaped by the second)."""
-    _need_gpu()
-    import multimodalfilter_amd as mmf
-    from multimodalfilter_amd import _abi, engine, synthetic
-
-    dev = torch.device("cuda:0")
-    N, M, d, T = 32, 300, 3, 12
-    traj = {k: v.to(dev) for k, v in synthetic.make_trajectories(state_dim=d, T=T, N=N, seed=5).items()}
-    eps0, eps, us = synthetic.draw_filter_noise(T=T, N=N, M=M, state_dim=d, seed=6)
-    noise = (eps0.to(dev), torch.stack(eps).to(dev), torch.stack(us).to(dev))
-    torch.manual_seed(0)
-    f = mmf.door_models.DoorCrossmodalParticleFilter().to(dev).eval()
-    f.num_particles = M
-    obs = {k: traj[k][1:] for k in ("image", "gripper_pos", "gripper_sensors")}
-    cov = (torch.eye(d, device=dev) * 0.1)[None].expand(N, d, d)
-
-    def run():
-        f.noise = mmf.StackedNoise(*noise)
-        f.initialize_beliefs(mean=traj["states"][0], covariance=cov)
-        out = f.forward_loop(observations=obs, controls=traj["controls"][1:])
-        return out, f.particle_states.clone(), f.particle_log_weights.clone()
-
-    want = run()
-    old = engine.LOOP_GRAPH
-    engine.LOOP_GRAPH = True
-    try:
-        for _ in range(2):
-            got = run()
-            for a, b in zip(got, want):
-                assert torch.equal(a, b)
-    finally:
-        engine.LOOP_GRAPH = old
-        torch.cuda.synchronize()
-        _abi.load().mmf_loop_graphs_release()
-
-
 def test_rccl_executes_the_collectives_one_rank():
     """The exchange steps of the multi-GPU layout (X1 all-gather of per-sequence errors, the max-over-ranks clock,
     X2 the flat gradient all-reduce, the barrier) on the ``nccl`` (= RCCL) backend with DEVICE tensors.  This box
