@@ -60,6 +60,16 @@ def test_product_path_refuses_cpu_tensors():
         dyn(initial_states=torch.zeros(2, 3), controls=torch.zeros(2, 7))
     with pytest.raises(_abi.MmfError):
         _abi.ptr(torch.zeros(3))
+    # round 5's training entry points: host tensors are refused before any launch, there is no torch fallback behind them
+    from multimodalfilter_amd import engine
+
+    with pytest.raises(_abi.MmfError):
+        engine.Fc64Function.apply(torch.zeros(4, 8192), torch.zeros(64, 8192), torch.zeros(64))
+    with pytest.raises(_abi.MmfError):
+        dyn.encode_controls(torch.zeros(2, 7))
+    assert dyn._ctrl_prog is not None  # the program is built before the tensors are looked at
+    with pytest.raises(_abi.MmfError):
+        dyn._ctrl_prog.run_autograd({"controls": torch.zeros(2, 7)}, {"bias": 64}, 2)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
