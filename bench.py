@@ -97,66 +97,58 @@ BURN_IN = 24  # untimed particle-filter steps ahead of the warm-up: the cloud co
               # calibration at t = 0); the heads are calibrated to the TRACKING regime
 
 
-def pmc_traffic(kernel_key: str):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-    collected in separate runs of this same command; FETCH_SIZE doubled as the gfx950 note of
-    MI355X_MICROARCH.md prescribes).  ``None`` when no profile of this workload is committed."""
-    for rnd in ("r04", "r03", "r02"):       # the newest committed round that profiled this kernel
-        for fname in ("pmc_hbm_traffic.json", "pmc_hbm_traffic_f32.json"):
+def profile_rounds():
+    """``profiles/rNN`` directories, newest round first."""
+    import re
+    base = os.path.join(ROOT, "profiles")
+    try:
+        rounds = [d for d in os.listdir(base) if re.fullmatch(r"r\d+", d) and os.path.isdir(os.path.join(base, d))]
+    except OSError:
+        return []
+    return [os.path.join(base, d) for d in sorted(rounds, key=lambda d: int(d[1:]), reverse=True)]
+
+
+def _kernels_of(path):
+    with open(path) as fh:
+        return json.load(fh)["kernels"]
+
+
+def pmc_traffic(kernel_key: str, files=("pmc_hbm_traffic.json", "pmc_hbm_traffic_f32.json")):
+    """``(HBM bytes per launch, the committed file they come from)`` -- the rocprofv3 PMC passes of this same command
+    (FETCH_SIZE and WRITE_SIZE collected in separate runs; FETCH_SIZE doubled as the gfx950 note of MI355X_MICROARCH.md
+    prescribes), from the NEWEST ``profiles/rNN`` that profiled this kernel.  ``(None, None)`` when none did."""
+    for rnd in profile_rounds():
+        for fname in files:
+            path = os.path.join(rnd, fname)
             try:
-                with open(os.path.join(ROOT, "profiles", rnd, fname)) as fh:
-                    kernels = json.load(fh)["kernels"]
-                hits = [v for name, v in kernels.items() if name.startswith(kernel_key)]
+                hits = [v for name, v in _kernels_of(path).items() if name.startswith(kernel_key)]
                 if hits:
-                    return hits[0]["hbm_bytes_corrected"]
+                    return hits[0]["hbm_bytes_corrected"], os.path.relpath(path, ROOT)
             except (OSError, KeyError, ValueError):
                 pass
-    return None
+    return None, None
+
+
+# the kernels of ONE image-encoder launch sequence, by generation of K4 (newest first): round 6's resident kernel keeps B in
+# LDS; rounds 3-5 ran stem_conv2a + conv2b_conv3 (conv 16->8 inside); both end in the split-K linear layer
+K4_SEQUENCES = (("image_encoder_resident_kernel<false", "fc_partial_f16x3_kernel", "fc_tail_kernel<false"),
+                ("stem_conv2a_kernel<false", "conv2b_conv3_kernel<false", "fc_partial_f16x3_kernel", "fc_tail_kernel<false"))
 
 
 def pmc_traffic_k4_ekf():
-    """HBM bytes of ONE image-encoder launch sequence of the EKF bench (4096 images x 2 encoders), summed over
-    its five kernels, from the PMC passes of that very command (``profiles/r03/pmc_hbm_traffic_ekf.json``)."""
-    try:
-        path = os.path.join(ROOT, "profiles", "r04", "pmc_hbm_traffic_ekf.json")
-        if not os.path.exists(path):
-            path = os.path.join(ROOT, "profiles", "r03", "pmc_hbm_traffic_ekf.json")
-        with open(path) as fh:
-            k = json.load(fh)["kernels"]
-        total, found = 0.0, 0
-        for prefix in ("stem_conv2a_kernel<false", "conv2b_conv3_kernel<false", "conv4_kernel", "fc_partial_f16x3_kernel", "fc_tail_kernel<false"):
-            hits = [v for name, v in k.items() if name.startswith(prefix)]
-            if hits:  # (conv 16->8 runs inside conv2b_conv3)
-                total += hits[0]["hbm_bytes_corrected"]
-                found += 1
-        return total if found >= 4 else None
-    except (OSError, KeyError, ValueError, IndexError):
-        return None
-
-
-def pmc_traffic_k4_sequence(n_images: int, nets: int):
-    """HBM bytes of ONE fused image-encoder launch sequence (stem+conv2a, conv2b+conv3, conv 16->8,
-    linear partials + tail) from the committed K4 PMC passes (``scripts/bench_k4.py`` under
-    rocprofv3, ``profiles/r02/pmc_k4_traffic.json``), for the launch shape that was profiled."""
-    path = os.path.join(ROOT, "profiles", "r03", "pmc_k4_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r02", "pmc_k4_traffic.json")
-    shapes = {(2048, 2): ("131072", "131072", "131072", "131072", "262144"), (1024, 3): ("130560", "130560", "130560", "98304", "196608")}
-    if (n_images, nets) not in shapes:
-        return None
-    g = shapes[(n_images, nets)]
-    try:
-        with open(path) as fh:
-            k = json.load(fh)["kernels"]
-        want = (("stem_conv2a_kernel<false", g[0]), ("conv2b_conv3_kernel<false", g[1]), ("conv4_kernel", g[2]),
-                ("fc_partial_f16x3_kernel", g[3]), ("fc_tail_kernel<false", g[4]))
-        total = 0.0
-        for prefix, grid in want:
-            hits = [v for name, v in k.items() if name.startswith(prefix) and name.endswith(f"grid={grid}")]
-            total += hits[0]["hbm_bytes_corrected"]
-        return total
-    except (OSError, KeyError, ValueError):
-        return None
+    """``(HBM bytes, source file)`` of ONE image-encoder launch sequence of the EKF bench (4096 images x 2 encoders), summed
+    over its kernels, from the PMC passes of that very command (newest ``profiles/rNN/pmc_hbm_traffic_ekf.json``)."""
+    for rnd in profile_rounds():
+        path = os.path.join(rnd, "pmc_hbm_traffic_ekf.json")
+        try:
+            k = _kernels_of(path)
+        except (OSError, KeyError, ValueError):
+            continue
+        for seq in K4_SEQUENCES:
+            hits = [[v for name, v in k.items() if name.startswith(prefix)] for prefix in seq]
+            if all(hits):
+                return sum(h[0]["hbm_bytes_corrected"] for h in hits), os.path.relpath(path, ROOT)
+    return None, None
 
 
 def build_filter(wl, device, seed=0):
@@ -500,12 +492,7 @@ def main_train(args, wl):
     real = distributed.all_reduce_gradients
 
     def timed_all_reduce(module, average=True):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        n = real(module, average)
-        b.record()
-        marks.append((a, b))
-        return n
+        return real(module, average, marks)   # events (start, packed, reduced, end) on the stream around the exchange
 
     distributed.all_reduce_gradients = timed_all_reduce
     try:
@@ -529,7 +516,8 @@ def main_train(args, wl):
     sums = distributed.all_gather_rows(chk)
     if rank != 0:
         return
-    ar_ms = [a.elapsed_time(b) for a, b in marks]
+    ar_ms = [m[1].elapsed_time(m[2]) for m in marks]      # the collective alone (gloo: incl. its host round trip)
+    ex_ms = [m[0].elapsed_time(m[3]) for m in marks]      # pack kernel + collective + scale kernel; no copy back
     out = {"metric": "training particle-steps/sec (batch x particles x subsequence steps, forward + backward + optimiser)",
            "value": world * N * M * (L - 1) * K / dt, "unit": "particle-steps/s (forward + backward)",
            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak",
@@ -540,6 +528,8 @@ def main_train(args, wl):
                       "filter": wl["cls"], "batch_per_gpu": N, "particles": M, "subsequence_length": L, "global_batch": N * world,
                       "world_size_seen": world, "parallelism": f"data-parallel x{world}: replicated weights, one flat gradient all-reduce per step"},
            "allreduce_ms": (sum(ar_ms) / len(ar_ms)) if ar_ms else 0.0,
+           "gradient_exchange_ms": (sum(ex_ms) / len(ex_ms)) if ex_ms else 0.0,
+           "gradient_exchange": "torch.cat into one flat buffer, ONE in-place all-reduce, one scale kernel, p.grad re-pointed at views (no copy back)",
            "allreduce_elements": sum(p.numel() for p in f.parameters() if p.requires_grad),
            "weights_identical_across_ranks": bool((sums == sums[0]).all()),
            "loss_first_last": [losses[0], losses[-1]],
@@ -664,8 +654,10 @@ def leg_ekf(name, wl, *, K, W, device, seed=7100, cpu_batch=256, cpu_steps=6, pl
     dom = timer.summary().get("image_encoder")
     if dom:
         ach = dom["flops_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e12
+        traffic, source = pmc_traffic_k4_ekf() if (B == 1024 and not wl.get("blackout")) else (None, None)
         out["roofline"] = {"kernel": "image encoder launch sequence (K4) per chunk of images", "bound": "mfma", "achieved": ach,
-                           "peak": MFMA_PEAK["f16x3"], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK["f16x3"], "avg_us": 1e3 * dom["avg_ms"]}
+                           "peak": MFMA_PEAK["f16x3"], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK["f16x3"], "avg_us": 1e3 * dom["avg_ms"],
+                           "traffic": traffic, "traffic_source": source}
     cores = min(CPU_THREADS, os.cpu_count() or 1)
     base, parity = cpu_baseline_ekf(wl, f, d, cores, sample_batch=cpu_batch, sample_steps=cpu_steps)
     out["cpu_baseline"] = base
@@ -870,6 +862,7 @@ def main():
         lo, hi = distributed.shard_bounds(args.global_batch, rank, world)
         wl["batch"], scaling = hi - lo, "strong"
     K, W, B, M = args.steps, args.warmup, wl["batch"], wl["particles"]
+    rows_total = args.global_batch if args.global_batch else B * world   # what the evaluation all-gather assembles
     spec = mmf.door_models._ns.task if wl["task"] == "door" else mmf.push_models._ns.task
     d = spec.state_dim
     pf = wl["kind"] == "pf"
@@ -929,7 +922,7 @@ def main():
                 r.steps(*segs[0])
             if W > 0:  # the W warm-up steps cover the whole path, including the evaluation statistic
                 pred_w = r.steps(*segs[1])
-                distributed.all_gather_rows(evaluation.per_trajectory_mse(pred_w, tr["states"][segs[1][0] + 1:segs[1][1] + 1], start=0))
+                distributed.all_gather_rows(evaluation.per_trajectory_mse(pred_w, tr["states"][segs[1][0] + 1:segs[1][1] + 1], start=0), rows_total)
             engine.set_kernel_timer(timer)
             if sync_clock:
                 distributed.barrier()
@@ -937,7 +930,7 @@ def main():
             t0 = time.perf_counter()
             pred = r.steps(*segs[2])
             mse_local = evaluation.per_trajectory_mse(pred, tr["states"][segs[2][0] + 1:T_all + 1], start=mse_start)
-            mse_all = distributed.all_gather_rows(mse_local)  # RCCL all-gather of per-sequence errors
+            mse_all = distributed.all_gather_rows(mse_local, rows_total)  # RCCL all-gather of per-sequence errors: ONE collective when the shards are equal
             if sync_clock:
                 torch.cuda.synchronize()
                 distributed.barrier()
@@ -1016,8 +1009,9 @@ def main():
             "headline_opening_the_process_ms_per_step": 1e3 * first / K,
             "headline_after_f32_pass_fp64_study_and_1s_idle_ms_per_step": 1e3 * elapsed / K,
             "note": "value / ms_per_step are the LAST pass (pre-roll on other inputs, burn-in, W warm-up steps, then exactly K timed)"},
-        "traffic_source": "profiles/r04 (r03 / r02 where a kernel was not re-profiled): pmc_hbm_traffic*.json, pmc_k4_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                          "separate passes; bytes per launch = 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction)",
+        "traffic_method": "every roofline object names the committed file its `traffic` was read from (`traffic_source`: the newest "
+                          "profiles/rNN that profiled the kernel); rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this "
+                          "command, bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction)",
     }
     if calibration is not None:
         out["head_calibration_trace"] = [[w, round(a, 3), round(b, 4)] for w, a, b in calibration]
@@ -1026,9 +1020,10 @@ def main():
         dom = ks["particle_net_measure"]
         ach = dom["flops_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e12
         default_shape = (args.workload == "door_pf" and B == 256 and M == 4096)
+        traffic, source = pmc_traffic(k2_kernel_key(d, prec)) if default_shape else (None, None)
         r = {"kernel": k2_kernel_name(d, prec) + " (measurement network)", "bound": "mfma", "achieved": ach,
              "peak": MFMA_PEAK[prec], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK[prec],
-             "traffic": pmc_traffic(k2_kernel_key(d, prec)) if default_shape else None}
+             "traffic": traffic, "traffic_source": source}
         if prec == "f16x3":
             r["note"] = ("achieved counts ALGORITHMIC fp32 FLOPs; the kernel executes 3 f16 MFMA "
                          "products per algorithmic product (executed-MFMA fraction = 3 x frac)")
@@ -1044,20 +1039,20 @@ def main():
             k1 = ks.get("pf_reweight_resample")
             if k1:
                 gbs = k1["bytes_per_launch"] / (k1["avg_ms"] * 1e-3) / 1e9
+                traffic, source = pmc_traffic("pf_resample_systematic_kernel") if default_shape else (None, None)
                 out["roofline_k1"] = {"kernel": f"pf_resample_systematic_kernel<{d}, true>", "bound": "hbm",
                                       "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": gbs / HBM_PEAK_GBS,
-                                      "traffic": pmc_traffic("pf_resample_systematic_kernel") if default_shape else None}
+                                      "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source}
         if not pf and "image_encoder" in ks:
             # EKF steps are > 99 % image-encoder MACs: the K4 launch sequence
             # (stem + four 3x3 convolutions + linear tail) is the dominant "kernel"
             dom = ks["image_encoder"]
             ach = dom["flops_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "image encoder launch sequence (stem_conv2a_kernel, conv2b_conv3_kernel incl. conv 16->8, "
-                                         "fc_partial_f16x3_kernel, fc_tail_kernel) per chunk of images",
+            traffic, source = pmc_traffic_k4_ekf() if (B == 1024 and args.workload == "door_ekf") else (None, None)
+            out["roofline"] = {"kernel": "image encoder launch sequence (K4: convolution stack, fc_partial_f16x3_kernel, "
+                                         "fc_tail_kernel) per chunk of images",
                                "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK["f16x3"], "unit": "TFLOP/s",
-                               "frac": ach / MFMA_PEAK["f16x3"],
-                               "traffic": pmc_traffic_k4_ekf() if (B == 1024 and args.workload == "door_ekf") else None,
+                               "frac": ach / MFMA_PEAK["f16x3"], "traffic": traffic, "traffic_source": source,
                                "note": "ALGORITHMIC fp32 FLOPs (26.12 MMAC per image per encoder); every product is 3 f16 MFMA "
                                        "products (executed-MFMA fraction = 3 x frac); traffic = one launch sequence over 4096 "
                                        "images x 2 encoders (the image virtual sensor's and the weight model's), PMC passes of this command"}
@@ -1155,6 +1150,24 @@ def main():
         out["configs"] = run_configs(args, device, f, d, K, W)
         out["configs"]["seconds"] = round(time.perf_counter() - t_cfg, 1)
     out["bench_seconds"] = round(time.perf_counter() - t_start, 1)
+    # the figures a reader of a truncated record needs, as the LAST key of the line (a driver that keeps the tail of stdout
+    # keeps this) and, for the exact-f32 mode, inside `roofline` (kept whole by the driver's parser)
+    summary = {"value": out["value"], "ms_per_step": out["ms_per_step"],
+               "frac": (out.get("roofline") or {}).get("frac"), "traffic": (out.get("roofline") or {}).get("traffic")}
+    f32m = out.get("f32_mode")
+    if f32m:
+        summary.update(f32_value=f32m["value"], f32_ms_per_step=f32m["ms_per_step"], f32_frac=(f32m.get("roofline") or {}).get("frac"))
+        if out.get("roofline") is not None:
+            out["roofline"]["f32_mode"] = {"value": f32m["value"], "ms_per_step": f32m["ms_per_step"],
+                                           "frac": (f32m.get("roofline") or {}).get("frac"), "peak": MFMA_PEAK["f32"]}
+    for key, short in (("C2_door_crossmodal_pf_256x1024", "c2"), ("C3_push_crossmodal_pf_1024x4096", "c3"),
+                       ("C4_door_crossmodal_ekf_1024_per_gpu_share_of_8192", "c4"), ("C5_push_unimodal_pf_train_32x8192x16", "c5")):
+        leg = (out.get("configs") or {}).get(key) or {}
+        if "ms_per_step" in leg:
+            summary[short + "_ms_per_step"] = leg["ms_per_step"]
+            if leg.get("roofline"):
+                summary[short + "_frac"] = leg["roofline"]["frac"]
+    out["summary"] = {k: (float(f"{v:.6g}") if isinstance(v, float) else v) for k, v in summary.items()}
     print(json.dumps(out), flush=True)
 
 

@@ -52,13 +52,23 @@ def shard_trajectories(traj: Dict[str, torch.Tensor], rank: int, world: int) -> 
     return {k: v[:, lo:hi].contiguous() for k, v in traj.items()}
 
 
-def all_gather_rows(x: torch.Tensor) -> torch.Tensor:
-    """Concatenate per-rank ``(N_local, ...)`` tensors along dim 0 (ragged shards allowed)."""
+def all_gather_rows(x: torch.Tensor, total_rows: int = None) -> torch.Tensor:
+    """Concatenate per-rank ``(N_local, ...)`` tensors along dim 0 (ragged shards allowed).
+
+    ``total_rows``: the global row count, when the caller knows it (the evaluation path does: the shards are
+    ``shard_bounds(total_rows, rank, world)``).  If it divides evenly every rank holds ``total_rows / world`` rows and
+    knows that the others do -- ONE collective; otherwise the shard sizes are exchanged first (two)."""
     if _single():
         return x
     world = dist.get_world_size()
     # gloo moves host memory; RCCL moves device memory over xGMI
     comm_dev = x.device if dist.get_backend() == "nccl" else torch.device("cpu")
+    if total_rows is not None and total_rows % world == 0:
+        assert x.shape[0] == total_rows // world, (x.shape, total_rows, world)
+        mine = x.to(comm_dev).contiguous()
+        out = torch.empty((total_rows,) + tuple(x.shape[1:]), dtype=x.dtype, device=comm_dev)
+        dist.all_gather_into_tensor(out, mine)
+        return out.to(x.device)
     sizes = [torch.zeros(1, dtype=torch.int64, device=comm_dev) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([x.shape[0]], dtype=torch.int64, device=comm_dev))
     sizes = [int(s) for s in sizes]
@@ -84,28 +94,49 @@ def barrier():
         dist.barrier()
 
 
-def all_reduce_gradients(module: torch.nn.Module, average: bool = True) -> int:
-    """Data-parallel gradient exchange (X2): one flat all-reduce of every parameter gradient
+def all_reduce_gradients(module: torch.nn.Module, average: bool = True, marks: list = None) -> int:
+    """Data-parallel gradient exchange (X2): ONE flat all-reduce of every parameter gradient
     (<= 1.43 M fp32 = 5.7 MB for the largest filter; a ring over xGMI is per-link bound,
     2(P-1)/P * S / 153 GB/s ~ 65 us at P = 8 -- nothing to overlap at this size).
+
+    Device work per exchange: one pack kernel (``torch.cat`` of the gradients into a fresh flat buffer), the in-place
+    collective on that buffer, one scale kernel -- and NO copy back: every ``p.grad`` is re-pointed at its slice of the
+    reduced buffer (views; ``optimizer.step()`` reads them, ``zero_grad(set_to_none=True)`` drops them).  Round 5 copied
+    the result back with one ``copy_`` launch per parameter tensor (100+ per step around a 30-65 us collective).
+    ``marks``: a list that receives the CUDA events ``(start, packed, reduced, end)`` of this call (``bench.py
+    --workload push_train`` reports the collective apart from the pack / scale around it).
     Returns the number of elements reduced."""
     params = [p for p in module.parameters() if p.requires_grad]
     if not params:
         return 0
     if _single():
         return sum(p.numel() for p in params)
-    for p in params:
-        if p.grad is None:
-            p.grad = torch.zeros_like(p)
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
-    comm = flat if dist.get_backend() == "nccl" else flat.cpu()
-    dist.all_reduce(comm, op=dist.ReduceOp.SUM)
+    dev = params[0].device
+    ev = None
+    if marks is not None and dev.type == "cuda":
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    if ev:
+        ev[1].record()
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)      # in place, device memory, RCCL over xGMI
+        if ev:
+            ev[2].record()
+    else:                                                # gloo moves host memory
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host)
+        if ev:
+            ev[2].record()
     if average:
-        comm = comm / dist.get_world_size()
-    comm = comm.to(flat.device)
+        flat.div_(dist.get_world_size())
     off = 0
     for p in params:
         n = p.numel()
-        p.grad.copy_(comm[off:off + n].view_as(p))
+        p.grad = flat[off:off + n].view_as(p)
         off += n
+    if ev:
+        ev[3].record()
+        marks.append(tuple(ev))
     return off

@@ -241,7 +241,9 @@ def _checked(fn, *, step: bool):
             break
         # a bare training step runs the differentiable path (torch ops / exact-fp32 K6 kernels): no launch of it
         # writes the f16x3 flag, so there is nothing to clear or to read back (one blocking .item() per step otherwise)
-        if dev is None or dev.type != "cuda" or (step and use_autograd(self)):
+        # -- UNLESS the image encoder's precision was chosen explicitly (bf16 / f16x3: ImageConvsFunction then hands
+        # the flag to mmf_image_convs_train_forward), in which case the step is checked like any other
+        if dev is None or dev.type != "cuda" or (step and use_autograd(self) and not IMAGE_ENCODER_PRECISION):
             return fn(self, *args, **kwargs)
         depth = getattr(_CHECK, "depth", None)
         if depth is None:
@@ -658,6 +660,10 @@ class PfTrainLoopFunction(torch.autograd.Function):
             b = bufs[i]
             own = params[offs[i]:offs[i + 1]]
             flat = torch.empty(sum(p.numel() for p in own), dtype=torch.float32, device=dev)
+            # mmf_pf_train_finalize writes the gradients of (first layer, encoder block, join, residual blocks, head) in
+            # _sources() order, derived from (d, n_res, join_in, n_out) alone: hold the parameters' layout to that count
+            assert flat.numel() == U * d + U + (2 + 2 * net.n_res) * (U * U + U) + U * net.join.in_features + net.n_out * U + net.n_out, \
+                "a per-particle network whose _sources() layout differs from (d, n_res, join_in, n_out) cannot use mmf_pf_train_finalize"
             bias_grads.append(E(T * N, U))
             fa = _abi.MmfPfTrainFinalizeArgs()
             fa.T, fa.N, fa.SL, fa.S, fa.n_res, fa.d, fa.n_out = T, N, SL, int(a.n_splits), net.n_res, d, net.n_out
@@ -1066,7 +1072,7 @@ def encode_images(encoders, images: torch.Tensor):
         # and draining, profiles/r04: 0.265 PF against 0.31), a multiple of 256 so every workgroup of the persistent
         # grids gets the same number of images
         n_chunks = -(-N // _IMAGE_CHUNK)
-        per = min(_IMAGE_CHUNK, -(-(-(-N // n_chunks)) // 256) * 256) if N > 256 else N
+        per = max(1, min(_IMAGE_CHUNK, -(-(-(-N // n_chunks)) // 256) * 256) if N > 256 else N)  # N == 0: an empty loop
         for c0 in range(0, N, per):
             n = min(per, N - c0)
             chunk = images[c0:c0 + n]

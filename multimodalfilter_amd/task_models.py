@@ -8,8 +8,11 @@ parametrised factory; ``door_models`` / ``push_models`` expose the resulting cla
 
 Where the arithmetic runs:
 * per particle (N*M rows): dynamics and measurement MLPs -> ``csrc/particle_net.hip`` (K2)
-* per trajectory (N rows): control / observation encoders, CNNs, virtual sensors, weight
-  models -> device-side torch modules from ``layers.py`` (K4 image-encoder kernel: DESIGN.md)
+* per trajectory (N rows): control / observation encoders, virtual sensors, weight models ->
+  K7 programs (``trajprog.TrajProgram`` -> ``csrc/traj_program.hip``; reverse mode + parameter
+  gradients in ``csrc/traj_train.hip``); the image encoders -> K4 (``csrc/image_encoder.hip``).
+  The ``layers.py`` modules only HOLD the parameters under the reference's ``state_dict`` keys
+  (and run as torch ops under ``engine.set_training_backend("autograd")``, the cross-check)
 * EKF Jacobian -> forward-mode tangents in ``csrc/particle_net.hip`` (K5)
 """
 from dataclasses import dataclass

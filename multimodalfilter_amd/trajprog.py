@@ -355,6 +355,12 @@ class _TrainPlan:
                                                           bias_off=b_region if j == 0 else -1, reserved=0))
                     if xv["grad"]:          # g[source] += W_s^T dz: a LINEAR over the transposed block
                         out_pad = 64 if dim <= 64 else 128
+                        # the kernel's LINEAR epilogue stores whole padded tiles (out_pad columns from dst_off, all four
+                        # waves): a sub-range source must sit on a 64-column boundary and its padded tile must stay inside
+                        # the vector it belongs to, or the store would run into the next row of the slot
+                        assert off % 64 == 0 and off + out_pad <= -(-xv["width"] // 64) * 64, (
+                            f"reverse LINEAR into columns {off}..{off + dim} of a {xv['width']}-wide vector: sub-range sources "
+                            "that receive a gradient must start at a multiple of 64 and their 64 / 128-column tile must fit the vector")
                         parts.append((weight, col, dim, I.out_dim, out_pad))
                         started = sl in live
                         if not started and (off != 0 or dim != xv["width"]):
@@ -451,6 +457,10 @@ class TrajProgramFunction(torch.autograd.Function):
         _abi.traj_program(fwd, len(plan.fwd), prog._blob, io, R, *_footprint_of(plan.fwd))
         ctx.prog, ctx.plan, ctx.R, ctx.names_in, ctx.names_out, ctx.out_dims = prog, plan, R, names_in, names_out, out_dims
         ctx.in_shapes = [t.shape for t in tensors[:len(names_in)]]
+        # the reverse program multiplies by the transposed blob, which is packed from the parameters' CURRENT values at
+        # backward time: the parameters are not saved tensors (they are read in place), so autograd's own version check does
+        # not cover them -- keep their version counters and refuse a backward across an in-place update, as torch would
+        ctx.param_versions = [p._version for p in plan.params]
         ctx.save_for_backward(stash)
         return tuple(outs)
 
@@ -459,6 +469,12 @@ class TrajProgramFunction(torch.autograd.Function):
         plan, R = ctx.plan, ctx.R
         (stash,) = ctx.saved_tensors
         dev = stash.device
+        for p, v in zip(plan.params, ctx.param_versions):
+            if p._version != v:
+                raise RuntimeError(
+                    "one of the variables needed for gradient computation has been modified by an inplace operation: a "
+                    f"parameter of shape {tuple(p.shape)} of a per-trajectory program is at version {p._version}; expected "
+                    f"version {v} (the reverse program reads the weights in place: call backward before optimizer.step())")
         _fwd, bwd, desc = plan.device_state(dev)
         io = [None] * len(plan.bwd_io)
         io[plan.bwd_io["__stash"]] = stash

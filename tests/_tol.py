@@ -40,3 +40,20 @@ def rel_err_elementwise(got, want, floor: float = 1e-3) -> float:
     if top == 0.0:
         return float(got.abs().max())
     return float(((got - want).abs() / want.abs().clamp_min(floor * top)).max())
+
+
+def rel_err_finite(got, want) -> float:
+    """``rel_err`` over the entries where ``want`` is finite (log-likelihoods carry ``-inf`` for blacked-out modalities; the
+    caller asserts that the infinities sit at the same places): masked entries count as equal."""
+    import numpy as np
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    if want.ndim == 0:
+        return scalar_rel(got, want)
+    fin = np.isfinite(want)
+    return rel_err(torch.from_numpy(np.where(fin, got, 0.0)), torch.from_numpy(np.where(fin, want, 0.0)))
+
+
+def scalar_rel(got, want) -> float:
+    """|got - want| / |want| for two scalars (losses)."""
+    got, want = float(got), float(want)
+    return abs(got - want) / abs(want) if want != 0.0 else abs(got)

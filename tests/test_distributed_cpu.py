@@ -59,6 +59,14 @@ def _worker(rank, world, port, N, T, M, d, out_dir):
     mse = evaluation.per_trajectory_mse(pred, mine["states"][1:], start=1)
     distributed.barrier()
     gathered = distributed.all_gather_rows(mse)
+    if N % world == 0:  # equal shards and a caller that knows the total: ONE collective, same rows
+        calls = []
+        real_sizes = dist.all_gather
+        dist.all_gather = lambda *a, **k: (calls.append(1), real_sizes(*a, **k))[1]
+        try:
+            assert torch.equal(distributed.all_gather_rows(mse, N), gathered) and not calls
+        finally:
+            dist.all_gather = real_sizes
     slowest = distributed.max_over_ranks(float(rank + 1), torch.device("cpu"))
     assert slowest == float(world)
     if rank == 0:
@@ -67,8 +75,9 @@ def _worker(rank, world, port, N, T, M, d, out_dir):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_sharding_matches_single_process(tmp_path):
-    N, T, M, d = 5, 3, 16, 2  # ragged: rank 0 owns 3 trajectories, rank 1 owns 2
+@pytest.mark.parametrize("N", [5, 4])  # 5: ragged (rank 0 owns 3 trajectories, rank 1 owns 2); 4: equal shards = one collective
+def test_two_rank_sharding_matches_single_process(tmp_path, N):
+    T, M, d = 3, 16, 2
     port = _free_port()
     mp.spawn(_worker, args=(2, port, N, T, M, d, str(tmp_path)), nprocs=2, join=True)
     gathered = np.load(tmp_path / "gathered.npy")
@@ -125,6 +134,12 @@ def _grad_worker(rank, world, port, out_dir):
     local = [p.grad.clone() for p in net.parameters()]
     n = distributed.all_reduce_gradients(net)
     assert n == sum(p.numel() for p in net.parameters())
+    # round 6: no copy back -- every p.grad is a view of the ONE reduced buffer, in parameter order
+    base = next(net.parameters()).grad.untyped_storage().data_ptr()
+    off = 0
+    for p in net.parameters():
+        assert p.grad.untyped_storage().data_ptr() == base and p.grad.storage_offset() == off and p.grad.shape == p.shape
+        off += p.numel()
     torch.save({"local": local, "reduced": [p.grad.clone() for p in net.parameters()]},
                os.path.join(out_dir, f"g{rank}.pt"))
     dist.destroy_process_group()

@@ -122,14 +122,13 @@ def test_engine_ekf_equals_kalman_closed_form(d, loop):
     o.initialize_beliefs(mean=mu0, covariance=cov0)
     want_o = o.forward_loop(observations={"z": zs}, controls=us)
 
-    scale = max(1.0, float(want_o.abs().max()))
-    assert float((est - want_o).abs().max()) / scale < REL_TOL
+    assert rel_err(est, want_o, dims=1) < REL_TOL, rel_err(est, want_o, dims=1)
     cov = f._belief_covariance.cpu()
     assert rel_err(cov, o._belief_covariance) < REL_TOL, rel_err(cov, o._belief_covariance)
     for n in range(N):
         want = _kalman_closed_form(A, B, L, Rt, mu0[n], 0.1 * torch.eye(d), us[:, n], zs[:, n])
         for t in range(T):
-            assert float((est[t, n].double() - want[t][0]).abs().max()) / scale < REL_TOL, (n, t)
+            assert rel_err(est[t, n], want[t][0], dims=1) < REL_TOL, (n, t, rel_err(est[t, n], want[t][0], dims=1))
         assert rel_err(cov[n], want[-1][1]) < REL_TOL, (n, rel_err(cov[n], want[-1][1]))
 
 
@@ -177,7 +176,6 @@ def test_engine_pf_soft_resampling_tracks_oracle_and_kalman(mode):
     f.record_indices = True
     f.noise = mmf.ReplayNoise([eps0], [])
     f.initialize_beliefs(mean=mu0.to(dev), covariance=cov0.to(dev))
-    scale = max(1.0, float(want.abs().max()))
     differ = 0
     for t in range(T):
         f.particle_states = beliefs[t][0].to(dev).contiguous()
@@ -185,7 +183,7 @@ def test_engine_pf_soft_resampling_tracks_oracle_and_kalman(mode):
         f._spare_states = None
         f.noise = mmf.ReplayNoise([eps[t]], [uu[t]])
         est = f(observations={"z": zs[t].to(dev)}, controls=us[t].to(dev)).cpu()
-        assert float((est - want[t]).abs().max()) / scale < REL_TOL, t
+        assert rel_err(est, want[t], dims=1) < REL_TOL, (t, rel_err(est, want[t], dims=1))
         same = f.last_resample_indices.cpu().long() == want_idx[t]
         differ += int((~same).sum())
         lw = f.particle_log_weights.cpu()
@@ -273,7 +271,6 @@ def test_engine_pf_with_user_models_tracks_oracle_and_kalman(mode):
     f.record_indices = True
     f.noise = mmf.ReplayNoise([eps0] + eps, uu)
     f.initialize_beliefs(mean=mu0.to(dev), covariance=cov0.to(dev))
-    scale = max(1.0, float(want.abs().max()))
     # (a) teacher-forced: before every step the engine holds the belief the oracle held.  This
     # likelihood is sharply peaked, and systematic resampling walks a CUMULATIVE sum: one ancestor
     # that differs (a last-ulp difference between the GPU's and the CPU's torch arithmetic of the
@@ -286,7 +283,7 @@ def test_engine_pf_with_user_models_tracks_oracle_and_kalman(mode):
         f._spare_states = None
         f.noise = mmf.ReplayNoise([eps[t]], [uu[t]])
         est = f(observations={"z": zs[t].to(dev)}, controls=us[t].to(dev)).cpu()
-        assert float((est - want[t]).abs().max()) / scale < REL_TOL, t
+        assert rel_err(est, want[t], dims=1) < REL_TOL, (t, rel_err(est, want[t], dims=1))
         differ += int((f.last_resample_indices.cpu().long() != want_idx[t]).sum())
     assert differ <= 1e-3 * T * N * M, f"{differ} of {T * N * M} resample indices differ"
 
@@ -299,7 +296,7 @@ def test_engine_pf_with_user_models_tracks_oracle_and_kalman(mode):
             got = f.forward_loop(observations={"z": zs.to(dev)}, controls=us.to(dev)).cpu()
         else:
             got = torch.stack([f(observations={"z": zs[t].to(dev)}, controls=us[t].to(dev)).cpu() for t in range(T)])
-        assert float((got[0] - want[0]).abs().max()) / scale < REL_TOL  # no resampling history yet
+        assert rel_err(got[0], want[0], dims=1) < REL_TOL, rel_err(got[0], want[0], dims=1)  # no resampling history yet
         for n in range(N):
             kf = _kalman_closed_form(A, B, L, Rt, mu0[n], 0.1 * torch.eye(d), us[:, n], zs[:, n])
             for t in range(T):
@@ -544,8 +541,7 @@ def test_calibrated_headline_workload_free_running(calibrated_door_case, precisi
     finally:
         engine.set_default_precision(old)
     want, truth = c["want"], c["traj"]["states"][1:]
-    scale = max(1.0, float(want.abs().max()))
-    assert float((got[0] - want[0]).abs().max()) / scale < REL_TOL
+    assert rel_err(got[0], want[0], dims=1) < REL_TOL, rel_err(got[0], want[0], dims=1)
     # the two runs as draws of the same estimator: their distance against the posterior's own
     # spread (std of the particle cloud the estimate is a weighted mean of)
     worst = 0.0
@@ -594,9 +590,8 @@ def test_particle_count_adaptation_matches_oracle():
 
     want, S_o, W_o = run(otf.base, otf.filters, OReplay, "cpu")
     got, S_e, W_e = run(mmf.base, mmf.filters, mmf.ReplayNoise, dev)
-    scale = max(1.0, float(want.abs().max()))
-    assert float((got - want).abs().max()) / scale < REL_TOL
-    assert float((S_e - S_o).abs().max()) / max(1.0, float(S_o.abs().max())) < REL_TOL
+    assert rel_err(got, want, dims=1) < REL_TOL, rel_err(got, want, dims=1)
+    assert rel_err(S_e, S_o, dims=1) < REL_TOL, rel_err(S_e, S_o, dims=1)   # every particle's state vector
     assert float((W_e - W_o).abs().max()) < 1e-4
 
 
@@ -753,7 +748,7 @@ def test_engine_unscented_filter_known_answers(strategy):
     for n in range(N):
         want = _kalman_closed_form(A, B, L, Rt, mu0[n], 0.1 * torch.eye(d), us[:, n], zs[:, n])
         for t in range(T):
-            assert float((est[t, n].double() - want[t][0]).abs().max()) < REL_TOL * max(1.0, float(want[t][0].abs().max())), (n, t)
+            assert rel_err(est[t, n], want[t][0], dims=1) < REL_TOL, (n, t, rel_err(est[t, n], want[t][0], dims=1))
         assert rel_err(cov[n], want[-1][1]) < REL_TOL, (n, rel_err(cov[n], want[-1][1]))
 
     # (b)
@@ -782,8 +777,7 @@ def test_engine_unscented_filter_known_answers(strategy):
     odev = {k: v.to(dev) for k, v in obs.items()}
     loop = e.forward_loop(observations=odev, controls=ctrl.to(dev))
     cov_loop = e._belief_covariance.clone()
-    scale = max(1.0, float(want.abs().max()))
-    assert float((loop.cpu() - want).abs().max()) / scale < REL_TOL
+    assert rel_err(loop.cpu(), want, dims=1) < REL_TOL, rel_err(loop.cpu(), want, dims=1)
     assert rel_err(cov_loop, o._belief_covariance) < REL_TOL, rel_err(cov_loop, o._belief_covariance)
     e.initialize_beliefs(mean=x0.to(dev), covariance=cov0.to(dev))
     step = torch.stack([e(observations={k: v[t] for k, v in odev.items()}, controls=ctrl[t].to(dev)) for t in range(T)])

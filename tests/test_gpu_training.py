@@ -9,6 +9,8 @@ pytestmark = pytest.mark.gpu
 from oracle import models as om
 from oracle.tf.base import ReplayNoise
 
+from _tol import rel_err, scalar_rel
+
 
 @pytest.fixture()
 def autograd_backend():
@@ -45,7 +47,7 @@ GRAD_TOL = 5e-3  # observed up to 2.4e-3 (the 5x5 stem, 25 weights each summing 
 
 
 def _compare_grads(oracle, engine_model, loss_o, loss_e, min_checked=20):
-    assert abs(float(loss_e.detach()) - float(loss_o.detach())) < 1e-4 * max(1.0, abs(float(loss_o.detach())))
+    assert scalar_rel(loss_e.detach(), loss_o.detach()) < 1e-4
     loss_o.backward()
     loss_e.backward()
     eng = dict(engine_model.named_parameters())
@@ -107,7 +109,7 @@ def test_trainable_process_noise_gets_its_gradient(training_backend):
     gq_e = eng.dynamics_model.Q_scale_tril_diag.grad
     assert gq_e is not None and float(gq_o.abs().max()) > 0
     assert float((gq_e.cpu() - gq_o).abs().max()) / float(gq_o.abs().max()) < GRAD_TOL
-    assert abs(float(loss_e) - float(loss_o)) < 1e-4 * max(1.0, abs(float(loss_o)))
+    assert scalar_rel(loss_e, loss_o) < 1e-4
 
 
 @pytest.mark.parametrize("tname,cls,kind,N,M", [("door", "DoorCrossmodalParticleFilter", "crossmodal", 4, 30),
@@ -361,7 +363,7 @@ def test_train_filter_step_descends_and_matches_manual_sgd():
         loss0 = train.train_filter_step(f, batch, opt, initial_covariance=cov, noise=noise())
         engine.set_training_backend("autograd")
         loss_ref = train.filter_loss(g, batch, initial_covariance=cov, noise=noise())
-        assert abs(loss0 - float(loss_ref)) < 1e-4 * max(1.0, abs(loss0))
+        assert scalar_rel(loss0, loss_ref) < 1e-4
         loss_ref.backward()
         for (n, p), q in zip(f.named_parameters(), g.parameters()):
             if q.grad is None:
@@ -409,7 +411,7 @@ def test_training_step_at_config_c5_particle_count():
         loss_hip.backward()
         engine.set_training_backend("autograd")
         loss_ref = train.filter_loss(g, batch, initial_covariance=cov, noise=noise())
-        assert abs(float(loss_hip) - float(loss_ref)) < 1e-4 * max(1.0, abs(float(loss_ref)))
+        assert scalar_rel(loss_hip, loss_ref) < 1e-4
         loss_ref.backward()
         checked = 0
         for (n, p), q in zip(f.named_parameters(), g.parameters()):
@@ -462,7 +464,7 @@ def test_config_c5_training_step_with_reduced_precision_cnn(precision, loss_tol,
         loss = train.filter_loss(f, batch, initial_covariance=cov, noise=noise())
         loss.backward()
         assert calls and all(c == mmf._abi.IMAGE_PRECISIONS[precision] for c in calls)
-        assert abs(float(loss) - float(loss_ref)) < loss_tol * max(1.0, abs(float(loss_ref)))
+        assert scalar_rel(loss, loss_ref) < loss_tol
         assert precision == "f16x3" or float(loss) != float(loss_ref)  # bf16 really ran
         checked = 0
         for (n, p), q in zip(f.named_parameters(), g.parameters()):
@@ -699,7 +701,7 @@ def test_k6_image_convs_function_matches_fp64_autograd(N):
     a3 = F.conv2d(a2, w3, b3, padding=1) * m3
     ref = F.conv2d(a3, w4, b4, padding=1)
     want = torch.autograd.grad(ref, p64, gout.double())
-    assert float((a4.detach().cpu().double() - ref.detach()).abs().max()) / max(1.0, float(ref.abs().max())) < 1e-4
+    assert rel_err(a4.detach(), ref.detach(), dims=3) < 1e-4   # every image's (8, 32, 32) feature map
     for name, a, b in zip("w1 w2a w2b w3 w4 b1 b2a b2b b3 b4".split(), got, want):
         scale = max(1e-6, float(b.abs().max()))
         assert float((a.cpu().double() - b).abs().max()) / scale < 1e-4, name
@@ -744,8 +746,8 @@ def test_k6_dynamics_with_jacobian_matches_fp64_autograd(tname, N):
         got = torch.autograd.grad(loss, [xe, ue] + [ep[n] for n in names])
     finally:
         engine.set_training_backend(None)
-    assert float((mu.detach().cpu().double() - mu6.detach()).abs().max()) < 1e-4 * max(1.0, float(mu6.abs().max()))
-    assert float((A.detach().cpu().double() - A6.detach()).abs().max()) < 1e-4 * max(1.0, float(A6.abs().max()))
+    assert rel_err(mu.detach(), mu6.detach(), dims=1) < 1e-4
+    assert rel_err(A.detach(), A6.detach(), dims=2) < 1e-4
     for name, a, b in zip(["x", "controls"] + names, got, want):
         scale = max(1e-6, float(b.abs().max()))
         assert float((a.cpu().double() - b).abs().max()) / scale < 1e-4, name
@@ -805,9 +807,9 @@ def test_native_training_recursion_matches_stepwise(tname, cls, N, M, T, chunk_r
         engine.set_default_precision(old_prec)
         f.use_native_loop = True
     (l0, p0, g0, s0, w0), (l1, p1, g1, s1, w1) = results[False], results[True]
-    assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0))
-    assert float((p0 - p1).abs().max()) < 1e-5 * max(1.0, float(p0.abs().max()))
-    assert float((s0 - s1).abs().max()) < 1e-5 * max(1.0, float(s0.abs().max()))
+    assert scalar_rel(l1, l0) < 1e-5
+    assert rel_err(p1, p0, dims=1) < 1e-5
+    assert rel_err(s1, s0, dims=1) < 1e-5
     assert float((w0 - w1).abs().max()) < 1e-4
     assert set(g0) == set(g1) and len(g0) > 20
     # a gradient that is zero analytically (the head bias of a single measurement network: the log-weights are
