@@ -1,53 +1,54 @@
 """Where do the device-to-device copies of a bench.py run come from?
 
-rocprofv3's kernel stats of the headline command list ``__amd_rocclr_copyBuffer`` (hipMemcpyAsync D2D,
-what ``Tensor.copy_`` / ``.clone()`` / ``.contiguous()`` of a strided view become).  This runs ``bench.main()``
-under ``torch.profiler`` with Python stacks and prints every ``aten::copy_`` / ``aten::clone`` that spent device
-time, grouped by the innermost frame of this repository.
+rocprofv3's kernel stats of the headline command list ``__amd_rocclr_copyBuffer`` (hipMemcpyAsync D2D: what
+``Tensor.copy_`` / ``.clone()`` / ``.contiguous()`` of same-dtype dense tensors become).  This runs ``bench.main()``
+under a ``TorchDispatchMode`` that sees every ``aten::copy_`` / ``clone`` / ``_to_copy`` between CUDA tensors and books
+it to the innermost Python frame of this repository.
 
-    python scripts/debug/find_copies.py [bench.py flags ...]  > gpurun_out/find_copies.txt
+    python scripts/debug/find_copies.py [bench.py flags ...]  2> gpurun_out/find_copies.txt
 """
 import collections
 import os
 import sys
+import traceback
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
-from torch.profiler import ProfilerActivity, profile  # noqa: E402
+from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402
+
+SITES = collections.defaultdict(lambda: [0, 0])
+
+
+class CopyFinder(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = func.__name__ if hasattr(func, "__name__") else str(func)
+        if name.split(".")[0] in ("copy_", "clone", "_to_copy", "contiguous"):
+            ts = [a for a in args if isinstance(a, torch.Tensor)]
+            if ts and all(t.is_cuda for t in ts):
+                site = "?"
+                for fr in reversed(traceback.extract_stack()[:-1]):
+                    if fr.filename.startswith(ROOT) and "find_copies" not in fr.filename:
+                        site = f"{os.path.relpath(fr.filename, ROOT)}:{fr.lineno} ({fr.name})"
+                        break
+                same = len(ts) < 2 or (ts[0].dtype == ts[1].dtype)
+                rec = SITES[(name, site, "memcpy-shaped" if same and all(t.is_contiguous() for t in ts) else "kernel")]
+                rec[0] += 1
+                rec[1] += ts[0].numel() * ts[0].element_size()
+        return func(*args, **(kwargs or {}))
 
 
 def main():
     import bench
 
     sys.argv = ["bench.py"] + (sys.argv[1:] or ["--steps", "20", "--warmup", "5"])
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    with CopyFinder():
         bench.main()
-    by_site = collections.defaultdict(lambda: [0, 0.0, 0])
-    for ev in prof.events():
-        if ev.name not in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::_to_copy"):
-            continue
-        dev_us = getattr(ev, "device_time_total", 0.0) or getattr(ev, "cuda_time_total", 0.0)
-        if dev_us <= 0:
-            continue
-        site = "?"
-        for fr in ev.stack or ():
-            if ROOT in fr or "bench" in fr or "multimodalfilter_amd" in fr:
-                site = fr.replace(ROOT + "/", "")
-                break
-        rec = by_site[(ev.name, site)]
-        rec[0] += 1
-        rec[1] += dev_us
-    rows = sorted(by_site.items(), key=lambda kv: -kv[1][1])
-    print(f"{'calls':>7} {'device us':>12}  op  site", file=sys.stderr)
-    for (name, site), (n, us, _) in rows[:60]:
-        print(f"{n:7d} {us:12.1f}  {name}  {site}", file=sys.stderr)
-    kinds = collections.Counter()
-    for ev in prof.events():
-        if "Memcpy" in ev.name or "copyBuffer" in ev.name:
-            kinds[ev.name] += 1
-    print("memcpy-like device activities:", dict(kinds), file=sys.stderr)
+    rows = sorted(SITES.items(), key=lambda kv: -kv[1][0])
+    print(f"{'calls':>7} {'MB':>10}  op  kind  site", file=sys.stderr)
+    for (name, site, kind), (n, b) in rows[:80]:
+        print(f"{n:7d} {b / 1e6:10.2f}  {name}  {kind}  {site}", file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -57,3 +57,16 @@ def scalar_rel(got, want) -> float:
     """|got - want| / |want| for two scalars (losses)."""
     got, want = float(got), float(want)
     return abs(got - want) / abs(want) if want != 0.0 else abs(got)
+
+
+# Where the REFERENCE's own fp32 arithmetic is not accurate to 1e-4: the same formulas (oracle/, pinned to the golden vectors
+# bit for bit) evaluated in fp64 differ from the reference's fp32 output by the number given -- the posterior covariance of the
+# measurement-fused EKF after 3 steps is a difference of nearly equal matrices (``P - K H P``).  The engine is held to twice
+# that distance there; ``tests/test_oracle_golden.py::test_conditioning_exceptions_are_the_references_own_fp32_error``
+# re-measures the numbers on the CPU.  ``None``: the covariance has collapsed to rounding noise (|entries| <= 6e-10 under a
+# 0.1 I prior, fp64 says ~1e-17): there is no relative error to speak of, the engine is held to 1e-4 of the PRIOR's scale.
+REFERENCE_FP32_GAP = {
+    "filter_kf_meas_crossmodal/door/n1m1/belief_covariance": 1.38e-3,
+    "filter_kf_meas_unimodal/door/n4m8/belief_covariance": None,
+}
+PRIOR_COVARIANCE_SCALE = 0.1

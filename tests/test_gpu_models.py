@@ -14,7 +14,7 @@ from oracle import golden_cases as gc
 from oracle import models as om
 from oracle.tf.base import ReplayNoise
 
-from _tol import REL_TOL, rel_err, rel_err_finite
+from _tol import PRIOR_COVARIANCE_SCALE, REFERENCE_FP32_GAP, REL_TOL, rel_err, rel_err_finite
 
 
 def _need_gpu():
@@ -111,6 +111,13 @@ def test_engine_matches_reference_vectors(golden, on_gpu, case, tname, n, m):
         got = out[k]
         assert got.shape == want.shape, k
         np.testing.assert_array_equal(np.isneginf(got), np.isneginf(want), err_msg=k)
+        if prefix + k in REFERENCE_FP32_GAP:   # the reference's own fp32 arithmetic is not 1e-4 accurate here (tests/_tol.py)
+            gap = REFERENCE_FP32_GAP[prefix + k]
+            if gap is None:
+                assert float(np.abs(got - want).max()) < REL_TOL * PRIOR_COVARIANCE_SCALE, k
+            else:
+                assert rel_err_finite(got, want) < 2 * gap, f"{k}: rel err {rel_err_finite(got, want):.3e} against the reference's own {gap:.2e}"
+            continue
         err = rel_err_finite(got, want)   # per vector / per matrix, 1e-4 of its own Frobenius norm (tests/_tol.py)
         assert err < REL_TOL, f"{k}: rel err {err:.3e}"
 

@@ -71,3 +71,32 @@ def test_parameter_counts_match_reference():
                 PushUnimodalKalmanFilter=313168, PushUnimodalParticleFilter=696993)
     for name, count in want.items():
         assert sum(p.numel() for p in om.build(name).parameters()) == count, name
+
+
+def test_conditioning_exceptions_are_the_references_own_fp32_error(golden):
+    """``tests/_tol.REFERENCE_FP32_GAP``: the two golden outputs the GPU suite does not hold to 1e-4 relative.  The oracle
+    reproduces the reference's fp32 output exactly there (``test_oracle_matches_reference_vectors``); evaluated in fp64 the
+    same formulas land the recorded distance away -- the reference's own rounding error, not the engine's."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _tol import PRIOR_COVARIANCE_SCALE, REFERENCE_FP32_GAP, rel_err
+
+    z = golden["door"]
+    inp = {k[len("input/"):]: z[k] for k in z.files if k.startswith("input/")}
+    inp64 = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in inp.items()}
+    task = om.TASKS["door"]
+    for key, gap in REFERENCE_FP32_GAP.items():
+        name, tname, shape, out_key = key.split("/")
+        case = next(c for c in gc.CASES if c.name == name)
+        n, m = (int(x) for x in shape[1:].split("m"))
+        torch.set_default_dtype(torch.float64)
+        try:
+            out64 = gc.run_case(case, case.make(task).double(), task, inp64, n, m)[out_key]
+        finally:
+            torch.set_default_dtype(torch.float32)
+        want = z[key]
+        if gap is None:  # collapsed to rounding noise: fp64 says zero to 1e-12 of the prior
+            assert np.abs(want).max() < 1e-8 * PRIOR_COVARIANCE_SCALE and np.abs(out64).max() < 1e-12 * PRIOR_COVARIANCE_SCALE
+        else:
+            measured = rel_err(out64, want)
+            assert 0.8 * gap < measured < 1.25 * gap, (key, measured)
