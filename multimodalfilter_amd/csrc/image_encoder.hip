@@ -64,6 +64,7 @@ struct Layout {
   int g3;                // f16x3 conv 32->16 for v_mfma_f32_16x16x32_f16: [tap][hi|lo][lane][8 halves]
   int q2a, q2b, q3, qs;  // MMF_PREC_BF16 twins of h2a / h2b / g3 / hs: same fragment order, slot "hi" = bf16(w), slot "lo" unused
   int g4;                // f16x3 conv 16->8 for v_mfma_f32_16x16x32_f16, two taps per MFMA: [tap pair][hi|lo][lane][8 halves]
+  int g4x;               // f16x3 conv 16->8 for v_mfma_f32_32x32x16_f16 with the three kx taps in M (row 8 kx + co, rows 24-31 zero): [ky][hi|lo][lane][8 halves]
   int total;
 };
 // floats (= halves / 2) of a 3x3 conv in f16x3 fragment order [tap][kc][hi|lo][lane][8 halves]
@@ -99,6 +100,7 @@ __host__ __device__ constexpr Layout layout() {
   L.q3 = o; o += 9 * 2 * 64 * 8 / 2;
   L.qs = o; o += 2 * 2 * 64 * 8 / 2;
   L.g4 = o; o += 5 * 2 * 64 * 8 / 2;
+  L.g4x = o; o += 3 * 2 * 64 * 8 / 2;
   L.total = o;
   return L;
 }
@@ -171,6 +173,19 @@ __global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ o
       v = d.res_w[1][o * kFeat + k];
     } else if (q0 < L.h2a) {
       v = d.res_b[1][q0 - L.r2b];
+    } else if (q0 >= L.g4x) {
+      // conv 16->8 in 32x32x16 A fragments, one per ky: element i of lane (row, h) = W[co][ci = 8 h + i][ky][kx] with
+      // row = 8 kx + co (rows 24 .. 31 zero): the three kx taps of a row of taps share one pass over the input fragment
+      unsigned short hb[2];
+      for (int z = 0; z < 2; ++z) {
+        const int he = 2 * (q0 - L.g4x) + z;
+        const int i = he & 7, lane = (he >> 3) & 63, part = (he >> 9) & 1, ky = he >> 10;
+        const int row = lane & 31, kx = row >> 3, co = row & 7, ci = 8 * (lane >> 5) + i;
+        const float w = kWScale * (row < 24 && co < cout4 ? d.conv_w[4][(co * 16 + ci) * 9 + 3 * ky + kx] : 0.f);
+        const __half hi = __float2half_rn(w);
+        hb[z] = part ? __half_as_ushort(__float2half_rn(w - __half2float(hi))) : __half_as_ushort(hi);
+      }
+      v = __uint_as_float(static_cast<unsigned>(hb[0]) | (static_cast<unsigned>(hb[1]) << 16));
     } else if (q0 >= L.g4) {
       // conv 16->8 in 16x16x32 fragments: element i of lane (co, q) for tap pair p = input channel
       // 8 (q & 1) + i of tap 2 p + (q >> 1) (the tenth tap is zero)

@@ -1066,7 +1066,7 @@ def encode_images(encoders, images: torch.Tensor):
             if not hasattr(e, "_mmf_packed"):
                 object.__setattr__(e, "_mmf_packed", PackedImageEncoder(e))
             packs.append(e._mmf_packed.blob())
-        feats = [torch.empty((N, 64), dtype=torch.float32, device=images.device) for _ in grp]
+        pieces = []  # per chunk: (nets, n, 64), written by the launch sequence itself
         # bounded workspace: at most _IMAGE_CHUNK images per launch sequence, in EQUAL chunks (round 5: 5,120 images run
         # as 2 x 2,560, not 4,096 + 1,024 -- the short chunk's persistent grids spent a third of their launch filling
         # and draining, profiles/r04: 0.265 PF against 0.31), a multiple of 256 so every workgroup of the persistent
@@ -1082,10 +1082,15 @@ def encode_images(encoders, images: torch.Tensor):
             flag = range_flag(images.device)
             _timed("image_encoder", image_encoder_flops(n) * len(grp), 0.0,
                    lambda: _abi.image_encoder(packs, chunk, feat, ws, flag, prec, variant))
-            for k in range(len(grp)):
-                feats[k][c0:c0 + n] = feat[k]
+            pieces.append(feat)
+        # round 6: no copy per chunk and network (round 5's `feats[k][c0:c0 + n] = feat[k]` was the bench's 1,500
+        # `copyBuffer` launches, scripts/debug/find_copies.py): one chunk = views of what the kernels wrote, several
+        # chunks = one concatenation per network
         for k, i in enumerate(grp):
-            out[i] = feats[k]
+            if not pieces:
+                out[i] = torch.empty((0, 64), dtype=torch.float32, device=images.device)
+            else:
+                out[i] = pieces[0][k] if len(pieces) == 1 else torch.cat([p[k] for p in pieces], dim=0)
     return out
 
 

@@ -116,7 +116,7 @@ def test_engine_matches_reference_vectors(golden, on_gpu, case, tname, n, m):
             if gap is None:
                 assert float(np.abs(got - want).max()) < REL_TOL * PRIOR_COVARIANCE_SCALE, k
             else:
-                assert rel_err_finite(got, want) < 2 * gap, f"{k}: rel err {rel_err_finite(got, want):.3e} against the reference's own {gap:.2e}"
+                assert rel_err_finite(got, want) < 4 * gap, f"{k}: rel err {rel_err_finite(got, want):.3e} against the reference's own {gap:.2e}"
             continue
         err = rel_err_finite(got, want)   # per vector / per matrix, 1e-4 of its own Frobenius norm (tests/_tol.py)
         assert err < REL_TOL, f"{k}: rel err {err:.3e}"
