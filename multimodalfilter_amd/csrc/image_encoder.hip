@@ -11,10 +11,10 @@
 //   MMF_PREC_F32    one launch per layer, fp32 activations in HBM, exact fp32 products on
 //                   v_mfma_f32_16x16x4_f32 (conv_kernel below: M = output channels, N = 16 pixels of a
 //                   row, K = (tap, 4 input channels); input band + zero halo in LDS as [ci][row][40]).
-//   MMF_PREC_F16X3  (default) image_encoder_fused.inc: stem + conv 32->32, conv 32->32 + skip +
-//                   conv 32->16, and conv 16->8 as three fused persistent kernels with the activations
-//                   in LDS as split f16 planes; then the split-K linear tail below.
-//   MMF_PREC_BF16   the first two of those kernels with single bf16 products.
+//   MMF_PREC_F16X3  (default) image_encoder_resident.inc: the whole convolution stack as ONE resident
+//                   producer / consumer kernel, every activation in LDS row rings as split f16 planes
+//                   (only the image and the 8-channel map E cross HBM); then the split-K linear tail below.
+//   MMF_PREC_BF16   the same kernel with single bf16 products in the stem and the 32 -> 32 / 32 -> 16 convolutions.
 // The per-layer f16x3 kernels (conv_f16x3_kernel<32,...>) remain as the TRAINING forward (every activation kept).
 // The 8192->64 linear is a split-K MFMA GEMM followed by a one-wave-per-image tail (bias, ReLU,
 // ResLinear 64).  Rooflines and measurements: DESIGN.md section 3, K4.
@@ -63,7 +63,6 @@ struct Layout {
   int hs;                // f16x3 5x5 stem as 2 k-steps of 16 taps: [k-step][hi|lo][lane][8 halves]
   int g3;                // f16x3 conv 32->16 for v_mfma_f32_16x16x32_f16: [tap][hi|lo][lane][8 halves]
   int q2a, q2b, q3, qs;  // MMF_PREC_BF16 twins of h2a / h2b / g3 / hs: same fragment order, slot "hi" = bf16(w), slot "lo" unused
-  int g4;                // f16x3 conv 16->8 for v_mfma_f32_16x16x32_f16, two taps per MFMA: [tap pair][hi|lo][lane][8 halves]
   int g4x;               // f16x3 conv 16->8 for v_mfma_f32_32x32x16_f16 with the three kx taps in M (row 8 kx + co, rows 24-31 zero): [ky][hi|lo][lane][8 halves]
   int total;
 };
@@ -99,7 +98,6 @@ __host__ __device__ constexpr Layout layout() {
   L.q2b = o; o += conv_h_floats(32);
   L.q3 = o; o += 9 * 2 * 64 * 8 / 2;
   L.qs = o; o += 2 * 2 * 64 * 8 / 2;
-  L.g4 = o; o += 5 * 2 * 64 * 8 / 2;
   L.g4x = o; o += 3 * 2 * 64 * 8 / 2;
   L.total = o;
   return L;
@@ -186,22 +184,9 @@ __global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ o
         hb[z] = part ? __half_as_ushort(__float2half_rn(w - __half2float(hi))) : __half_as_ushort(hi);
       }
       v = __uint_as_float(static_cast<unsigned>(hb[0]) | (static_cast<unsigned>(hb[1]) << 16));
-    } else if (q0 >= L.g4) {
-      // conv 16->8 in 16x16x32 fragments: element i of lane (co, q) for tap pair p = input channel
-      // 8 (q & 1) + i of tap 2 p + (q >> 1) (the tenth tap is zero)
-      unsigned short hb[2];
-      for (int z = 0; z < 2; ++z) {
-        const int he = 2 * (q0 - L.g4) + z;
-        const int i = he & 7, lane = (he >> 3) & 63, part = (he >> 9) & 1, pair = he >> 10;
-        const int co = lane & 15, q = lane >> 4, tap = 2 * pair + (q >> 1);
-        const float w = kWScale * (co < cout4 && tap < 9 ? d.conv_w[4][(co * 16 + 8 * (q & 1) + i) * 9 + tap] : 0.f);
-        const __half hi = __float2half_rn(w);
-        hb[z] = part ? __half_as_ushort(__float2half_rn(w - __half2float(hi))) : __half_as_ushort(hi);
-      }
-      v = __uint_as_float(static_cast<unsigned>(hb[0]) | (static_cast<unsigned>(hb[1]) << 16));
     } else if (q0 >= L.q2a) {
       // bf16 twins (round to nearest even): same index -> weight maps as h2a / h2b / g3 / hs, "lo" slots zero
-      const int offs[5] = {L.q2a, L.q2b, L.q3, L.qs, L.g4};
+      const int offs[5] = {L.q2a, L.q2b, L.q3, L.qs, L.g4x};
       int c = 0;
       while (q0 >= offs[c + 1]) ++c;
       unsigned short hb[2];
@@ -1018,7 +1003,8 @@ extern "C" size_t mmf_image_encoder_floats(void) { return static_cast<size_t>(la
 
 extern "C" size_t mmf_image_encoder_workspace_bytes(int n_images, int n_nets) {
   if (n_images < 0 || n_nets < 1 || n_nets > kMaxNets) return 0;
-  // three 32-channel activation tensors (ping, pong, skip) + FC partial sums
+  // three 32-channel activation tensors (ping, pong, skip: the exact-fp32 per-layer path; the resident kernel uses the
+  // first 8 channels of the third for E) + FC partial sums
   const size_t act = static_cast<size_t>(n_nets) * n_images * 32 * kImg * kImg;
   return (3 * act + static_cast<size_t>(n_nets) * kFcSplit * n_images * kFeat) * sizeof(float);
 }
@@ -1065,17 +1051,8 @@ extern "C" int mmf_image_encoder(const float* const* packed, int n_nets, const f
     FusedArgs fa{};
     for (int i = 0; i < n_nets; ++i) fa.packed[i] = packed[i];
     fa.images = images; fa.N = N; fa.range_flag = range_flag;
-    static const bool two_kernels = getenv("MMF_K4_TWO_KERNELS") != nullptr;  // A/B switch while round 6 measures the resident kernel
-    if (!two_kernels) {
-      fa.out_e = bufC;
-      if ((rc = launch_resident(fa, n_nets, bf16, s))) return rc;
-    } else {
-    fa.out = bufA;
-    if ((rc = launch_fused(fa, n_nets, 0, bf16, s))) return rc;
-    fa.bin = bufA; fa.out = bufB;
     fa.out_e = bufC;
-    if ((rc = launch_fused(fa, n_nets, 1, bf16, s))) return rc;
-    }
+    if ((rc = launch_resident(fa, n_nets, bf16, s))) return rc;
     bufB = bufC;  // the linear tail reads E
   } else {
   // conv 1 -> 32, k5, ReLU                      images -> A

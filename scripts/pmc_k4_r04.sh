@@ -17,7 +17,7 @@ cd $R
 python3 - "$P" "$OUT/$TAG.json" <<'PY'
 import collections, csv, glob, json, sys
 src, dst = sys.argv[1:3]
-want = {"conv2b_conv3": "conv2b_conv3_kernel<false, 2, true>", "stem_conv2a": "stem_conv2a_kernel<false>", "fc_partial": "fc_partial_f16x3_kernel", "jacobian": "particle_net_kernel<3, 3, 2",
+want = {"resident": "image_encoder_resident_kernel<false>", "conv2b_conv3": "conv2b_conv3_kernel<false, 2, true>", "stem_conv2a": "stem_conv2a_kernel<false>", "fc_partial": "fc_partial_f16x3_kernel", "jacobian": "particle_net_kernel<3, 3, 2",
         "traj_program": "traj_program_kernel"}
 dur = collections.defaultdict(list)
 for f in glob.glob(f"{src}/**/*kernel_trace.csv", recursive=True):
@@ -35,6 +35,8 @@ out = {"command": "scripts/pmc_k4_r04.sh: rocprofv3 --pmc <8 counters> --kernel-
        "unit": "counter value per launch (sum over the chip), averaged over the launches of the pass; us = kernel-trace duration under the counters",
        "kernels": {}}
 for k in want:
+    if not dur[k]:
+        continue  # a kernel of an earlier round
     c = {n: sum(v) / len(v) for n, v in sorted(cnt[k].items())}
     us = sum(dur[k]) / max(len(dur[k]), 1)
     row = {"launches": len(dur[k]), "avg_us_under_pmc": round(us, 2), "counters": {n: round(v) for n, v in c.items()}}
