@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 38
+#define MMF_ABI_VERSION 39
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -575,35 +575,22 @@ typedef struct MmfPfTrainArgs {
   float* g_logw_b;
   float* d_tmp;
   int32_t* range_flag;
-  int32_t compact;           /* ABI 35.  1: the recompute buffers in half the bytes -- `stash` and `dz` are then f16 arrays of
-                                the SAME SHAPES (half the allocation), activations stored as f16 and the pre-activation
-                                gradients as f16 relative to the largest magnitude of their 32-row tile, kept in `dz_scale`; the
-                                weight-gradient products of the f16 values are exact (f16 MFMA, fp32 accumulate).  With
-                                `compact` ALONE the data path of the backward (d_states, the masks, the recursion's
-                                gradients) is untouched: only the parameter gradients see the rounding (2^-11 relative per
-                                stored element, measured <= 1e-3 of the gradient norm -- tests/test_gpu_training.py).
-                                (`backward_f16x3` below additionally moves the DATA path to three-product f16 arithmetic:
-                                see there.)  0: fp32 buffers (bit-identical to ABI 34) */
-  float* dz_scale;           /* compact: scratch (max(NLd, NLm) + 1, chunk_traj M); else unused */
-  int32_t recompute_f16x3;   /* ABI 36.  backward, with compact = 1 and precision = MMF_PREC_F16X3: the recompute of a step's
-                                activations runs on `packed` (the forward pass's f16x3 blob) with the forward pass's own
-                                three-product arithmetic instead of exact fp32 products on `packed_f32`: the stash and the
-                                ReLU masks are then those of the forward pass that produced the loss.  0: exact fp32 */
-  int32_t backward_f16x3;    /* ABI 36.  backward, with compact = 1: `packed_t` of every network is an MMF_PREC_F16X3 blob of
-                                the transposed layers and the backward data path multiplies on the f16 MFMA with three
-                                products per product; each ROW of a layer's input is scaled by the power of two that
-                                brings its largest magnitude to [2^7, 2^8) and its result scaled back (exact: the backward
-                                is linear in the gradients and rows do not mix).  This changes the numerics of d_states and of
-                                every gradient that flows to earlier steps / the per-trajectory networks: 22 bits per element
-                                down to 2^-14 of its row's largest magnitude (measured vs the exact-fp32 backward: 1.6e-6
-                                overall, <= 5.5e-5 in the worst row).  0: exact fp32 products on an MMF_PREC_F32 blob */
-  int32_t fused;             /* ABI 37.  backward, with compact = recompute_f16x3 = backward_f16x3 = 1: every network's recompute,
-                                backward data path and weight gradients run as ONE kernel per network call
-                                (mmf_particle_net_train_fused: layer inputs and pre-activation gradients never reach HBM);
-                                each MmfTrainNet then carries `packed_dual`, and pw / pb are (NL, n_splits, 64, 64) /
-                                (NL, n_splits, 64) partials, ZEROED by the caller, one slot per workgroup (n_splits <= 256 =
-                                the largest grid).  stash / dz / dz_scale then only hold the three rows-by-64 slots the narrow
-                                reductions read (layer slots 2 and NL).  fused_act, fused_g_act: scratch (chunk_traj M, 64) fp32 */
+  float* dz_scale;           /* scratch: fp32 row scales of `dz` -- (max(NLd, NLm) + 1, chunk_traj M); fused: (sets, 2, chunk_traj M).
+                                ABI 39: `stash` and `dz` are ALWAYS f16 arrays (activations as f16, pre-activation gradients as f16
+                                relative to the largest magnitude of their 32-row tile, kept here; the weight-gradient products
+                                of the f16 values are exact: f16 MFMA, fp32 accumulate).  The fp32 buffers of ABI 34 (`compact = 0`)
+                                and the three-pass f16x3 recompute / backward of ABI 36 (`recompute_f16x3`, `backward_f16x3`) are
+                                gone: superseded by `fused`, timings kept in profiles/r05/bench_train_fused_ab.txt */
+  int32_t fused;             /* ABI 37.  1 (needs precision = MMF_PREC_F16X3): every network's recompute (in the forward pass's
+                                own three-product f16 arithmetic, on `packed`), backward data path and weight gradients run as ONE
+                                kernel per network call (mmf_particle_net_train_fused: layer inputs and pre-activation gradients
+                                never reach HBM); each MmfTrainNet then carries `packed_dual`, and pw / pb are (NL, n_splits, 64, 64)
+                                / (NL, n_splits, 64) partials, ZEROED by the caller, one slot per workgroup (n_splits <= 256 = the
+                                largest grid).  stash / dz / dz_scale then only hold the three rows-by-64 slots the narrow
+                                reductions read (layer slots 2 and NL).  fused_act, fused_g_act: scratch (chunk_traj M, 64) fp32.
+                                0: three passes per network call with EXACT fp32 products (recompute on `packed_f32`, transposed
+                                layers `packed_t` an MMF_PREC_F32 blob) over the f16 buffers -- the f32 engine mode's training path
+                                and the cross-check of the fused kernel (MMF_TRAIN_FUSED=0) */
   float* fused_act;
   float* fused_g_act;
   int32_t fused_sets;        /* ABI 38.  >= n_meas > 1: stash / dz / dz_scale / d_tmp hold one set of row slots per

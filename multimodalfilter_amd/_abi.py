@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 38
+ABI_VERSION = 39
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16, PREC_F16X3_DUAL = 0, 1, 2, 3
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
@@ -106,7 +106,7 @@ class MmfPfTrainArgs(Structure):
                 ("states", _FP), ("logw", _FP), ("estimates", _FP), ("d_states0", _FP), ("d_logw0", _FP),
                 ("stash", _FP), ("mask", _FP), ("dz", _FP), ("raw", _FP), ("d_raw", _FP), ("loglik", _FP), ("ll_steps", _FP),
                 ("g_states_a", _FP), ("g_states_b", _FP), ("g_logw_a", _FP), ("g_logw_b", _FP), ("d_tmp", _FP),
-                ("range_flag", _FP), ("compact", c_int32), ("dz_scale", _FP), ("recompute_f16x3", c_int32), ("backward_f16x3", c_int32),
+                ("range_flag", _FP), ("dz_scale", _FP),
                 ("fused", c_int32), ("fused_act", _FP), ("fused_g_act", _FP), ("fused_sets", c_int32)]
 
 

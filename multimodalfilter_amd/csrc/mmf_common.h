@@ -18,10 +18,10 @@
 int mmf_internal_pf_persistent(const MmfPfLoopArgs* args, void* stream);
 #define MMF_INTERNAL_NOT_RESIDENT (-1000)  /* its grid would not be co-resident on this device: take the launch path */
 
-// COMPACT recompute buffers of the native training recursion (particle_net_train.inc; MmfPfTrainArgs.compact)
-int mmf_internal_train_forward_h(const float* packed, int precision, int n_res, int kind, const float* states, const float* traj_bias,
+// the exact-fp32 three-pass backward of the native training recursion over f16 recompute buffers (particle_net_train.inc)
+int mmf_internal_train_forward_h(const float* packed, int n_res, int kind, const float* states, const float* traj_bias,
                                  void* stash_h, uint32_t* mask, float* out, int N, int M, int d, void* stream);
-int mmf_internal_train_backward_h(const float* packed_t, int precision, const float* head_w, int n_res, int kind, const uint32_t* mask,
+int mmf_internal_train_backward_h(const float* packed_t, const float* head_w, int n_res, int kind, const uint32_t* mask,
                                   const float* d_out, void* dz_h, float* dz_scale, float* d_states, int R, int d, void* stream);
 int mmf_internal_weight_grads_h(const void* dz_h, const float* dz_scale, const void* stash_h, float* partial_w, float* partial_b,
                                 int n_layers, int R, int n_splits, int accumulate, void* stream);

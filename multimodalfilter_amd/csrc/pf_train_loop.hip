@@ -150,50 +150,34 @@ extern "C" int mmf_pf_train_backward(const MmfPfTrainArgs* a, void* stream) {
   const int NLmax = NLd > NLm ? NLd : NLm;
   // fused (ABI 37): recompute + backward + weight gradients of a network call as ONE kernel (particle_net_fused.hip);
   // stash / dz / dz_scale then hold only the three (C, 64) row slots of the narrow reductions
-  const bool fused = a->fused != 0;
-  if (fused && (!a->compact || !a->recompute_f16x3 || !a->backward_f16x3 || a->precision != MMF_PREC_F16X3 || !a->fused_act ||
-                !a->fused_g_act || a->n_splits > 256))
-    return MMF_EINVAL;
   const size_t Cmax = static_cast<size_t>(a->chunk_traj < N ? a->chunk_traj : N) * M;
-  // compact: stash / dz are f16 arrays of the same shapes (element offsets are the same, bytes half) + row scales of dz
-  const bool cmp = a->compact != 0;
-  if (cmp && !a->dz_scale) return MMF_EINVAL;
-  const size_t esz = cmp ? 2 : 4;
-  const bool f16r = cmp && a->recompute_f16x3 != 0 && a->precision == MMF_PREC_F16X3;
-  const bool f16b = cmp && a->backward_f16x3 != 0;
+  const bool fused = a->fused != 0;
+  if (fused && (a->precision != MMF_PREC_F16X3 || !a->fused_act || !a->fused_g_act || a->n_splits > 256)) return MMF_EINVAL;
+  if (!fused && a->precision != MMF_PREC_F32) return MMF_EINVAL;  // the three passes multiply exact fp32 products
+  if (!a->dz_scale) return MMF_EINVAL;
+  // stash / dz are f16 arrays (ABI 39: always) + fp32 row scales of dz
+  const size_t esz = 2;
   auto stash_of = [&](int set) { return reinterpret_cast<char*>(a->stash) + 0 * esz; };
   auto dz_of = [&](int set) { return reinterpret_cast<char*>(a->dz) + 0 * esz; };
-  auto scale_of = [&](int set) { return cmp ? a->dz_scale + 0 : nullptr; };
+  auto scale_of = [&](int set) { return a->dz_scale + 0; };
   auto net_fwd = [&](const MmfTrainNet& net, int n_res, int kind, const float* xs, const float* bias, char* stash, uint32_t* mask,
                      float* raw, int Nc, hipStream_t s) {
-    // compact + recompute_f16x3: the recompute in the forward pass's own arithmetic, on the forward pass's blob
-    return cmp ? (f16r ? mmf_internal_train_forward_h(net.packed, MMF_PREC_F16X3, n_res, kind, xs, bias, stash, mask, raw, Nc, M, d, s)
-                       : mmf_internal_train_forward_h(net.packed_f32, MMF_PREC_F32, n_res, kind, xs, bias, stash, mask, raw, Nc, M, d, s))
-               : mmf_particle_net_train_forward(net.packed_f32, n_res, kind, xs, bias, reinterpret_cast<float*>(stash), mask, raw, Nc, M, d, s);
+    return mmf_internal_train_forward_h(net.packed_f32, n_res, kind, xs, bias, stash, mask, raw, Nc, M, d, s);
   };
   auto net_bwd = [&](const MmfTrainNet& net, int n_res, int kind, const uint32_t* mask, const float* d_out, char* dz, float* sc,
                      float* d_states, int Ci, hipStream_t s) {
-    // backward_f16x3: `packed_t` is then the f16x3 blob of the transposed layers
-    return cmp ? mmf_internal_train_backward_h(net.packed_t, f16b ? MMF_PREC_F16X3 : MMF_PREC_F32, net.head_w, n_res, kind, mask, d_out, dz, sc,
-                                               d_states, Ci, d, s)
-               : mmf_particle_net_train_backward(net.packed_t, net.head_w, n_res, kind, mask, d_out, reinterpret_cast<float*>(dz), d_states, Ci, d, s);
+    return mmf_internal_train_backward_h(net.packed_t, net.head_w, n_res, kind, mask, d_out, dz, sc, d_states, Ci, d, s);
   };
   auto net_wgrads = [&](const MmfTrainNet& net, const char* dz, const float* sc, const char* stash, int n_layers, int Ci, int acc,
-                        hipStream_t s) {
-    return cmp ? mmf_internal_weight_grads_h(dz, sc, stash, net.pw, net.pb, n_layers, Ci, S, acc, s)
-               : mmf_particle_net_weight_grads_acc(reinterpret_cast<const float*>(dz), reinterpret_cast<const float*>(stash), net.pw,
-                                                   net.pb, n_layers, Ci, S, acc, s);
-  };
+                        hipStream_t s) { return mmf_internal_weight_grads_h(dz, sc, stash, net.pw, net.pb, n_layers, Ci, S, acc, s); };
   // the narrow reductions read dz of the first layer (slot NL) and of the join (slot 2), and the head's input (stash slot NL)
   auto net_sgrads = [&](const MmfTrainNet& net, const char* dz, const float* sc, const char* stash, int NL, size_t C, const float* xs,
                         const float* d_out, size_t slot0, int Nc, int n_out, hipStream_t s) {
     const size_t oL = static_cast<size_t>(NL) * C * MMF_UNITS * esz, o2 = 2 * C * MMF_UNITS * esz;
     float *pf = net.p_first + slot0 * MMF_UNITS * 4, *ph = net.p_head + slot0 * 4 * MMF_UNITS, *pd = net.p_dout + slot0 * 4,
           *pt = net.p_traj + slot0 * MMF_UNITS;
-    return cmp ? mmf_internal_small_grads_h(dz + oL, sc + static_cast<size_t>(NL) * C, dz + o2, sc + 2 * C, stash + oL, xs, d_out, pf, ph,
-                                            pd, pt, Nc, M, d, n_out, SL, s)
-               : mmf_particle_net_small_grads(reinterpret_cast<const float*>(dz + oL), reinterpret_cast<const float*>(dz + o2),
-                                              reinterpret_cast<const float*>(stash + oL), xs, d_out, pf, ph, pd, pt, Nc, M, d, n_out, SL, s);
+    return mmf_internal_small_grads_h(dz + oL, sc + static_cast<size_t>(NL) * C, dz + o2, sc + 2 * C, stash + oL, xs, d_out, pf, ph,
+                                      pd, pt, Nc, M, d, n_out, SL, s);
   };
   // fused: one launch (dynamics: three) per network call, then the narrow reductions on the rows it left
   // row slots of one fused network call (set k of the caller's scratch when the step's networks share a launch)

@@ -484,35 +484,24 @@ class ParticleNetFunction(torch.autograd.Function):
 # buffers inside the 256 MiB Infinity Cache) 65.7, 65,536 56.1, 262,144 45.0 -- on-die hand-offs do not pay
 # for the small launches (150 KB of weights staged per workgroup for 4 tiles, half-empty grids)
 TRAIN_CHUNK_ROWS = int(os.environ.get("MMF_TRAIN_CHUNK_ROWS", "262144"))
-# MmfPfTrainArgs.compact: the recompute buffers of the backward in half the bytes (activations as f16, pre-activation
-# gradients as f16 relative to the largest magnitude of their 32-row tile + one fp32 scale per row and layer).  They are the
-# recursion's HBM traffic (written once, read once by the weight-gradient pass).  With this switch ALONE only the PARAMETER
-# gradients see the rounding (the backward's data path -- d_states, the recursion's gradients -- is computed in registers
-# from fp32); tests/test_gpu_training.py bounds it.  NOTE the defaults below: TRAIN_RECOMPUTE_F16X3 and
-# TRAIN_BACKWARD_F16X3 are ON as well, and with them the data path (d_states, every gradient that flows to earlier steps
-# and to the per-trajectory networks) runs in the forward pass's three-product f16 arithmetic with an exact power-of-two
-# scale PER ROW (an element keeps 22 bits down to 2^-14 of its own particle's largest gradient; measured against the
-# exact-fp32 backward: 1.6e-6 overall, <= 5.5e-5 in the worst row -- scripts/debug/bwd_h_check.py).  The reference trains
-# in fp32: MMF_TRAIN_BACKWARD_F16X3=0 (or MMF_PRECISION=f32) restores exact fp32 products on the data path.
-# MMF_TRAIN_COMPACT_STASH=0 restores the fp32 buffers (bit-identical to round 3).
-TRAIN_COMPACT_STASH = os.environ.get("MMF_TRAIN_COMPACT_STASH", "1") != "0"
-# MmfPfTrainArgs.recompute_f16x3 (with the compact buffers, when the engine's mode is f16x3): the backward recomputes a
-# step's activations with the arithmetic the forward pass used (the inference kernels' three f16 products per product)
-# instead of exact fp32 products -- the stash and the ReLU masks are then the forward pass's own, at a fifth of the
-# exact-fp32 MFMA time.  MMF_TRAIN_RECOMPUTE_F16X3=0: exact fp32 recompute (round 3).
-TRAIN_RECOMPUTE_F16X3 = os.environ.get("MMF_TRAIN_RECOMPUTE_F16X3", "1") != "0"
-# MmfPfTrainArgs.backward_f16x3 (with the two above): the backward DATA path (transposed layers on gradients) on the
-# three-product f16 arithmetic too, every layer's input tile scaled by an exact power of two into the f16 range and
-# the result scaled back (the backward is linear in the gradients).  MMF_TRAIN_BACKWARD_F16X3=0: exact fp32 products.
-TRAIN_BACKWARD_F16X3 = os.environ.get("MMF_TRAIN_BACKWARD_F16X3", "1") != "0"
-# MmfPfTrainArgs.fused (round 5, with the three above): recompute + backward data path + weight gradients of a network call
-# as ONE kernel (csrc/particle_net_fused.hip) -- layer inputs and pre-activation gradients never reach HBM; the weight
-# gradients accumulate in registers across the launch (one partial per workgroup).  MMF_TRAIN_FUSED=0: the three passes
-# over the compact buffers (round 4), kept as the cross-check of tests/test_gpu_training.py.
+# The backward of the native training recursion, per network call of a step (round 6: two forms, not six):
+#  * fused (default when the engine's mode is f16x3 and the networks have the reference's depths): recompute in the forward
+#    pass's own three-product f16 arithmetic + backward data path + weight gradients as ONE kernel
+#    (csrc/particle_net_fused.hip) -- layer inputs and pre-activation gradients never reach HBM, the weight gradients
+#    accumulate in registers across the launch (one partial per workgroup).  Numerics: the data path (d_states, every
+#    gradient that flows to earlier steps and to the per-trajectory networks) keeps 22 bits per element down to 2^-14 of its
+#    own particle's largest gradient (measured against the exact-fp32 backward: 1.6e-6 overall, <= 5.5e-5 in the worst row).
+#  * three passes with EXACT fp32 products over f16 recompute buffers (activations as f16, pre-activation gradients as f16
+#    relative to the largest magnitude of their 32-row tile: only the PARAMETER gradients see that rounding): the training
+#    path of the f32 engine mode (the reference trains in fp32: MMF_PRECISION=f32) and the cross-check of the fused kernel
+#    (MMF_TRAIN_FUSED=0, tests/test_gpu_training.py).
+# Rounds 3-4's other forms (fp32 buffers; f16x3 recompute / backward in three passes) are deleted; their timings are in
+# profiles/r05/bench_train_fused_ab.txt.
 TRAIN_FUSED = os.environ.get("MMF_TRAIN_FUSED", "1") != "0"
 TRAIN_FUSED_SLOTS = 256  # weight-gradient partials per layer = the largest grid of the fused kernel
-# the measurement networks of a step in one launch (MmfPfTrainArgs.fused_sets); MMF_TRAIN_FUSED_MERGE=0: one launch each
-TRAIN_FUSED_MERGE = os.environ.get("MMF_TRAIN_FUSED_MERGE", "1") != "0"
+# the measurement networks of a step share one launch (MmfPfTrainArgs.fused_sets); False: one launch each (what a filter with
+# ONE measurement network runs anyway; tests compare the two bit for bit)
+TRAIN_FUSED_MERGE = True
 
 
 class PfTrainLoopFunction(torch.autograd.Function):
@@ -591,16 +580,12 @@ class PfTrainLoopFunction(torch.autograd.Function):
         P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
         a = _abi.MmfPfTrainArgs()
         a.T, a.N, a.M, a.d, a.n_meas = T, N, M, d, K
-        # recompute in the forward pass's own arithmetic (f16x3 blobs) or with exact fp32 products
-        f16r = TRAIN_COMPACT_STASH and TRAIN_RECOMPUTE_F16X3 and ctx.fwd_precision == _abi.PREC_F16X3
         a.n_res_dyn, a.n_res_meas, a.logw_stride = dyn_net.n_res, meas[0][0].n_res, K_all
-        a.precision = _abi.PREC_F16X3 if f16r else _abi.PREC_F32
-        a.recompute_f16x3 = int(f16r)
-        f16b = bool(f16r and TRAIN_BACKWARD_F16X3)
-        a.backward_f16x3 = int(f16b)
         a.chunk_traj, a.n_splits, a.n_slices = chunk_traj, S, SL
-        fused = bool(f16b and TRAIN_FUSED and all(n.n_res == (3 if i == 0 else 2) for i, n in enumerate(nets)))
+        # fused: recompute in the forward pass's own arithmetic (f16x3 blobs); otherwise three passes of exact fp32 products
+        fused = bool(ctx.fwd_precision == _abi.PREC_F16X3 and TRAIN_FUSED and all(n.n_res == (3 if i == 0 else 2) for i, n in enumerate(nets)))
         a.fused = int(fused)
+        a.precision = _abi.PREC_F16X3 if fused else _abi.PREC_F32
         if fused:
             S = min(TRAIN_FUSED_SLOTS, max(1, -(-C // 128)))  # one partial per workgroup (4 tiles of 32 rows per pass)
             a.n_splits = S
@@ -619,11 +604,11 @@ class PfTrainLoopFunction(torch.autograd.Function):
                      p_dout=E(T, N * SL, 4), p_traj=E(T, N * SL, U))
             bufs.append(b)
             head_ws.append(params[offs[i + 1] - 2].to(torch.float32).contiguous())
-            tblobs.append(None if fused else _transposed_blob(net, _abi.PREC_F16X3 if f16b else _abi.PREC_F32))
+            tblobs.append(None if fused else _transposed_blob(net, _abi.PREC_F32))
             if fused:
                 tn.packed_dual = P(net.blob(_abi.PREC_F16X3_DUAL))
             tn.packed_f32 = P(ctx.blobs[i])
-            tn.packed = P(ctx.fwd_blobs[i]) if f16r else tn.packed_f32
+            tn.packed = P(ctx.fwd_blobs[i]) if fused else tn.packed_f32
             tn.packed_t, tn.head_w = P(tblobs[i]), P(head_ws[i])
             tn.pw, tn.pb, tn.p_first, tn.p_head, tn.p_dout, tn.p_traj = (P(b[k]) for k in ("pw", "pb", "p_first", "p_head", "p_dout", "p_traj"))
         for k in range(K):
@@ -632,8 +617,7 @@ class PfTrainLoopFunction(torch.autograd.Function):
             if keep["beta"] is not None and col is not None:
                 a.meas_logw[k] = ctypes.c_void_p(keep["beta"].data_ptr() + 4 * col)
         g_est = g_est.to(torch.float32).contiguous()
-        a.compact = int(TRAIN_COMPACT_STASH)
-        A = (lambda *shape: torch.empty(shape, dtype=torch.float16, device=dev)) if a.compact else E
+        A = lambda *shape: torch.empty(shape, dtype=torch.float16, device=dev)   # the recompute buffers are f16 (ABI 39)
         if fused:  # only the three (C, 64) row slots of the narrow reductions + the dynamics' encoder hand-offs
             fs = max(1, K)  # one set of row slots per measurement network: a step's networks share a launch
             scratch = dict(stash=A(fs, C, U), mask=None, dz=A(fs, 2, C, U), dz_scale=E(fs, 2, C), raw=None, d_raw=E(K + 8, C), ga=E(N, M, d), gb=E(N, M, d),
@@ -641,7 +625,7 @@ class PfTrainLoopFunction(torch.autograd.Function):
             a.fused_act, a.fused_g_act, a.fused_sets = P(scratch["act"]), P(scratch["g_act"]), (fs if TRAIN_FUSED_MERGE else 1)
         else:
             scratch = dict(stash=A(sets, NLmax + 1, C, U), mask=torch.empty((sets, NLmax + 1, C, 2), dtype=torch.int32, device=dev),
-                           dz=A(sets, NLmax + 1, C, U), dz_scale=E(sets, NLmax + 1, C) if a.compact else None, raw=E(sets, C, 8), d_raw=E(K + 8, C), ga=E(N, M, d), gb=E(N, M, d),
+                           dz=A(sets, NLmax + 1, C, U), dz_scale=E(sets, NLmax + 1, C), raw=E(sets, C, 8), d_raw=E(K + 8, C), ga=E(N, M, d), gb=E(N, M, d),
                            la=E(N, M), lb=E(N, M), d_tmp=E(sets, C, d), d_states0=E(N, M, d), d_logw0=E(N, M))
         a.dyn_bias, a.noise, a.scale_tril, a.g_estimates = P(keep["dyn_bias"]), P(keep["eps"]), P(keep["tril"]), P(g_est)
         a.states, a.logw, a.estimates = P(keep["states"]), P(keep["logw"]), P(keep["est"])
@@ -976,9 +960,9 @@ class Fc64Function(torch.autograd.Function):
 
 # round 5: the per-trajectory networks of a training step (vector encoders, weight model, hoisted join halves, the linear
 # tail of the image encoder) run forward AND backward in HIP (trajprog.TrajProgram.run_autograd, Fc64Function) under the
-# "hip" training backend.  MMF_TRAIN_TRAJ_PROGRAMS=0: torch modules + autograd (library GEMMs), the round-4 path, kept as
-# the cross-check of tests/test_gpu_training.py.
-TRAIN_TRAJ_PROGRAMS = os.environ.get("MMF_TRAIN_TRAJ_PROGRAMS", "1") != "0"
+# "hip" training backend.  The torch modules + autograd (library GEMMs) ARE the "autograd" backend; this flag lets
+# tests/test_gpu_training.py run them under the "hip" backend too, as the cross-check (no environment switch any more).
+TRAIN_TRAJ_PROGRAMS = True
 
 
 def use_traj_program_backward(*tensors) -> bool:

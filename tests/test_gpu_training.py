@@ -759,8 +759,7 @@ def test_k6_dynamics_with_jacobian_matches_fp64_autograd(tname, N):
     ("push", "PushUnimodalParticleFilter", 4, 64, 4, 128),
     ("door", "DoorParticleFilter", 3, 100, 3, 100),               # single measurement network, no modality weights
 ])
-@pytest.mark.parametrize("compact", [False, True], ids=["f32_buffers", "compact_buffers"])
-def test_native_training_recursion_matches_stepwise(tname, cls, N, M, T, chunk_rows, compact):
+def test_native_training_recursion_matches_stepwise(tname, cls, N, M, T, chunk_rows):
     """``engine.PfTrainLoopFunction`` (``mmf_pf_train_forward`` / ``mmf_pf_train_backward``: the whole
     recursion in two C calls, activations recomputed per chunk of trajectories, weight gradients
     accumulated on the device) against the step-by-step K6 path (one autograd Function per network call):
@@ -780,9 +779,8 @@ def test_native_training_recursion_matches_stepwise(tname, cls, N, M, T, chunk_r
     f = mmf.model_types(tname)[cls]().to(dev).train()
     f.num_particles = M
     engine.set_training_backend("hip")
-    old_chunk, old_prec, old_compact = engine.TRAIN_CHUNK_ROWS, engine.DEFAULT_PRECISION, engine.TRAIN_COMPACT_STASH
+    old_chunk, old_prec = engine.TRAIN_CHUNK_ROWS, engine.DEFAULT_PRECISION
     engine.TRAIN_CHUNK_ROWS = chunk_rows
-    engine.TRAIN_COMPACT_STASH = compact  # f16 recompute buffers (the default) or the fp32 ones: the same bounds hold
     # both paths on exact-fp32 products: with the default f16x3 forward the two particle sets differ by ~1e-6,
     # and on these tiny problems (a few hundred rows) ONE flipped ReLU moves a weight gradient by ~1e-2 of its
     # largest entry -- a property of the comparison, not of the kernels
@@ -803,7 +801,6 @@ def test_native_training_recursion_matches_stepwise(tname, cls, N, M, T, chunk_r
     finally:
         engine.set_training_backend(None)
         engine.TRAIN_CHUNK_ROWS = old_chunk
-        engine.TRAIN_COMPACT_STASH = old_compact
         engine.set_default_precision(old_prec)
         f.use_native_loop = True
     (l0, p0, g0, s0, w0), (l1, p1, g1, s1, w1) = results[False], results[True]
@@ -832,13 +829,14 @@ def test_native_training_recursion_matches_stepwise(tname, cls, N, M, T, chunk_r
     ("door", "DoorCrossmodalParticleFilter", 5, 300, 3, 600),     # ragged chunks
     ("push", "PushUnimodalParticleFilter", 8, 512, 4, 2048),
 ])
-def test_compact_recompute_buffers_change_only_the_rounding_of_parameter_gradients(tname, cls, N, M, T, chunk_rows):
-    """``MmfPfTrainArgs.compact`` (round 4: the backward's recompute buffers as f16 -- activations directly, the
-    pre-activation gradients relative to the largest magnitude of their 32-row tile with one fp32 scale per row and layer): the
-    forward recursion and the backward's DATA path (what flows to earlier steps) never read the buffers, so loss and
-    estimates are bit-identical; every parameter gradient stays within 1e-3 of its tensor's scale (f16 keeps 2^-11
-    per stored element and the products are summed over thousands of rows in fp32; observed <= 3e-4) -- and gradients
-    as small as 1e-9 survive (a plain f16 store of dz would flush them: the loss here is scaled by 1e-6)."""
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_gradients_of_any_magnitude_survive_the_f16_recompute_buffers(tname, cls, N, M, T, chunk_rows, precision):
+    """The backward's recompute buffers are f16 (activations directly, the pre-activation gradients relative to the
+    largest magnitude of their 32-row tile with one fp32 scale per row and layer -- three-pass form -- or relative to a
+    running exponent per layer -- fused form): a plain f16 store of ``dz`` would flush gradients of 1e-9.  The same step
+    with the loss scaled by 1e-6: identical estimates, and every parameter gradient 1e-6 times the unscaled one to 1e-3 of
+    its tensor's scale (the backward is linear in the loss; observed <= 3e-4), in the exact-fp32 three-pass form (f32 mode)
+    and in the fused form (f16x3 mode)."""
     import multimodalfilter_amd as mmf
     from multimodalfilter_amd import engine
 
@@ -853,16 +851,15 @@ def test_compact_recompute_buffers_change_only_the_rounding_of_parameter_gradien
     f = mmf.model_types(tname)[cls]().to(dev).train()
     f.num_particles = M
     engine.set_training_backend("hip")
-    old_chunk, old_compact, old_f16r = engine.TRAIN_CHUNK_ROWS, engine.TRAIN_COMPACT_STASH, engine.TRAIN_RECOMPUTE_F16X3
+    old_chunk, old_prec = engine.TRAIN_CHUNK_ROWS, engine.DEFAULT_PRECISION
     engine.TRAIN_CHUNK_ROWS = chunk_rows
-    engine.TRAIN_RECOMPUTE_F16X3 = False  # the buffers' FORMAT is what is compared: both sides recompute with exact fp32 products
+    engine.set_default_precision(precision)
     seen = []
     real = mmf._abi.pf_train_backward
-    mmf._abi.pf_train_backward = lambda a, *rest: (seen.append(int(a.compact)), real(a, *rest))[1]
+    mmf._abi.pf_train_backward = lambda a, *rest: (seen.append(int(a.fused)), real(a, *rest))[1]
     results = []
     try:
-        for compact, loss_scale in ((False, 1.0), (True, 1.0), (False, 1e-6), (True, 1e-6)):
-            engine.TRAIN_COMPACT_STASH = compact
+        for loss_scale in (1.0, 1e-6):
             f.zero_grad(set_to_none=True)
             f.noise = mmf.ReplayNoise([eps0] + eps, [])
             f.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
@@ -870,106 +867,40 @@ def test_compact_recompute_buffers_change_only_the_rounding_of_parameter_gradien
             loss = torch.mean((pred - target.to(dev)) ** 2) * loss_scale
             loss.backward()
             torch.cuda.synchronize()
-            results.append((loss.detach().clone(), pred.detach().clone(),
-                            {n: p.grad.detach().clone() for n, p in f.named_parameters() if p.grad is not None}))
+            results.append((pred.detach().clone(), {n: p.grad.detach().clone() for n, p in f.named_parameters() if p.grad is not None}))
     finally:
         mmf._abi.pf_train_backward = real
         engine.set_training_backend(None)
-        engine.TRAIN_CHUNK_ROWS, engine.TRAIN_COMPACT_STASH, engine.TRAIN_RECOMPUTE_F16X3 = old_chunk, old_compact, old_f16r
-    assert seen == [0, 1, 0, 1]
-    for (l0, p0, g0), (l1, p1, g1) in ((results[0], results[1]), (results[2], results[3])):
-        assert torch.equal(l0, l1) and torch.equal(p0, p1)
-        assert set(g0) == set(g1) and len(g0) > 20
-        top = max(float(v.abs().max()) for v in g0.values())
-        assert top > 0
-        worst = max((float((g0[k] - g1[k]).abs().max()) / max(1e-3 * top, float(g0[k].abs().max())), k) for k in g0)
-        print("compact vs fp32 recompute buffers, largest relative gradient difference:", worst)
-        assert worst[0] < 1e-3, worst
-        # parameters the buffers never touch (the encoders' of the crossmodal weights / per-trajectory biases reach
-        # the networks only through p_traj / p_dout, reduced from dz) differ by rounding too, never by a dropped term
-        assert all(bool(torch.isfinite(v).all()) for v in g1.values())
-
-
-@pytest.mark.parametrize("tname,cls,N,M,T,chunk_rows,tol", [
-    ("door", "DoorCrossmodalParticleFilter", 32, 30, 6, 262144, GRAD_TOL),  # the reference's training shape
-    # ragged chunks; 4,500 rows: ONE pre-activation that lies between the two arithmetics moves a bias gradient by a row's
-    # share of the sum -- observed 2.5e-4 with the hoisted terms from the GEMM library and 7.3e-3 with them from the K7
-    # programs (same inputs to both runs either way; the last ulp of the hoisted term decides which rows sit on the edge)
-    ("door", "DoorCrossmodalParticleFilter", 5, 300, 3, 600, 1e-2),
-    ("push", "PushUnimodalParticleFilter", 8, 512, 4, 2048, GRAD_TOL),
-])
-def test_recompute_in_the_forward_arithmetic_tracks_the_exact_fp32_recompute(tname, cls, N, M, T, chunk_rows, tol):
-    """``MmfPfTrainArgs.recompute_f16x3`` + ``backward_f16x3`` (round 4): with the engine in its default f16x3 mode the
-    backward recomputes each step's activations with the three-product f16 arithmetic the FORWARD pass used, on the
-    forward pass's blob, instead of exact fp32 products -- the activations and ReLU masks it differentiates through are
-    then the ones that produced the loss -- and runs the transposed layers of the data path in the same arithmetic,
-    every layer's gradient tile scaled into the f16 range by an exact power of two and back.  The forward pass is untouched (loss and estimates bit-identical); against the exact-fp32
-    recompute the gradients differ by the two arithmetics' 1e-6 on the activations plus the occasional ReLU whose
-    pre-activation lies between them: GRAD_TOL, the file's fp32-vs-fp32 tolerance (observed <= 1e-3)."""
-    import multimodalfilter_amd as mmf
-    from multimodalfilter_amd import engine
-
-    dev = torch.device("cuda:0")
-    task = om.TASKS[tname]
-    d = task.state_dim
-    obs, ctrl, x0, target, g = _data(task, T, N, 61)
-    eps0 = torch.randn((N, M, d), generator=g)
-    eps = [torch.randn((N, M, d), generator=g) for _ in range(T)]
-    cov = (torch.eye(d) * 0.1)[None].expand(N, d, d)
-    torch.manual_seed(6)
-    f = mmf.model_types(tname)[cls]().to(dev).train()
-    f.num_particles = M
-    engine.set_training_backend("hip")
-    old_chunk, old_f16r, old_prec = engine.TRAIN_CHUNK_ROWS, engine.TRAIN_RECOMPUTE_F16X3, engine.DEFAULT_PRECISION
-    engine.TRAIN_CHUNK_ROWS = chunk_rows
-    engine.set_default_precision("f16x3")
-    seen = []
-    real = mmf._abi.pf_train_backward
-    mmf._abi.pf_train_backward = lambda a, *rest: (seen.append((int(a.recompute_f16x3), int(a.precision), int(a.backward_f16x3))), real(a, *rest))[1]
-    results = []
-    try:
-        for f16r in (False, True):
-            engine.TRAIN_RECOMPUTE_F16X3 = f16r
-            f.zero_grad(set_to_none=True)
-            f.noise = mmf.ReplayNoise([eps0] + eps, [])
-            f.initialize_beliefs(mean=x0.to(dev), covariance=cov.to(dev))
-            pred = f.forward_loop(observations={k: v.to(dev) for k, v in obs.items()}, controls=ctrl.to(dev))
-            loss = torch.mean((pred - target.to(dev)) ** 2)
-            loss.backward()
-            torch.cuda.synchronize()
-            results.append((loss.detach().clone(), pred.detach().clone(),
-                            {n: p.grad.detach().clone() for n, p in f.named_parameters() if p.grad is not None}))
-    finally:
-        mmf._abi.pf_train_backward = real
-        engine.set_training_backend(None)
-        engine.TRAIN_CHUNK_ROWS, engine.TRAIN_RECOMPUTE_F16X3 = old_chunk, old_f16r
+        engine.TRAIN_CHUNK_ROWS = old_chunk
         engine.set_default_precision(old_prec)
-    assert seen == [(0, mmf._abi.PREC_F32, 0), (1, mmf._abi.PREC_F16X3, 1)]
-    (l0, p0, g0), (l1, p1, g1) = results
-    assert torch.equal(l0, l1) and torch.equal(p0, p1)
+    assert seen == [int(precision == "f16x3")] * 2
+    (p0, g0), (p1, g1) = results
+    assert torch.equal(p0, p1)
     assert set(g0) == set(g1) and len(g0) > 20
     top = max(float(v.abs().max()) for v in g0.values())
-    worst = max((float((g0[k] - g1[k]).abs().max()) / max(1e-3 * top, float(g0[k].abs().max())), k) for k in g0)
-    print("f16x3 vs exact-fp32 recompute, largest relative gradient difference:", worst)
-    assert worst[0] < tol, worst
+    assert top > 0
+    worst = max((float((g0[k] - 1e6 * g1[k]).abs().max()) / max(1e-3 * top, float(g0[k].abs().max())), k) for k in g0)
+    print("loss x 1e-6 against the unscaled step, largest relative gradient difference:", worst)
+    assert worst[0] < 1e-3, worst
     assert all(bool(torch.isfinite(v).all()) for v in g1.values())
 
 
 @pytest.mark.parametrize("tname,cls,N,M,T,chunk_rows,tol", [
-    ("door", "DoorCrossmodalParticleFilter", 32, 30, 6, 262144, 2e-3),  # the reference's training shape, one chunk, tiles straddle trajectories
-    ("door", "DoorCrossmodalParticleFilter", 5, 300, 3, 600, 2e-3),     # ragged chunks: partial tiles, fewer workgroups than slots
-    ("door", "DoorParticleFilter", 3, 100, 3, 100, 4e-3),               # one measurement network; 900 rows: a bias gradient is a sum of few terms (observed 2.1e-3)
-    ("push", "PushUnimodalParticleFilter", 4, 2048, 3, 262144, 2e-3),   # config 5's filter: whole tiles, 64 workgroups
+    ("door", "DoorCrossmodalParticleFilter", 32, 30, 6, 262144, GRAD_TOL),  # the reference's training shape, one chunk, tiles straddle trajectories
+    # ragged chunks: partial tiles, fewer workgroups than slots.  4,500 rows: ONE pre-activation that lies between the two
+    # arithmetics moves a bias gradient by a row's share of the sum (round 4 measured 7.3e-3 for f16x3 against exact-fp32 recompute here)
+    ("door", "DoorCrossmodalParticleFilter", 5, 300, 3, 600, 1e-2),
+    ("door", "DoorParticleFilter", 3, 100, 3, 100, GRAD_TOL),               # one measurement network; 900 rows: a bias gradient is a sum of few terms
+    ("push", "PushUnimodalParticleFilter", 4, 2048, 3, 262144, GRAD_TOL),   # config 5's filter: whole tiles, 64 workgroups
 ])
 def test_fused_network_calls_track_the_three_pass_backward(tname, cls, N, M, T, chunk_rows, tol):
     """``MmfPfTrainArgs.fused`` (round 5): recompute + backward data path + weight gradients of every network call in
-    ONE kernel (``mmf_particle_net_train_fused``) against the three passes over the compact f16 buffers (round 4).
-    Both differentiate the forward pass's own f16x3 activations with the same three-product backward, so the recursion's
-    gradients (``d states``, through them every per-trajectory network's parameters) agree to the accumulation order;
-    the per-particle networks' weight gradients multiply the same f16-rounded operands but scale ``dz`` differently
-    (running exponent per layer instead of a scale per 32-row tile) -- both within 2^-11 relative per element.  Loss
-    and estimates are bit-identical (the forward is untouched); every gradient within 2e-3 of its scale, twice in a
-    row with identical bits (the fused kernel's summation order is fixed: no atomics)."""
+    ONE kernel (``mmf_particle_net_train_fused``, the forward pass's own three-product f16 arithmetic) against the
+    cross-check form (round 6: the ONE other form left): three passes with exact fp32 products over the f16 recompute
+    buffers.  The forward pass is the same (loss and estimates bit-identical); the gradients differ by the two
+    arithmetics' 1e-6 on the activations, by 2^-11 relative per stored ``dz`` element, plus the occasional ReLU whose
+    pre-activation lies between the arithmetics: GRAD_TOL, the file's fp32-vs-fp32 tolerance.  Twice in a row the fused
+    form gives identical bits (its summation order is fixed: no atomics)."""
     import multimodalfilter_amd as mmf
     from multimodalfilter_amd import engine
 
