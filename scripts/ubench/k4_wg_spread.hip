@@ -1,9 +1,9 @@
-// When do the workgroups of the fused K4 kernels (image_encoder_fused.inc) start and finish, by XCD?  Includes the product
+// When do the workgroups of the resident K4 kernel (image_encoder_resident.inc) start and finish, by XCD?  Includes the product
 // source with MMF_K4_WG_STAMPS: thread 0 of every workgroup stamps wall_clock64 (100 MHz) at entry and exit and its XCC_ID.
 // The launches are persistent grids with the same number of images per workgroup; a spread of finishing times is what a
 // static partition leaves on the table.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -Iinclude -Imultimodalfilter_amd/csrc \
-//         -o scripts/ubench/k4_wg_spread scripts/ubench/k4_wg_spread.hip && ./scripts/ubench/k4_wg_spread [images] [nets] [fast share] [brief]
+//         -o scripts/ubench/k4_wg_spread scripts/ubench/k4_wg_spread.hip && ./scripts/ubench/k4_wg_spread [images] [nets] [unused] [brief]
 #define MMF_K4_WG_STAMPS 1
 #include "../../multimodalfilter_amd/csrc/image_encoder.hip"
 
@@ -23,7 +23,6 @@ static float* dev_random(size_t n, float scale) {
 
 int main(int argc, char** argv) {
   const int N = argc > 1 ? atoi(argv[1]) : 4096, nets = argc > 2 ? atoi(argv[2]) : 2;
-  if (argc > 3) g_k4_fast_share = atoi(argv[3]);  // images of a CU's workgroup pair that go to the one dispatched first, in 32nds
   const bool brief = argc > 4;
   MmfImageEncoderDesc d{};
   const size_t cw[5] = {32 * 25, 32 * 32 * 9, 32 * 32 * 9, 16 * 32 * 9, 8 * 16 * 9};
@@ -47,14 +46,14 @@ int main(int argc, char** argv) {
     static int xcc[2][2048];
     (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_wg_stamp), sizeof(st));
     (void)hipMemcpyFromSymbol(xcc, HIP_SYMBOL(g_wg_xcc), sizeof(xcc));
-    const char* names[2] = {"stem_conv2a ", "conv2b_conv3"};
-    const int wgs[2] = {std::min(256 / nets, N) * nets, std::min(512 / nets, N) * nets};
-    for (int k = 0; k < 2; ++k) {
+    const char* names[1] = {"image_encoder_resident"};
+    const int wgs[1] = {std::min(256 / nets, N) * nets};
+    for (int k = 0; k < 1; ++k) {
       const int n = wgs[k];
       long long t0 = st[k][0][0], t1 = 0;
       for (int w = 0; w < n; ++w) { t0 = std::min(t0, st[k][0][w]); t1 = std::max(t1, st[k][1][w]); }
       const double dur = (t1 - t0) * 0.01;
-      printf("rep %d %s (fast share %d/32): %d workgroups, first start -> last end %.1f us\n", rep, names[k], g_k4_fast_share, n, dur);
+      printf("rep %d %s: %d workgroups, first start -> last end %.1f us\n", rep, names[k], n, dur);
       if (brief) continue;
       if (rep == 3) {  // which workgroups are the late ones?  By dispatch half, by parity, and a sample of XCD 0's in id order
         double half[2] = {0, 0}, par[2] = {0, 0};
