@@ -8,14 +8,19 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// round 6: the shader clock the loop holds (s_memtime ticks per s_memrealtime tick of 100 MHz), stamped by one lane per workgroup
+__device__ unsigned long long g_clk[256][4];
+
 template <int SHAPE, int FILL>
 __global__ __launch_bounds__(512) void k(const float* __restrict__ w, float* __restrict__ out, int iters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int i = threadIdx.x; i < 65536 / 16; i += 512) reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(w)[i];
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -58,6 +63,10 @@ __global__ __launch_bounds__(512) void k(const float* __restrict__ w, float* __r
     for (int i = 0; i < 8; ++i) s += filler[i];
     out[blockIdx.x * 512 + threadIdx.x] = s;
   }
+  if (threadIdx.x == 0) {
+    g_clk[blockIdx.x][0] = c0; g_clk[blockIdx.x][1] = __builtin_amdgcn_s_memtime();
+    g_clk[blockIdx.x][2] = r0; g_clk[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 template <int SHAPE, int FILL>
@@ -71,7 +80,18 @@ void run(const float* w, float* out) {
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double flop = 256.0 * 8 * iters * 16 * 2.0 * 32 * 32 * 16;  // per wave and iteration: 16 MFMAs of 32x32x16 (or 32 of 16x16x32)
-    if (rep == 2) printf("shape %s fill %d: %.3f ms  %.1f TFLOP/s\n", SHAPE ? "16x16x32" : "32x32x16", FILL, ms, flop / ms / 1e9);
+    if (rep == 2) {
+      static unsigned long long h[256][4];
+      hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clk), sizeof(h));
+      std::vector<double> ghz;
+      for (int b = 0; b < 256; ++b) ghz.push_back(0.1 * double(h[b][1] - h[b][0]) / double(h[b][3] - h[b][2]));
+      std::sort(ghz.begin(), ghz.end());
+      // matrix-pipe cycles the loop needs per SIMD: 2 waves x iters x 16 MFMAs x 32 cycles (or 32 x 16)
+      const double need = 2.0 * iters * 16 * 32, have = ghz[128] * 1e9 * ms * 1e-3;
+      printf("shape %s fill %d: %.3f ms  %.1f TFLOP/s; shader clock in the loop %.2f GHz (median of 256 workgroups, %.2f .. %.2f): "
+             "the matrix pipe is busy %.0f %% of those cycles\n", SHAPE ? "16x16x32" : "32x32x16", FILL, ms, flop / ms / 1e9, ghz[128], ghz[0], ghz[255],
+             100.0 * need / have);
+    }
   }
 }
 
