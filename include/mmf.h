@@ -115,6 +115,15 @@ int mmf_pf_reweight_backward(const float* logw_out, const float* states, const f
 /* Dynamic LDS bytes K1 will request for (M, mode) -- for occupancy planning / tests. */
 size_t mmf_pf_reweight_resample_lds_bytes(int M, int mode);
 
+/* ABI 39.  K1 for few trajectories ("for N < 256 split M across a WG-cluster"): with `enabled` != 0, plain
+ * systematic resampling (mode 1) of N <= CUs / 2 trajectories of M = M_out <= 4096 particles (M a multiple of 512, d = 2 or 3)
+ * gives every trajectory a CLUSTER of workgroups that meet twice through L2 (csrc/pf_resample_cluster.inc).  Same bits as
+ * the one-workgroup kernel -- ancestors, gathered particles and estimates (tests/test_gpu_kernels.py).  OFF by default: measured
+ * no faster (11.6 against 11.2 us per launch at 32 x 4096, profiles/r06/k1_cluster_ab.txt -- K1 at these sizes is one
+ * thread's instruction chain plus memory round trips, which more workgroups do not shorten). */
+void mmf_pf_set_resample_cluster(int enabled);
+int mmf_pf_get_resample_cluster(void);
+
 /* ---------------------------------------------------------------- K2: per-particle networks
  * The reference evaluates its dynamics and measurement MLPs as ~20 stock nn.Linear launches
  * over R = N*M rows, materialising (R, 64) activations after every layer and repeating the

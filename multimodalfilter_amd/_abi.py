@@ -139,6 +139,8 @@ SIGNATURES = {
     "mmf_pf_reweight_resample_soft": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP,
                                               c_int, c_int, c_int, c_int, c_int, ctypes.c_float, c_void_p]),
     "mmf_pf_reweight_resample_lds_bytes": (c_size_t, [c_int, c_int]),
+    "mmf_pf_set_resample_cluster": (None, [c_int]),
+    "mmf_pf_get_resample_cluster": (c_int, []),
     "mmf_particle_net_floats": (c_size_t, [c_int]),
     "mmf_pack_particle_net": (c_int, [POINTER(MmfParticleNetDesc), _FP, c_int, c_void_p]),
     "mmf_pf_dynamics": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
@@ -268,6 +270,13 @@ def pf_reweight_resample(loglik, logw_in, states_in, u, estimate, states_out, lo
             ptr(loglik), ptr(logw_in), ptr(states_in), ptr(u), ptr(estimate), ptr(states_out),
             ptr(logw_out), ptr(indices_out, dtype=torch.int32), N, M, M_out, d, mode,
             stream_of(states_in)), "mmf_pf_reweight_resample")
+
+
+def pf_set_resample_cluster(enabled: bool) -> bool:
+    """K1 for few trajectories as a cluster of workgroups per trajectory (same bits; off by default: no faster). Returns the previous setting."""
+    was = bool(load().mmf_pf_get_resample_cluster())
+    load().mmf_pf_set_resample_cluster(int(bool(enabled)))
+    return was
 
 
 def particle_net_floats(n_res: int) -> int:

@@ -35,6 +35,8 @@ __device__ unsigned long long g_k1_stamps[1024][8];
 #include "pf_resample_systematic.inc"
 
 namespace {
+#include "pf_resample_cluster.inc"
+int g_cluster_enabled = getenv("MMF_K1_CLUSTER") && getenv("MMF_K1_CLUSTER")[0] == '1';  // off: see mmf_pf_set_resample_cluster
 
 constexpr int kBlock = mmf::kK1Block;  // 16 waves; M = 4096 -> one float4 chunk per thread
 constexpr int kMaxWaves = mmf::kK1MaxWaves;
@@ -452,6 +454,43 @@ int launch_reweight_resample(const float* loglik, const float* logw_in, const fl
   hipStream_t s = static_cast<hipStream_t>(stream);
   const float lw_uniform = static_cast<float>(-std::log(static_cast<double>(M)));
   const float log_uniform = static_cast<float>(-std::log(static_cast<double>(M_out)));
+  if (mode == 1 && !soft && (d == 2 || d == 3)) {
+    // few trajectories (round 6): a cluster of workgroups per trajectory, two meetings through L2, the same bits
+    int dev = 0, cus = 0;
+    if (g_cluster_enabled && hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) {
+      const int C = cluster::plan(N, M, M_out, cus);
+      if (C > 0) {
+        // exchange area: kLanes launches' worth (consecutive launches never share one: a late reader of launch k cannot
+        // meet launch k + 1's granules), tags from a counter that never repeats, zeroed once; per device
+        constexpr int kLanes = 8, kMaxDevices = 16;
+        static mmf::Granule* area[kMaxDevices] = {};
+        static unsigned counter = 0;
+        if (dev < 0 || dev >= kMaxDevices) return MMF_EINVAL;
+        const size_t lane_granules = static_cast<size_t>(cus / 2) * cluster::kGranulesPerTraj;  // plan(): N <= cus / 2
+        if (!area[dev]) {
+          const size_t bytes = (kLanes * lane_granules + 2) * sizeof(mmf::Granule);
+          if (hipMalloc(reinterpret_cast<void**>(&area[dev]), bytes) != hipSuccess) return MMF_EINVAL;
+          if (hipMemsetAsync(area[dev], 0, bytes, s) != hipSuccess) return MMF_EINVAL;
+        }
+        ++counter;
+        if (counter == 0) counter = 1;  // tag 0 is "never written"
+        cluster::Args ca{};
+        ca.loglik = loglik; ca.logw_in = logw_in; ca.states_in = states_in; ca.u = u; ca.estimate = estimate;
+        ca.states_out = states_out; ca.logw_out = logw_out; ca.indices_out = indices_out;
+        ca.exchange = area[dev] + (counter % kLanes) * lane_granules;
+        ca.error_word = reinterpret_cast<unsigned*>(area[dev] + kLanes * lane_granules);
+        ca.M = M; ca.M_out = M_out; ca.C = C; ca.tag = counter;
+        ca.lw_uniform = lw_uniform; ca.log_uniform = log_uniform;
+        const int threads = M / (4 * C);
+        const size_t bytes = cluster::lds_bytes(M_out, threads, d);
+        if (d == 3) cluster::pf_resample_cluster_kernel<3><<<dim3(C, N), threads, bytes, s>>>(ca);
+        else cluster::pf_resample_cluster_kernel<2><<<dim3(C, N), threads, bytes, s>>>(ca);
+        MMF_CHECK_LAUNCH();
+        return 0;
+      }
+    }
+  }
   if (mode == 1 && !soft && M <= 20000 && M_out <= 20000) {
     // plain systematic resampling: the search-free kernel (offspring boundaries + prefix sum of marks)
     const size_t slots = (static_cast<size_t>(M) * 8 + 15) & ~static_cast<size_t>(15);
@@ -561,6 +600,9 @@ extern "C" int mmf_pf_argmax_estimate(const float* loglik, const float* logw_in,
   MMF_CHECK_LAUNCH();
   return 0;
 }
+
+extern "C" void mmf_pf_set_resample_cluster(int enabled) { g_cluster_enabled = enabled != 0; }
+extern "C" int mmf_pf_get_resample_cluster(void) { return g_cluster_enabled; }
 
 extern "C" int mmf_pf_reweight_resample(const float* loglik, const float* logw_in,
                                         const float* states_in, const float* u, float* estimate,

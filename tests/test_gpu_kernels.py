@@ -69,6 +69,43 @@ def test_k1_indices_bit_exact(N, M, d, mode):
     np.testing.assert_allclose(est, w_est, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("N,M,d", [(8, 1024, 3), (32, 4096, 3), (5, 2048, 2), (3, 4096, 2), (100, 512, 3), (16, 3072, 3)])
+def test_k1_cluster_of_workgroups_equals_one_workgroup_per_trajectory(N, M, d):
+    """Round 6 ("for N < 256 split M across a WG-cluster"): with few trajectories K1 gives each one a CLUSTER of
+    workgroups that meet twice through L2 (row maximum; integer totals + the waves' float partial sums).  Same particle
+    ownership, same per-thread chains, same per-wave trees, the partial sums added in wave order: ancestors, gathered
+    particles AND estimates carry the bits of the one-workgroup kernel -- which the same trajectories get when they sit in a
+    batch of more than half the CU count (or with the cluster switched off, as by default) -- and the ancestors equal the oracle's.  Hard cases inside: all the weight in one
+    slice (the other workgroups of the cluster write nothing), ``-inf`` log-likelihoods, ``u`` at 0 and at 1 - ulp."""
+    abi = _abi()
+    was = abi.pf_set_resample_cluster(True)   # off by default (no faster: profiles/r06/k1_cluster_ab.txt)
+    rng = np.random.RandomState(N * 31 + M + d)
+    ll = (rng.standard_normal((N, M)) * 3).astype(np.float32)
+    lw = np.log(rng.dirichlet(np.ones(M) * 0.5, N) + 1e-30).astype(np.float32)
+    x = rng.standard_normal((N, M, d)).astype(np.float32)
+    u = rng.uniform(0, 1, (N,)).astype(np.float32)
+    ll[0, : M // 2] = -np.inf                      # the first half of the slices carries nothing
+    ll[1 % N, :] = -60.0
+    ll[1 % N, M - 3] = 0.0                         # (almost) all the weight on one particle of the last slice
+    ll[2 % N, rng.randint(0, M, 17)] = -np.inf
+    u[0], u[1 % N] = 0.0, np.float32(1.0) - np.float32(2.0 ** -24)
+    try:
+        est, xo, lwo, idx = _k1(abi, ll, lw, x, u, 1)
+    finally:
+        abi.pf_set_resample_cluster(was)
+    # the same trajectories inside a large batch: one workgroup each (the cluster is for N <= half the CUs)
+    reps = -(-200 // N)
+    big = lambda a: np.concatenate([a] * reps, axis=0)
+    est1, xo1, lwo1, idx1 = _k1(abi, big(ll), big(lw), big(x), big(u), 1)
+    np.testing.assert_array_equal(idx, idx1[:N])
+    np.testing.assert_array_equal(xo, xo1[:N])
+    np.testing.assert_array_equal(est, est1[:N])     # every bit of the estimate
+    np.testing.assert_array_equal(lwo, lwo1[:N])
+    w_est, w_x, w_lw, w_idx = rs.reweight_resample(ll, lw, x, u, "systematic")
+    np.testing.assert_array_equal(idx, w_idx)
+    np.testing.assert_array_equal(xo, w_x)
+
+
 @pytest.mark.parametrize("N,M,Mo,d", [(1, 1, 1, 3), (3, 7, 7, 2), (4, 30, 300, 3), (5, 300, 30, 3), (2, 1000, 1000, 2),
                                       (3, 4096, 4096, 3), (2, 4099, 4099, 1), (2, 8192, 8192, 2), (1, 16384, 16384, 3)])
 @pytest.mark.parametrize("mode", ["systematic", "multinomial"])
