@@ -15,7 +15,8 @@
 //                   producer / consumer kernel, every activation in LDS row rings as split f16 planes
 //                   (only the image and the 8-channel map E cross HBM); then the split-K linear tail below.
 //   MMF_PREC_BF16   the same kernel with single bf16 products in the stem and the 32 -> 32 / 32 -> 16 convolutions.
-// The per-layer f16x3 kernels (conv_f16x3_kernel<32,...>) remain as the TRAINING forward (every activation kept).
+// The TRAINING forward in the f16x3 / bf16 modes is the same resident kernel with every activation the backward reads
+// kept on the way (mmf_image_convs_train_forward); round 2's per-layer f16x3 kernels, its previous form, are deleted.
 // The 8192->64 linear is a split-K MFMA GEMM followed by a one-wave-per-image tail (bias, ReLU,
 // ResLinear 64).  Rooflines and measurements: DESIGN.md section 3, K4.
 #include <hip/hip_fp16.h>
@@ -58,7 +59,7 @@ __host__ __device__ constexpr int conv_w_floats(int cin, int cout, int ks) {
 // ---- packed blob of one encoder (floats) -------------------------------------------------
 struct Layout {
   int w1, b1, w2a, b2a, w2b, b2b, w3, b3, w4, b4, fcw, fcb, r1t, r1b, r2t, r2b;
-  int h2a, h2b, h3, h4;  // f16x3 fragment-ordered copies of the 3x3 convolutions' weights
+  int h2a, h2b;          // f16x3 fragment-ordered copies of the two 32 -> 32 convolutions' weights (32x32x16 A fragments)
   int hfc;               // f16x3 fragment-ordered copy of the 8192 -> 64 linear layer's weights
   int hs;                // f16x3 5x5 stem as 2 k-steps of 16 taps: [k-step][hi|lo][lane][8 halves]
   int g3;                // f16x3 conv 32->16 for v_mfma_f32_16x16x32_f16: [tap][hi|lo][lane][8 halves]
@@ -89,8 +90,6 @@ __host__ __device__ constexpr Layout layout() {
   L.r2b = o; o += kFeat;
   L.h2a = o; o += conv_h_floats(32);
   L.h2b = o; o += conv_h_floats(32);
-  L.h3 = o; o += conv_h_floats(32);
-  L.h4 = o; o += conv_h_floats(16);
   L.hfc = o; o += kFcSplit * (kFcK / kFcSplit / 16) * 2 * 2 * 64 * 8 / 2;  // [split][k-step][tile][hi|lo][lane][8 halves]
   L.hs = o; o += 2 * 2 * 64 * 8 / 2;
   L.g3 = o; o += 9 * 2 * 64 * 8 / 2;
@@ -242,12 +241,11 @@ __global__ void pack_encoder_kernel(MmfImageEncoderDesc d, float* __restrict__ o
       v = __uint_as_float(static_cast<unsigned>(hb[0]) | (static_cast<unsigned>(hb[1]) << 16));
     } else {
       // f16x3 sections: two halves per float slot
-      const int offs[5] = {L.h2a, L.h2b, L.h3, L.h4, L.hfc};
-      const int cins[4] = {32, 32, 32, 16}, couts[4] = {32, 32, 16, cout4};
+      const int offs[3] = {L.h2a, L.h2b, L.hfc};
       int c = 0;
       while (q0 >= offs[c + 1]) ++c;
       const float* W = d.conv_w[c + 1];
-      const int cin = cins[c], cout = couts[c], KC = cin / 16;
+      const int cin = 32, cout = 32, KC = cin / 16;
       unsigned short hb[2];
       for (int z = 0; z < 2; ++z) {
         const int he = 2 * (q0 - offs[c]) + z;
@@ -378,271 +376,6 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(ConvArgs a) {
           a.out[o] = v;
         }
       }
-}
-
-// ---- 3x3 convolution, f16x3 products ---------------------------------------------------------
-// Same band decomposition, but the activations are staged ONCE per band as two f16 planes
-// (x = hi + lo exactly to 2^-22, round-toward-zero) in a channel-innermost [row][col][ci] LDS
-// image, so a B fragment of v_mfma_f32_32x32x16_f16 (8 consecutive input channels of one pixel)
-// is a single ds_read_b128; the 16-byte chunks of a pixel are XOR-swizzled with the column so
-// the 16 lanes of a b128 group fall on 16 different slots of the 256-B bank row.  GEMM view:
-// M = 32 output channels, N = the 32 pixels of an image row, K = 16 input channels of one tap;
-// each product is hi*hi + hi*lo + lo*hi (3 MFMAs at 16x the f32-MFMA rate).  Workgroups are
-// persistent: weights are staged once, and the next band's global loads are issued into
-// registers before the current band is computed (async-STAGE split), so the kernel runs at
-// the HBM / L2 rate of its activation traffic instead of load + compute + store in series.
-struct ConvHArgs {
-  const float* packed[kMaxNets];
-  const float* in;    // (nets, N, CIN, 32, 32) fp32
-  const float* skip;  // (nets, N, COUT, 32, 32) or null
-  float* out;         // (nets, N, COUT, 32, 32)
-  int* range_flag;
-  int N;
-  int hoff, boff;
-};
-
-constexpr int kWPh = 34;  // padded row of the f16 image: 1 | 32 pixels | 1
-
-template <int CIN>
-__device__ __forceinline__ int swz(int col) {
-  return CIN == 32 ? (col >> 2) & 3 : (col >> 3) & 1;
-}
-
-// Phase clocks for scripts/ubench/k4_phases.hip (compiled out of the library).
-#ifdef MMF_K4_PHASE_CLOCKS
-__device__ long long g_phase[4][8];  // [3x3 layer][phase]
-#define K4_CLOCK(i)                                                     \
-  do {                                                                  \
-    const long long now_ = wall_clock64();                              \
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_phase[kLayerId][i] += now_ - tprev_; \
-    tprev_ = now_;                                                      \
-  } while (0)
-#else
-#define K4_CLOCK(i)
-#endif
-
-// BAND output rows per workgroup, one wave per two rows.  BAND = 8 keeps two workgroups resident
-// per CU (2 x (planes 43.5 KB + weights 36.9 KB) <= 160 KB): while one is in its MFMA phase
-// the other stages / stores, which a single lock-stepped workgroup per CU cannot overlap
-// (measured per 16-row band, one workgroup per CU: stage 3.6 us + MFMA 4.0 us + store 2.2 us in
-// series; scripts/ubench/k4_phases.hip).
-// BF: one bf16 product per MAC (operands rounded to bf16, fp32 accumulation, weights from the bf16
-// twins in the same fragment order): the training forward of MMF_PREC_BF16, which needs every
-// layer's activations in HBM anyway.
-template <int CIN, int COUT, bool RELU, bool SKIP, int BAND, bool BF = false>
-__global__ __launch_bounds__(BAND * 32) void conv_f16x3_kernel(ConvHArgs a) {
-  constexpr int THREADS = BAND * 32;
-  constexpr int RB = BAND + 2;
-  constexpr int KC = CIN / 16;
-  constexpr int CG = CIN / 8;                      // 16-byte chunks per pixel
-  constexpr int PIX = CIN * 2;                     // bytes per pixel per plane
-  constexpr int PLANE = RB * kWPh * PIX;           // bytes per plane
-  constexpr int NW = 9 * KC * 2 * 64 * 16;         // weight bytes
-  constexpr int XG = kImg / 4;                     // groups of 4 pixels per row
-  constexpr int ITEMS = RB * CG * XG;              // staging items: 8 channels x 4 pixels
-  constexpr int IPT = (ITEMS + THREADS - 1) / THREADS;
-  constexpr int BPI = kImg / BAND;                 // bands per image
-  extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-  unsigned char* tile_hi = ldsb;
-  unsigned char* tile_lo = ldsb + PLANE;
-  unsigned char* wl = ldsb + 2 * PLANE;
-
-  const int net = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j = lane & 31, h = lane >> 5;
-  const float* blob = a.packed[net];
-  {
-    const float4* src = reinterpret_cast<const float4*>(blob + a.hoff);
-    float4* dst = reinterpret_cast<float4*>(wl);
-    for (int i = tid; i < NW / 16; i += THREADS) dst[i] = src[i];
-    // the two padding columns of every row are zero for the whole kernel
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    for (int i = tid; i < RB * 2 * CG; i += THREADS) {
-      const int cg = i % CG, side = (i / CG) & 1, rr = i / (2 * CG);
-      const int off = (rr * kWPh + (side ? kWPh - 1 : 0)) * PIX + 16 * cg;
-      *reinterpret_cast<u32x4*>(tile_hi + off) = z;
-      *reinterpret_cast<u32x4*>(tile_lo + off) = z;
-    }
-  }
-  const float* in_net = a.in + static_cast<size_t>(net) * a.N * CIN * kImg * kImg;
-  const int nbands = BPI * a.N;
-
-  // staging item -> (row rr of the band, channel chunk cg, pixel group xg): lanes run along a
-  // row first, so one wave-instruction reads 128-B contiguous segments of the NCHW planes
-  const int it_xg[2] = {tid % XG, (tid + THREADS) % XG};
-  const int it_cg[2] = {(tid / XG) % CG, ((tid + THREADS) / XG) % CG};
-  const int it_rr[2] = {tid / (XG * CG), (tid + THREADS) / (XG * CG)};
-  static_assert(IPT <= 2, "staging indices are precomputed for two rounds");
-
-  // prefetch registers: IPT items x 8 channels x 4 pixels.  The loads are UNCONDITIONAL (row and
-  // item clamped to valid addresses) and the out-of-image / out-of-range masking happens at
-  // commit time: a select on the loaded value here would make the wave wait for every load
-  // before the MFMA phase it is supposed to overlap with.
-  f32x4 pf[IPT][8];
-  auto prefetch = [&](int band) {
-    const int img = band / BPI, y0 = (band % BPI) * BAND;
-    const float* in = in_net + static_cast<size_t>(img) * CIN * kImg * kImg;
-#pragma unroll
-    for (int it = 0; it < IPT; ++it) {
-      const int y = min(max(y0 - 1 + min(it_rr[it], RB - 1), 0), kImg - 1);
-      const float* p = in + ((it_cg[it] * 8) * kImg + y) * kImg + 4 * it_xg[it];
-      // The skip variant also holds 32 skip values across the MFMA loop; with 64 prefetch
-      // registers genuinely in flight as well it needs 344 registers and loses the second
-      // workgroup per CU (456 us instead of ~360).  There the select below makes the wave wait
-      // for the loads here (the old blocking scheme), which lets the allocator overlap them.
-      const int yr = y0 - 1 + it_rr[it];
-      const bool ok = tid + it * THREADS < ITEMS && yr >= 0 && yr < kImg;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p + i * kImg * kImg);
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        pf[it][i] = SKIP ? (ok ? v : zero) : v;
-      }
-    }
-  };
-  float amax = 0.f;
-  auto commit = [&](int band) {  // registers -> split -> swizzled LDS planes
-    const int y0 = (band % BPI) * BAND;
-#pragma unroll
-    for (int it = 0; it < IPT; ++it) {
-      if (tid + it * THREADS < ITEMS) {
-        const int y = y0 - 1 + it_rr[it];
-        const bool inside = y >= 0 && y < kImg;  // rows above / below the image are zero padding
-#pragma unroll
-        for (int px = 0; px < 4; ++px) {
-          u32x4 hv, lv;
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            const float x0 = inside ? pf[it][2 * p][px] : 0.f, x1 = inside ? pf[it][2 * p + 1][px] : 0.f;
-            amax = fmaxf(amax, fmaxf(fabsf(x0), fabsf(x1)));
-            const f32x2 xs = {x0, x1};
-            if constexpr (BF) {
-              using bf2 = __attribute__((ext_vector_type(2))) __bf16;
-              hv[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(xs, bf2));
-              lv[p] = 0u;
-            } else {
-              const half2v hh = __builtin_convertvector(xs, half2v);  // round to nearest even
-              const f32x2 hf = {static_cast<float>(hh[0]), static_cast<float>(hh[1])};
-              const f32x2 r = xs - hf;
-              const half2v ll = __builtin_convertvector(r, half2v);
-              hv[p] = __builtin_bit_cast(unsigned, hh);
-              lv[p] = __builtin_bit_cast(unsigned, ll);
-            }
-          }
-          const int cc = 4 * it_xg[it] + px + 1;
-          const int off = (it_rr[it] * kWPh + cc) * PIX + 16 * (it_cg[it] ^ swz<CIN>(cc));
-          *reinterpret_cast<u32x4*>(tile_hi + off) = hv;
-          if constexpr (!BF) *reinterpret_cast<u32x4*>(tile_lo + off) = lv;
-        }
-      }
-    }
-  };
-
-  // bias per accumulator register, loaded once: a global load between the prefetch and the MFMA
-  // loop would make the wave drain the (in-order) load counter, i.e. wait for the prefetch
-  float bias_r[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int ch = (r & 3) + 8 * (r >> 2) + 4 * h;
-    bias_r[r] = ch < COUT ? (BF ? 1.0f : kWScale) * blob[a.boff + ch] : 0.f;
-  }
-
-  int band = blockIdx.x;
-  if (band < nbands) prefetch(band);
-#ifdef MMF_K4_PHASE_CLOCKS
-  constexpr int kLayerId = CIN == 16 ? 3 : (COUT == 16 ? 2 : (SKIP ? 1 : 0));
-  long long tprev_ = wall_clock64();
-#endif
-  for (; band < nbands; band += gridDim.x) {
-    __syncthreads();  // everyone finished reading the previous band's planes (and the weights landed)
-    K4_CLOCK(0);
-    commit(band);
-    K4_CLOCK(1);
-    __syncthreads();
-    K4_CLOCK(2);
-    if (band + gridDim.x < nbands) prefetch(band + gridDim.x);  // in flight during the MFMAs
-    K4_CLOCK(3);
-
-    const int img = band / BPI, y0 = (band % BPI) * BAND;
-    const int r0 = 2 * wave;
-    const size_t obase = (static_cast<size_t>(net) * a.N + img) * COUT * kImg * kImg;
-    f32x16 acc[2];
-    f32x16 skipv[SKIP ? 2 : 1];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ch = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const float b = SKIP ? (ch < COUT ? (BF ? 1.0f : kWScale) * blob[a.boff + ch] : 0.f) : bias_r[r];  // skip variant: fewer live registers
-      acc[0][r] = b;
-      acc[1][r] = b;
-      if (SKIP) {  // issued now, consumed after the MFMAs: the load latency hides under them
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-          skipv[rr][r] = ch < COUT ? a.skip[obase + (static_cast<size_t>(ch) * kImg + (y0 + r0 + rr)) * kImg + j] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap % 3;
-      const int col = j + kx;
-      const int sw = swz<CIN>(col);
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        const unsigned char* wp = wl + ((tap * KC + kc) * 2) * 1024 + lane * 16;
-        const half8 ahi = *reinterpret_cast<const half8*>(wp);
-        const half8 alo = *reinterpret_cast<const half8*>(wp + 1024);
-        const int chunk = (2 * kc + h) ^ sw;
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-          const int off = ((r0 + rr + ky) * kWPh + col) * PIX + 16 * chunk;
-          const half8 bhi = *reinterpret_cast<const half8*>(tile_hi + off);
-          if constexpr (BF) {
-            using bf8 = __attribute__((ext_vector_type(8))) __bf16;
-            acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, ahi), __builtin_bit_cast(bf8, bhi), acc[rr], 0, 0, 0);
-          } else {
-            const half8 blo = *reinterpret_cast<const half8*>(tile_lo + off);
-            acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[rr], 0, 0, 0);
-            acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc[rr], 0, 0, 0);
-            acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc[rr], 0, 0, 0);
-          }
-        }
-      }
-    }
-    K4_CLOCK(4);
-    // epilogue: lane (x = j, h), reg r -> channel (r&3) + 8(r>>2) + 4h; 128-B row segments
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ch = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (ch < COUT) {
-          const size_t o = obase + (static_cast<size_t>(ch) * kImg + (y0 + r0 + rr)) * kImg + j;
-          float v = acc[rr][r] * (BF ? 1.0f : kWInv);
-          if (SKIP) v += skipv[rr][r];
-          if (RELU) v = fmaxf(v, 0.f);
-          a.out[o] = v;
-        }
-      }
-    K4_CLOCK(5);
-  }
-  if (!BF && a.range_flag != nullptr && !(amax < 65504.0f)) atomicOr(a.range_flag, 1);
-}
-
-template <int CIN, int COUT, bool RELU, bool SKIP, bool BF = false>
-int launch_conv_h(const ConvHArgs& a, int nets, hipStream_t s) {
-  constexpr int BAND = 8;
-  constexpr size_t lds = 2 * (BAND + 2) * kWPh * CIN * 2 + 9 * (CIN / 16) * 2 * 64 * 16;
-  constexpr int per_cu = static_cast<int>(160 * 1024 / lds) < 2 ? 1 : 2;  // co-resident workgroups
-  static_assert(lds <= 160 * 1024, "f16 planes + weights must fit LDS");
-  auto k = conv_f16x3_kernel<CIN, COUT, RELU, SKIP, BAND, BF>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-  if (e != hipSuccess) return static_cast<int>(e);
-  int gx = (kImg / BAND) * a.N;
-  const int cap = 256 * per_cu / nets > 0 ? 256 * per_cu / nets : 1;  // persistent workgroups
-  if (gx > cap) gx = cap;
-  k<<<dim3(gx, nets), BAND * 32, lds, s>>>(a);
-  MMF_CHECK_LAUNCH();
-  return 0;
 }
 
 // ---- 8192 -> 64 linear, split-K partial sums ----------------------------------------------
@@ -994,6 +727,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_stem_kernel(const float* __res
   }
 }
 
+constexpr int kWPh = 34;  // padded row of the f16 planes: 1 | 32 pixels | 1
+
 #include "image_encoder_fused.inc"
 #include "image_encoder_resident.inc"
 
@@ -1120,25 +855,19 @@ extern "C" int mmf_image_convs_train_forward(const float* packed, const float* i
   c.packed[0] = packed;
   c.N = N;
   int rc;
-  // the 5x5 stem (3 % of the MACs, one input channel): exact fp32 in every mode
+  if (precision != MMF_PREC_F32) {
+    // round 6: the inference path's resident kernel with every activation the backward reads kept on the way (fp32,
+    // (N, C, 32, 32)): one launch instead of five per-layer kernels with the activations through HBM in between
+    // (the reference-sized training step spent a tenth of its time in those: profiles/r05/train_refsize_kernel_stats.csv)
+    FusedArgs fa{};
+    fa.packed[0] = packed;
+    fa.images = images; fa.N = N; fa.range_flag = range_flag;
+    fa.out_e = a4; fa.keep_a1 = a1; fa.keep_h = h; fa.keep_a2 = a2; fa.keep_a3 = a3;
+    return launch_resident(fa, 1, precision == MMF_PREC_BF16, s);
+  }
+  // the 5x5 stem (3 % of the MACs, one input channel)
   c.in = images; c.in_net_stride = 0; c.out = a1; c.woff = L.w1; c.boff = L.b1;
   if ((rc = launch_conv<1, 32, 5, true, false>(c, 1, s))) return rc;
-  if (precision != MMF_PREC_F32) {
-    // per-layer MFMA kernels with the activations in HBM (what the backward reads): the two 32->32
-    // convolutions (72 % of the MACs) with bf16 or f16x3 products, conv 32->16 and 16->8 f16x3
-    ConvHArgs hc{};
-    hc.packed[0] = packed;
-    hc.N = N; hc.range_flag = range_flag;
-    const bool bf = precision == MMF_PREC_BF16;
-    hc.in = a1; hc.skip = nullptr; hc.out = h; hc.hoff = bf ? L.q2a : L.h2a; hc.boff = L.b2a;
-    if ((rc = bf ? launch_conv_h<32, 32, true, false, true>(hc, 1, s) : launch_conv_h<32, 32, true, false>(hc, 1, s))) return rc;
-    hc.in = h; hc.skip = a1; hc.out = a2; hc.hoff = bf ? L.q2b : L.h2b; hc.boff = L.b2b;
-    if ((rc = bf ? launch_conv_h<32, 32, true, true, true>(hc, 1, s) : launch_conv_h<32, 32, true, true>(hc, 1, s))) return rc;
-    hc.in = a2; hc.skip = nullptr; hc.out = a3; hc.hoff = L.h3; hc.boff = L.b3;
-    if ((rc = launch_conv_h<32, 16, true, false>(hc, 1, s))) return rc;
-    hc.in = a3; hc.out = a4; hc.hoff = L.h4; hc.boff = L.b4;
-    return launch_conv_h<16, 8, false, false>(hc, 1, s);
-  }
   c.in = a1; c.out = h; c.woff = L.w2a; c.boff = L.b2a;
   if ((rc = launch_conv<32, 32, 3, true, false>(c, 1, s))) return rc;
   c.in = h; c.skip = a1; c.out = a2; c.woff = L.w2b; c.boff = L.b2b;

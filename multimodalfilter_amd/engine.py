@@ -135,6 +135,15 @@ def image_encoder_precision_code() -> int:
     return _abi.IMAGE_PRECISIONS[IMAGE_ENCODER_PRECISION or DEFAULT_PRECISION]
 
 
+def training_image_precision_code() -> int:
+    """Arithmetic of the image encoders' TRAINING forward (``ImageConvsFunction``): exact fp32 products (per-layer kernels;
+    the reference trains in fp32, and the engine-wide default does not reach training) unless the image-encoder precision
+    was set explicitly -- ``set_image_encoder_precision("bf16")`` is BASELINE config 5, ``"f16x3"`` the inference
+    arithmetic; both run the resident K4 kernel with every activation the backward reads kept on the way (round 6: one launch,
+    84 us per 512 images against 359 us for the five per-layer kernels, profiles/r06/train_refsize_fwd_ab.txt)."""
+    return _abi.IMAGE_PRECISIONS[IMAGE_ENCODER_PRECISION] if IMAGE_ENCODER_PRECISION else _abi.PREC_F32
+
+
 # Small particle-filter loops (mmf_pf_persistent_plan > 0: e.g. the reference's 32 x 300 evaluation) as ONE persistent
 # launch per forward_loop: role-specialised workgroups keep one network's weights in LDS for all T steps and hand the
 # particles over through L2 (csrc/pf_persistent.inc); bit-identical to the launch-per-step loop.  "0": A/B, off.
@@ -239,11 +248,11 @@ def _checked(fn, *, step: bool):
         for p in self.parameters():
             dev = p.device
             break
-        # a bare training step runs the differentiable path (torch ops / exact-fp32 K6 kernels): no launch of it
-        # writes the f16x3 flag, so there is nothing to clear or to read back (one blocking .item() per step otherwise)
-        # -- UNLESS the image encoder's precision was chosen explicitly (bf16 / f16x3: ImageConvsFunction then hands
-        # the flag to mmf_image_convs_train_forward), in which case the step is checked like any other
-        if dev is None or dev.type != "cuda" or (step and use_autograd(self) and not IMAGE_ENCODER_PRECISION):
+        # a bare training step runs the differentiable path (torch ops / exact-fp32 K6 kernels): no launch of it writes
+        # the f16x3 flag, so there is nothing to clear or to read back (one blocking .item() per step otherwise) -- UNLESS
+        # the image encoders' training forward was given a reduced precision (ImageConvsFunction then splits operands and
+        # hands the flag to mmf_image_convs_train_forward), in which case the step is checked like any other
+        if dev is None or dev.type != "cuda" or (step and use_autograd(self) and training_image_precision_code() == _abi.PREC_F32):
             return fn(self, *args, **kwargs)
         depth = getattr(_CHECK, "depth", None)
         if depth is None:
@@ -888,9 +897,7 @@ class ImageConvsFunction(torch.autograd.Function):
         N = img.shape[0]
         mk = lambda c: torch.empty((N, c, 32, 32), dtype=torch.float32, device=img.device)
         a1, h, a2, a3, a4 = mk(32), mk(32), mk(32), mk(16), mk(8)
-        # exact fp32 unless the image-encoder precision was set explicitly (BASELINE config 5:
-        # set_image_encoder_precision("bf16")); the engine-wide default does not reach training
-        prec = _abi.IMAGE_PRECISIONS[IMAGE_ENCODER_PRECISION] if IMAGE_ENCODER_PRECISION else _abi.PREC_F32
+        prec = training_image_precision_code()
         _abi.image_convs_train_forward(blob, img, a1, h, a2, a3, a4,
                                        range_flag(img.device) if prec != _abi.PREC_F32 else None, prec)
         ctx.seq = seq
