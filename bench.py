@@ -367,6 +367,32 @@ def reference_sized_regimes(device):
     times = sorted(times[2:])
     out["train_e2e_32x30x16"] = {"ms_per_optimiser_step": 1e3 * times[len(times) // 2],
                                  "backend": "hip (native K6 recursion: mmf_pf_train_forward / _backward)"}
+    # the same step captured once as a hipGraph and replayed (train.GraphedFilterStep: same kernels, same bits; the eager
+    # step is host-bound at this size), image-encoder training forward through the resident K4 kernel
+    engine.set_training_backend("hip")
+    engine.set_image_encoder_precision("f16x3")
+    try:
+        torch.manual_seed(0)
+        fg = mmf.door_models.DoorCrossmodalParticleFilter().to(device).train()
+        fg.noise = mmf.NoiseSource(seed=5)
+        step = train.GraphedFilterStep(fg, torch.optim.Adam(fg.parameters(), lr=1e-4, capturable=True), initial_covariance=cov,
+                                       noise=fg.noise, eager_steps=2)
+        times = []
+        for _ in range(10):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            step(batch)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        times = sorted(times[4:])
+        out["train_e2e_32x30x16"]["hipgraph_replay_ms_per_optimiser_step"] = 1e3 * times[len(times) // 2]
+        out["train_e2e_32x30x16"]["hipgraph_note"] = ("train.GraphedFilterStep: forward + backward + Adam(capturable) captured once, replayed per batch; "
+                                                       "image-encoder training forward = the resident K4 kernel (f16x3)")
+    except Exception as e:  # a capture problem must not take the bench line with it
+        out["train_e2e_32x30x16"]["hipgraph_error"] = f"{type(e).__name__}: {e}"[:300]
+    finally:
+        engine.set_image_encoder_precision(None)
+        engine.set_training_backend(None)
     return out
 
 

@@ -216,11 +216,20 @@ def persistent_loop_gave_up(device) -> bool:
     return True
 
 
+# While a training step is being captured into a hipGraph (train.GraphedFilterStep) nothing may read the device: the checks
+# that cost a host read -- the range flag at the end of a forward_loop, "covariance not positive definite" in
+# initialize_beliefs -- only accumulate in the range flag (bits 1 / 16) and are read ONCE after every replay.
+CAPTURING = False
+
+
 def check_range(device):
     """Raise if any f16x3 launch since the last check saturated its operand split (one
     4-byte device->host read; filters call it once per ``forward_loop`` / on demand)."""
     flag = _RANGE_FLAGS.get(str(device))
     bits = 0 if flag is None else int(flag.item())
+    if bits & 16:
+        flag.zero_()
+        raise ValueError("initialize_beliefs: covariance is not positive definite (reported by a captured training step)")
     if bits & 4:
         flag.zero_()
         raise _abi.MmfError(
@@ -253,6 +262,8 @@ def _checked(fn, *, step: bool):
         # the image encoders' training forward was given a reduced precision (ImageConvsFunction then splits operands and
         # hands the flag to mmf_image_convs_train_forward), in which case the step is checked like any other
         if dev is None or dev.type != "cuda" or (step and use_autograd(self) and training_image_precision_code() == _abi.PREC_F32):
+            return fn(self, *args, **kwargs)
+        if CAPTURING:  # a hipGraph capture: no host read; the flag accumulates and is read after the replay
             return fn(self, *args, **kwargs)
         depth = getattr(_CHECK, "depth", None)
         if depth is None:

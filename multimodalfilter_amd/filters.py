@@ -92,7 +92,9 @@ class ParticleFilter(base.Filter):
             _abi.pf_init_particles(mean.detach().to(torch.float32).contiguous(),
                                    covariance.detach().to(torch.float32).contiguous(),
                                    eps.to(torch.float32).contiguous(), states, logw, not_pd)
-            if int(not_pd.item()):
+            if engine.CAPTURING:  # no host read inside a hipGraph capture: bit 16 of the range flag, read after the replay
+                engine.range_flag(mean.device).bitwise_or_(not_pd.ne(0).to(torch.int32) * 16)
+            elif int(not_pd.item()):
                 raise ValueError("initialize_beliefs: covariance is not positive definite")
             self.particle_states, self.particle_log_weights = states, logw
         self._spare_states = None

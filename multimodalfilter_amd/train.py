@@ -42,7 +42,8 @@ def default_noise(filter_model) -> NoiseSource:
 
 
 def filter_loss(filter_model, batch: Dict[str, torch.Tensor], *, initial_covariance: torch.Tensor,
-                noise: Optional[NoiseSource] = None, measurement_initialize: bool = False) -> torch.Tensor:
+                noise: Optional[NoiseSource] = None, measurement_initialize: bool = False,
+                initial_scale_tril: Optional[torch.Tensor] = None) -> torch.Tensor:
     """MSE of ``forward_loop`` on ``batch`` = ``{"states" (L, N, d), "controls" (L, N, 7), "image",
     "gripper_pos", "gripper_sensors" (L, N, ...)}`` (time-major)."""
     assert filter_model.training, "call filter_model.train() first"
@@ -54,7 +55,7 @@ def filter_loss(filter_model, batch: Dict[str, torch.Tensor], *, initial_covaria
         filter_model.measurement_initialize_beliefs({k: v[0] for k, v in obs.items()})
     else:
         noise = noise if noise is not None else default_noise(filter_model)
-        tril = torch.linalg.cholesky(initial_covariance.to(torch.float32))
+        tril = initial_scale_tril if initial_scale_tril is not None else torch.linalg.cholesky(initial_covariance.to(torch.float32))
         mean = states[0] + noise.gaussian((N, d), like=states) @ tril.t()
         filter_model.initialize_beliefs(mean=mean, covariance=initial_covariance[None].expand(N, d, d))
     pred = filter_model.forward_loop(observations={k: v[1:] for k, v in obs.items()}, controls=batch["controls"][1:])
@@ -73,6 +74,77 @@ def train_filter_step(filter_model, batch, optimizer: torch.optim.Optimizer, *, 
         distributed.all_reduce_gradients(filter_model)
     optimizer.step()
     return float(loss.detach())
+
+
+class GraphedFilterStep:
+    """``train_filter_step`` captured ONCE as a hipGraph and replayed: the reference-sized training step (32 trajectories x
+    30 particles x 16 steps, ``train_helpers.py:124-162``) is ~430 kernel launches of a few microseconds each, and the host
+    -- Python, autograd, ~8 us between launches -- not the GPU bounds it (GPU busy 64-69 %, profiles/r06/
+    train_refsize_fwd_ab.txt).  A replay is one launch of the whole step: same kernels, same order, same arithmetic.
+
+        step = GraphedFilterStep(filter_model, optimizer, initial_covariance=cov)
+        for batch in batches:           # every batch of the SAME shapes (the reference's fixed batch / subsequence sizes)
+            loss = step(batch)
+
+    The first ``eager_steps`` calls run ``train_filter_step`` eagerly (they build the packed blobs, per-trajectory programs
+    and allocator blocks a capture must not create); the next call captures forward + backward + ``optimizer.step()`` on static
+    copies of the batch and replays it; later calls copy the batch in and replay.  Randomness: the explicit ``NoiseSource``
+    generators are registered with the graph, so every replay draws fresh numbers, in the order the eager step would.  The
+    checks that need a host read (range flag, "covariance not positive definite") accumulate on the device during a replay and are
+    read once after it.  Requirements: a capturable optimiser (``torch.optim.SGD``, or Adam with ``capturable=True``), no
+    host-dependent control flow in user models, batches of one shape (a new shape raises)."""
+
+    def __init__(self, filter_model, optimizer: torch.optim.Optimizer, *, initial_covariance: torch.Tensor,
+                 noise: Optional[NoiseSource] = None, measurement_initialize: bool = False, all_reduce: bool = False,
+                 eager_steps: int = 2):
+        assert not all_reduce, "the gradient all-reduce is not captured: use train_filter_step for data-parallel training"
+        self.model, self.optimizer, self.cov = filter_model, optimizer, initial_covariance
+        self.noise = noise if noise is not None else default_noise(filter_model)
+        self.measurement_initialize, self.eager_left = measurement_initialize, int(eager_steps)
+        self.graph, self.static, self.loss, self.tril = None, None, None, None
+        self.stream = None   # eager steps and the capture share ONE side stream: autograd remembers the stream a parameter's
+                             # gradient accumulator was created on, and a capture must not reach back to the default stream
+
+    def _capture(self, batch):
+        dev = batch["states"].device
+        self.static = {k: v.detach().clone() for k, v in batch.items()}
+        self.tril = torch.linalg.cholesky(self.cov.to(torch.float32))   # outside the capture: the factorisation reads its status on the host
+        self.graph = torch.cuda.CUDAGraph()
+        sources = {id(s): s for s in (self.noise, getattr(self.model, "noise", None)) if type(s) is NoiseSource}
+        for src in sources.values():
+            self.graph.register_generator_state(src._gen(dev))
+        self.optimizer.zero_grad(set_to_none=True)
+        engine.clear_range(dev)
+        engine.CAPTURING = True
+        try:
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                loss = filter_loss(self.model, self.static, initial_covariance=self.cov, noise=self.noise,
+                                   measurement_initialize=self.measurement_initialize, initial_scale_tril=self.tril)
+                loss.backward()
+                self.optimizer.step()
+                self.loss = loss.detach()
+        finally:
+            engine.CAPTURING = False
+
+    def __call__(self, batch: Dict[str, torch.Tensor]) -> float:
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=batch["states"].device)
+        if self.eager_left > 0:
+            self.eager_left -= 1
+            self.stream.wait_stream(torch.cuda.current_stream(batch["states"].device))
+            with torch.cuda.stream(self.stream):
+                loss = train_filter_step(self.model, batch, self.optimizer, initial_covariance=self.cov, noise=self.noise,
+                                         measurement_initialize=self.measurement_initialize)   # (reads the loss: synchronises)
+            return loss
+        if self.graph is None:
+            self._capture(batch)
+        else:
+            for k, v in self.static.items():
+                assert batch[k].shape == v.shape, f"GraphedFilterStep was captured for {k} of shape {tuple(v.shape)}, got {tuple(batch[k].shape)}"
+                v.copy_(batch[k])
+        self.graph.replay()
+        engine.check_range(batch["states"].device)   # the replay's deferred checks: one 4-byte read
+        return float(self.loss)
 
 
 # ------------------------------------------------------------------------------ pre-training losses

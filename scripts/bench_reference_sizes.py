@@ -83,11 +83,30 @@ def train_regime(args, dev, backend):
         losses.append(train.train_filter_step(f, batch, opt, initial_covariance=cov, noise=f.noise))
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
-    engine.set_training_backend(None)
     times = sorted(times[2:])
-    return {"regime": "train_e2e", "backend": backend, "filter": "DoorCrossmodalParticleFilter", "batch": N,
-            "particles": M, "subsequence_length": L, "ms_per_optimiser_step": 1e3 * times[len(times) // 2],
-            "ms_best": 1e3 * times[0], "loss_first_last": [losses[0], losses[-1]]}
+    out = {"regime": "train_e2e", "backend": backend, "filter": "DoorCrossmodalParticleFilter", "batch": N,
+           "particles": M, "subsequence_length": L, "ms_per_optimiser_step": 1e3 * times[len(times) // 2],
+           "ms_best": 1e3 * times[0], "loss_first_last": [losses[0], losses[-1]]}
+    if backend == "hip":  # the same step as ONE hipGraph replay per batch (train.GraphedFilterStep: same kernels, same bits)
+        torch.manual_seed(0)
+        fg = mmf.door_models.DoorCrossmodalParticleFilter().to(dev).train()
+        fg.noise = mmf.NoiseSource(seed=5)
+        step = train.GraphedFilterStep(fg, torch.optim.Adam(fg.parameters(), lr=1e-4, capturable=True), initial_covariance=cov,
+                                       noise=fg.noise, eager_steps=2)
+        gt, gl = [], []
+        for it in range(args.train_iters + 4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gl.append(step(batch))
+            torch.cuda.synchronize()
+            gt.append(time.perf_counter() - t0)
+        gt = sorted(gt[4:])
+        out["hipgraph_replay_ms_per_optimiser_step"] = 1e3 * gt[len(gt) // 2]
+        out["hipgraph_replay_ms_best"] = 1e3 * gt[0]
+        out["hipgraph_note"] = ("train.GraphedFilterStep, Adam(capturable=True); bit-identical to eager steps with the same optimiser: "
+                                "tests/test_gpu_training.py::test_graphed_training_step_replays_the_eager_step")
+    engine.set_training_backend(None)
+    return out
 
 
 def train_cpu_twin(args):

@@ -1,13 +1,13 @@
-# Round-5 profile (run on the GPU box): kernel-trace stats + HBM traffic counters of the default bench, the EKF / f32 /
+# Round-6 profile (run on the GPU box): kernel-trace stats + HBM traffic counters of the default bench, the EKF / f32 /
 # philox variants, the reference-sized regimes (persistent loop on and off), K2's / K4's / the fused training kernels' SQ
 # counters, the training step with its HBM traffic per kernel (fused against the three-pass backward), the phase clocks of
 # the fused training kernel, the K1 batch sweep, and the plain bench lines (incl. --workload push_train).
-#   bash scripts/profile_round_r05.sh [out-dir under gpurun_out/]
-#   then: python scripts/collect_profiles.py gpurun_out/<dir> profiles/r05 ; python scripts/profiles_summary.py profiles/r05
+#   bash scripts/profile_round_r06.sh [out-dir under gpurun_out/]
+#   then: python scripts/collect_profiles.py gpurun_out/<dir> profiles/r06 ; python scripts/profiles_summary.py profiles/r06
 # rocprofv3 writes under /tmp (a kernel trace of a long run is tens of MB; gpurun_out/ returns <= 64 MiB): only the
 # summaries (stats CSVs, this repo's kernels' trace / counter rows) are copied into $OUT.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/${1:-prof_r05}
+OUT=$R/gpurun_out/${1:-prof_r06}
 P=/tmp/mmf_prof
 rm -rf $P; mkdir -p $OUT $P
 HIPCC=/opt/rocm/bin/hipcc
@@ -16,6 +16,7 @@ $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -I$R/include -I$R/multimodalfilter_a
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form=1 -Wno-unused-value -I$R/include -I$R/multimodalfilter_amd/csrc -o $R/scripts/ubench/fused_phases $R/scripts/ubench/fused_phases.hip >> $OUT/ubench_build.log 2>&1
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form=1 -Wno-unused-value -DNO_PHASE_CLOCKS -I$R/include -I$R/multimodalfilter_amd/csrc -o $R/scripts/ubench/fused_phases_noclk $R/scripts/ubench/fused_phases.hip >> $OUT/ubench_build.log 2>&1
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -Wno-unused-value -I$R/include -I$R/multimodalfilter_amd/csrc -o $R/scripts/ubench/k4_wg_spread $R/scripts/ubench/k4_wg_spread.hip >> $OUT/ubench_build.log 2>&1
+$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -o $R/scripts/ubench/mfma_shape $R/scripts/ubench/mfma_shape.hip >> $OUT/ubench_build.log 2>&1
 $HIPCC --offload-arch=gfx950 -O3 -Wno-unused-value -o $R/scripts/ubench/handoff_latency $R/scripts/ubench/handoff_latency.hip >> $OUT/ubench_build.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 LEAN="--no-cpu-baseline --no-precision-study --no-reference-sizes --no-configs"
@@ -69,16 +70,14 @@ python scripts/debug/fused_check.py --sizes 3x40,5x7,32x30,7x300,32x8192 --quiet
 # K4: the same counters for the image-encoder kernels of the EKF bench
 bash scripts/pmc_k4_r04.sh final > /dev/null 2>&1
 cp gpurun_out/pmc_k4_r04/final.json $OUT/pmc_k4_sq_counters.json
+bash scripts/debug/k4_ablate.sh > $OUT/k4_ablate_final.txt 2>&1
 ./scripts/ubench/mfma_shape > $OUT/ubench_mfma_shape.txt 2>&1
-{ for sh in 16 17 18 19 20 16 19; do ./scripts/ubench/k4_wg_spread 4096 2 $sh b | grep "rep 3 conv2b"; done
-  for sh in 16 19 16 19; do ./scripts/ubench/k4_wg_spread 4096 3 $sh b | grep "rep 3 conv2b"; done
-  for sh in 16 19; do ./scripts/ubench/k4_wg_spread 1024 2 $sh b | grep "rep 3 conv2b"; done
-  ./scripts/ubench/k4_wg_spread 4096 2 16 | grep -A12 "rep 3"; ./scripts/ubench/k4_wg_spread 4096 2 19 | grep -A12 "rep 3"; } > $OUT/ubench_k4_wg_spread.txt 2>&1
+python scripts/debug/find_copies.py --steps 20 --warmup 5 --no-cpu-baseline --no-configs --no-reference-sizes > /dev/null 2> $OUT/find_copies.txt
+bash scripts/debug/k1_cluster_ab.sh > $OUT/k1_cluster_ab_final.txt 2>&1
+{ ./scripts/ubench/k4_wg_spread 4096 2 0; ./scripts/ubench/k4_wg_spread 4096 3 0; ./scripts/ubench/k4_wg_spread 1024 2 0 b; } > $OUT/ubench_k4_wg_spread.txt 2>&1
 ./scripts/ubench/handoff_latency > $OUT/ubench_handoff_latency.txt 2>&1
-python scripts/debug/k4_two_streams.py 4096 2 2>&1 | grep -v amdgpu.ids > $OUT/bench_k4_two_streams.txt; python scripts/debug/k4_two_streams.py 3072 3 2>&1 | grep -v amdgpu.ids >> $OUT/bench_k4_two_streams.txt
-{ echo "# default: K7 programs' reverse mode + fc64 kernels + finalize (MMF_TRAIN_TRAJ_PROGRAMS=1), merged measurement launches"; python scripts/bench_reference_sizes.py --only train --backends hip --no-cpu 2>&1 | grep "^{";
-  echo "# MMF_TRAIN_FUSED_MERGE=0"; MMF_TRAIN_FUSED_MERGE=0 python scripts/bench_reference_sizes.py --only train --backends hip --no-cpu 2>&1 | grep "^{";
-  echo "# MMF_TRAIN_TRAJ_PROGRAMS=0 (torch autograd + rocBLAS for the per-trajectory networks: round 4)"; MMF_TRAIN_TRAJ_PROGRAMS=0 python scripts/bench_reference_sizes.py --only train --backends hip --no-cpu 2>&1 | grep "^{";
+{ echo "# default (exact-fp32 image-encoder training forward)"; python scripts/bench_reference_sizes.py --only train --backends hip --no-cpu 2>&1 | grep "^{";
+  echo "# MMF_K4_PRECISION=f16x3 (image-encoder training forward = the resident K4 kernel)"; MMF_K4_PRECISION=f16x3 python scripts/bench_reference_sizes.py --only train --backends hip --no-cpu 2>&1 | grep "^{";
   echo "# default again"; python scripts/bench_reference_sizes.py --only train --backends hip --no-cpu 2>&1 | grep "^{"; } > $OUT/bench_train_refsize_ab.txt
 # plain bench lines (un-profiled)
 python bench.py > $OUT/bench_door_pf_n1.json 2> $OUT/bench.err
@@ -101,18 +100,14 @@ python scripts/bench_k4.py > $OUT/bench_k4.txt 2>> $OUT/bench.err
 python scripts/bench_k1.py > $OUT/bench_k1.txt 2>> $OUT/bench.err
 python scripts/bench_k1.py --batch-sweep > $OUT/bench_k1_dephase_ab.txt 2>> $OUT/bench.err
 # kernel-level checks of the compact training path against fp64 / the exact-fp32 kernel
-{ python scripts/debug/wgrad_h_check.py; python scripts/debug/bwd_h_check.py; } 2>&1 | grep -v amdgpu.ids > $OUT/check_train_f16_kernels.txt
 # the sizes the reference itself runs: persistent loop (default) vs the loop of launches, with the stamps of one step
 python scripts/bench_reference_sizes.py > $OUT/bench_reference_sizes.txt 2>> $OUT/bench.err
 { echo "# MMF_PF_PERSISTENT=1 (default)"; MMF_PERSIST_STAMPS=40 python scripts/bench_reference_sizes.py --only eval --no-cpu --eval-repeats 1 2>&1 | grep -v amdgpu.ids;
   echo "# MMF_PF_PERSISTENT=0 (one launch per kernel and step)"; MMF_PF_PERSISTENT=0 python scripts/bench_reference_sizes.py --only eval --no-cpu 2>&1 | grep -v amdgpu.ids; } > $OUT/bench_persistent_loop_ab.txt
 python scripts/bench_train.py > $OUT/bench_train_push_unimodal_pf.json 2>> $OUT/bench.err
 python scripts/bench_train.py --backends hip --cnn-precision bf16 >> $OUT/bench_train_push_unimodal_pf.json 2>> $OUT/bench.err
-{ echo "# default (round 5): recompute + backward + weight gradients of a network call as ONE kernel (MMF_TRAIN_FUSED=1)"; python scripts/bench_train.py --backends hip 2>&1 | grep "^{";
-  echo "# MMF_TRAIN_FUSED=0: three passes over f16 recompute buffers (round 4's default)"; MMF_TRAIN_FUSED=0 python scripts/bench_train.py --backends hip 2>&1 | grep "^{";
-  echo "# MMF_TRAIN_BACKWARD_F16X3=0 (three passes, f16 buffers, f16x3 recompute, exact-fp32 backward data path)"; MMF_TRAIN_BACKWARD_F16X3=0 python scripts/bench_train.py --backends hip 2>&1 | grep "^{";
-  echo "# MMF_TRAIN_RECOMPUTE_F16X3=0 (f16 buffers, exact-fp32 recompute and backward)"; MMF_TRAIN_RECOMPUTE_F16X3=0 python scripts/bench_train.py --backends hip 2>&1 | grep "^{";
-  echo "# MMF_TRAIN_COMPACT_STASH=0 (fp32 recompute buffers, exact-fp32 recompute: round 3)"; MMF_TRAIN_COMPACT_STASH=0 python scripts/bench_train.py --backends hip 2>&1 | grep "^{";
+{ echo "# default: recompute + backward + weight gradients of a network call as ONE kernel (MMF_TRAIN_FUSED=1)"; python scripts/bench_train.py --backends hip 2>&1 | grep "^{";
+  echo "# MMF_TRAIN_FUSED=0: the cross-check form, three passes of exact fp32 products over f16 recompute buffers"; MMF_TRAIN_FUSED=0 python scripts/bench_train.py --backends hip 2>&1 | grep "^{";
   echo "# default again"; python scripts/bench_train.py --backends hip 2>&1 | grep "^{"; } > $OUT/bench_train_fused_ab.txt
 ./scripts/ubench/k1_phases 256 4096 > $OUT/k1_phases.txt 2>&1; ./scripts/ubench/k1_phases 256 1024 >> $OUT/k1_phases.txt 2>&1; ./scripts/ubench/k1_phases 32 300 >> $OUT/k1_phases.txt 2>&1
 MMF_PRECISION=f32 python -m pytest tests -m gpu -q 2>&1 | grep -E '^E  |^FAILED|passed|failed' | tail -20 > $OUT/pytest_gpu_f32_mode.txt

@@ -1113,3 +1113,43 @@ def test_hip_backend_differentiates_the_per_trajectory_networks_through_their_pr
     top = max(float(v.abs().max()) for v in g0.values())
     worst = max((float((g0[k] - g1[k]).abs().max()) / max(1e-3 * top, float(g0[k].abs().max())), k) for k in g0)
     assert worst[0] < GRAD_TOL, worst
+
+
+@pytest.mark.parametrize("optim", ["sgd", "adam"])
+def test_graphed_training_step_replays_the_eager_step(optim):
+    """``train.GraphedFilterStep`` (round 6): the reference-sized end-to-end training step -- forward recursion, backward,
+    optimiser -- captured ONCE as a hipGraph and replayed per batch (the eager step is host-bound at this size: ~430 launches
+    of a few microseconds).  Same kernels in the same order on the same random numbers: over eight steps on changing batches
+    the losses and the final weights equal the eager steps' bit for bit, also with the image encoders' training forward on
+    the resident K4 kernel."""
+    import copy
+
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine, synthetic, train
+
+    dev = torch.device("cuda:0")
+    N, M, L, d = 8, 30, 6, 3
+    batches = [{k: v.to(dev) for k, v in synthetic.make_trajectories(state_dim=d, T=L - 1, N=N, seed=3 + i).items()} for i in range(3)]
+    cov = torch.eye(d, device=dev) * 0.1
+    torch.manual_seed(0)
+    f = mmf.door_models.DoorCrossmodalParticleFilter().to(dev).train()
+    f.num_particles = M
+    g = copy.deepcopy(f)
+    mk = (lambda m: torch.optim.SGD(m.parameters(), lr=1e-3)) if optim == "sgd" else (lambda m: torch.optim.Adam(m.parameters(), lr=1e-4, capturable=True))
+    of, og = mk(f), mk(g)
+    f.noise, g.noise = mmf.NoiseSource(seed=5), mmf.NoiseSource(seed=5)
+    engine.set_training_backend("hip")
+    engine.set_image_encoder_precision("f16x3" if optim == "adam" else None)
+    try:
+        step = train.GraphedFilterStep(g, og, initial_covariance=cov, noise=g.noise, eager_steps=2)
+        eager = [train.train_filter_step(f, batches[i % 3], of, initial_covariance=cov, noise=f.noise) for i in range(8)]
+        graphed = [step(batches[i % 3]) for i in range(8)]
+        assert step.graph is not None
+        with pytest.raises(AssertionError):
+            step({k: v[:, :4] for k, v in batches[0].items()})   # another batch shape: refused, not silently re-captured
+    finally:
+        engine.set_image_encoder_precision(None)
+        engine.set_training_backend(None)
+    assert graphed == eager
+    for (n, p), q in zip(f.named_parameters(), g.parameters()):
+        assert torch.equal(p.detach(), q.detach()), n
