@@ -375,7 +375,7 @@ def reference_sized_regimes(device):
         torch.manual_seed(0)
         fg = mmf.door_models.DoorCrossmodalParticleFilter().to(device).train()
         fg.noise = mmf.NoiseSource(seed=5)
-        step = train.GraphedFilterStep(fg, torch.optim.Adam(fg.parameters(), lr=1e-4, capturable=True), initial_covariance=cov,
+        step = train.GraphedFilterStep(fg, torch.optim.Adam(fg.parameters(), lr=1e-4, capturable=True, fused=True), initial_covariance=cov,
                                        noise=fg.noise, eager_steps=2)
         times = []
         for _ in range(10):

@@ -358,6 +358,23 @@ int mmf_image_convs_train_backward(const float* packed_bwd, const float* a1, con
 int mmf_conv_weight_grads(const float* g, const float* act, float* partial, float* partial_b, int N, int co,
                           int ci, int n_blocks, float* dw, float* db, void* stream);
 
+/* ABI 39.  mmf_image_convs_train_backward with the three layers that have 32 output channels (97 % of the MACs) on
+ * v_mfma_f32_32x32x16_f16, three products per product: every gradient tensor is scaled by the power of two that brings its
+ * largest magnitude to [2^14, 2^15) before its operand split and the result scaled back; masks, skip path and outputs as the
+ * exact-fp32 form.  conv 16->8's gradient stays exact.  scratch (4 floats, device): max |g3|, max |g2|, max |gh|, max |g_a4| on
+ * return -- reduced on the device (each launch leaves the next one's) -- the `g_absmax` words of mmf_conv_weight_grads_h. */
+int mmf_image_convs_train_backward_h(const float* packed_bwd, const float* a1, const float* h,
+                                     const float* a2, const float* a3, const float* g_a4, float* g1,
+                                     float* gh, float* g2, float* g3, float* scratch, int N, void* stream);
+
+/* ABI 39.  The same gradients of a 3x3 layer (co, ci) = (32, 32) | (16, 32) | (8, 16) on v_mfma_f32_32x32x16_f16 with the
+ * three-product f16 split of both operands (csrc/image_encoder_train_h.inc): 54 MFMAs of 32 cycles per image row instead of
+ * 144 of 64.  g_absmax: DEVICE scalar, the largest |g| (the caller reduces it first: no host read) -- g is multiplied by the
+ * power of two that brings it to [2^14, 2^15) and the sums are multiplied back, so gradients of any magnitude keep their
+ * leading bits; db is the exact fp32 sum.  range_flag (or null): OR-ed with 1 if an activation left the f16 range. */
+int mmf_conv_weight_grads_h(const float* g, const float* act, const float* g_absmax, float* partial, float* partial_b,
+                            int32_t* range_flag, int N, int co, int ci, int n_blocks, float* dw, float* db, void* stream);
+
 /* ---------------------------------------------------------------- particle-filter step loop
  * Replaces the Python loop of torchfilter's Filter.forward_loop (call site
  * crossmodal/eval_helpers.py:139-142) for the fused models: one call enqueues the kernels of

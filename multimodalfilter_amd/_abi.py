@@ -191,6 +191,8 @@ SIGNATURES = {
     "mmf_image_convs_train_forward": (c_int, [_FP] * 8 + [c_int, c_int, c_void_p]),
     "mmf_image_convs_train_backward": (c_int, [_FP] * 10 + [c_int, c_void_p]),
     "mmf_conv_weight_grads": (c_int, [_FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, _FP, _FP, c_void_p]),
+    "mmf_image_convs_train_backward_h": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, _FP, c_int, c_void_p]),
+    "mmf_conv_weight_grads_h": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, _FP, _FP, c_void_p]),
     "mmf_image_encoder": (c_int, [POINTER(c_void_p), c_int, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
 }
 
@@ -389,6 +391,14 @@ def image_convs_train_backward(packed_bwd, a1, h, a2, a3, g_a4, g1, gh, g2, g3):
                "mmf_image_convs_train_backward")
 
 
+def image_convs_train_backward_h(packed_bwd, a1, h, a2, a3, g_a4, g1, gh, g2, g3, scratch):
+    assert scratch.numel() >= 4 and scratch.dtype == torch.float32
+    with _on(g_a4):
+        _check(load().mmf_image_convs_train_backward_h(ptr(packed_bwd), ptr(a1), ptr(h), ptr(a2), ptr(a3), ptr(g_a4), ptr(g1),
+                                                       ptr(gh), ptr(g2), ptr(g3), ptr(scratch), g_a4.shape[0], stream_of(g_a4)),
+               "mmf_image_convs_train_backward_h")
+
+
 def conv_weight_grads(g, act, partial, partial_b, n_blocks: int, dw=None, db=None):
     """``partial (n_blocks, 9, 32, 32)``, ``partial_b (n_blocks, 32)``: one slot per workgroup; ``dw (co, ci, k, k)`` /
     ``db (co)``: the slots summed into ``nn.Conv2d``'s layout by a second launch."""
@@ -396,6 +406,15 @@ def conv_weight_grads(g, act, partial, partial_b, n_blocks: int, dw=None, db=Non
     with _on(g):
         _check(load().mmf_conv_weight_grads(ptr(g), ptr(act), ptr(partial), ptr(partial_b), g.shape[0], g.shape[1],
                                             act.shape[1], n_blocks, ptr(dw), ptr(db), stream_of(g)), "mmf_conv_weight_grads")
+
+
+def conv_weight_grads_h(g, act, g_absmax, partial, partial_b, range_flag, n_blocks: int, dw=None, db=None):
+    """``conv_weight_grads`` on the f16 matrix pipe with three products per product; ``g_absmax``: device scalar (largest |g|)."""
+    assert partial.numel() >= n_blocks * 9 * 32 * 32 and partial_b.numel() >= n_blocks * 32 and g_absmax.numel() == 1
+    with _on(g):
+        _check(load().mmf_conv_weight_grads_h(ptr(g), ptr(act), ptr(g_absmax), ptr(partial), ptr(partial_b),
+                                              ptr(range_flag, dtype=torch.int32), g.shape[0], g.shape[1], act.shape[1], n_blocks,
+                                              ptr(dw), ptr(db), stream_of(g)), "mmf_conv_weight_grads_h")
 
 
 def image_convs_backward_floats() -> int:

@@ -542,7 +542,9 @@ int launch_conv(const ConvArgs& a, int nets, hipStream_t s) {
 //   /root/reference/crossmodal/door_models/layers.py:43-58  in  torchfilter.train.* (train_helpers.py:76-162);
 // the 8192 -> 64 linear and the ResLinear behind it stay library GEMMs (rocBLAS through torch).
 struct BwdLayout {
-  int w4t, w3t, w2bt, w2at, zeros, total;  // dgrad weights in conv_kernel's fragment layout; 32 zero biases
+  int w4t, w3t, w2bt, w2at, zeros;  // dgrad weights in conv_kernel's fragment layout; 32 zero biases
+  int h3t, h2bt, h2at;              // round 6: the 32-output-channel layers again as f16x3 A fragments [tap][kc][hi|lo][lane][8 halves]
+  int total;
 };
 __host__ __device__ constexpr BwdLayout bwd_layout() {
   BwdLayout L{};
@@ -552,6 +554,9 @@ __host__ __device__ constexpr BwdLayout bwd_layout() {
   L.w2bt = o; o += conv_w_floats(32, 32, 3);
   L.w2at = o; o += conv_w_floats(32, 32, 3);
   L.zeros = o; o += 32;
+  L.h3t = o; o += 9 * 1 * 2 * 64 * 8 / 2;      // 16 -> 32: one k-chunk of 16 input channels per tap
+  L.h2bt = o; o += conv_h_floats(32);
+  L.h2at = o; o += conv_h_floats(32);
   L.total = o;
   return L;
 }
@@ -564,7 +569,26 @@ __global__ void pack_convs_backward_kernel(MmfImageEncoderDesc d, float* __restr
   const int src[4] = {4, 3, 2, 1};                                      // forward conv index in desc
   for (int q0 = blockIdx.x * blockDim.x + threadIdx.x; q0 < L.total; q0 += gridDim.x * blockDim.x) {
     float v = 0.f;
-    if (q0 < L.zeros) {
+    if (q0 >= L.h3t) {
+      // f16x3 A fragments of the backward convolutions with 32 output channels: element i of lane (row, half) in k-chunk kc
+      // of a tap = W'[co_b = row][ci_b = 16 kc + 8 half + i][ky][kx] = W[ci_b][co_b][2 - ky][2 - kx] of the forward layer, x 2^8
+      const int hoffs[4] = {L.h3t, L.h2bt, L.h2at, L.total};
+      const int hcin[3] = {16, 32, 32}, hsrc[3] = {3, 2, 1};
+      int c = 0;
+      while (q0 >= hoffs[c + 1]) ++c;
+      const int KC = hcin[c] / 16;
+      unsigned short hb[2];
+      for (int z = 0; z < 2; ++z) {
+        const int he = 2 * (q0 - hoffs[c]) + z;
+        const int i = he & 7, lane = (he >> 3) & 63, part = (he >> 9) & 1, rest = he >> 10;
+        const int kc = rest % KC, tap = rest / KC, ky = tap / 3, kx = tap % 3;
+        const int co_b = lane & 31, ci_b = 16 * kc + 8 * (lane >> 5) + i;
+        const float w = kWScale * d.conv_w[hsrc[c]][((ci_b * 32 + co_b) * 3 + (2 - ky)) * 3 + (2 - kx)];
+        const __half hi = __float2half_rn(w);
+        hb[z] = part ? __half_as_ushort(__float2half_rn(w - __half2float(hi))) : __half_as_ushort(hi);
+      }
+      v = __uint_as_float(static_cast<unsigned>(hb[0]) | (static_cast<unsigned>(hb[1]) << 16));
+    } else if (q0 < L.zeros) {
       int c = 0;
       while (q0 >= offs[c + 1]) ++c;
       const int e = q0 - offs[c];
@@ -731,6 +755,7 @@ constexpr int kWPh = 34;  // padded row of the f16 planes: 1 | 32 pixels | 1
 
 #include "image_encoder_fused.inc"
 #include "image_encoder_resident.inc"
+#include "image_encoder_train_h.inc"
 
 }  // namespace
 
@@ -904,6 +929,48 @@ extern "C" int mmf_image_convs_train_backward(const float* packed_bwd, const flo
   return launch_conv<32, 32, 3, false, true, true>(c, 1, s);
 }
 
+extern "C" int mmf_image_convs_train_backward_h(const float* packed_bwd, const float* a1, const float* h,
+                                                const float* a2, const float* a3, const float* g_a4, float* g1,
+                                                float* gh, float* g2, float* g3, float* scratch, int N, void* stream) {
+  if (!packed_bwd || !a1 || !h || !a2 || !a3 || !g_a4 || !g1 || !gh || !g2 || !g3 || !scratch || N < 0) return MMF_EINVAL;
+  if (N == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  constexpr BwdLayout B = bwd_layout();
+  ConvArgs c{};
+  c.packed[0] = packed_bwd;
+  c.N = N;
+  c.boff = B.zeros;
+  int rc;
+  if (hipMemsetAsync(scratch, 0, 4 * sizeof(float), s) != hipSuccess) return MMF_EINVAL;
+  // scratch: max |g3|, max |g2|, max |gh|, max |g_a4| -- the scales of the layers' operand splits here AND of
+  // mmf_conv_weight_grads_h afterwards (the caller hands the words on); each dgrad launch leaves the next one's
+  unsigned* mx = reinterpret_cast<unsigned*>(scratch);
+  auto absmax = [&](const float* x, size_t n, int slot) {
+    int blocks = static_cast<int>((n / 4 + 255) / 256);
+    if (blocks > 512) blocks = 512;
+    absmax_kernel<<<blocks, 256, 0, s>>>(x, n, mx + slot);
+  };
+  const size_t plane = static_cast<size_t>(N) * kImg * kImg;
+  absmax(g_a4, 8 * plane, 3);
+  // g3 = dgrad(conv 16->8)(g_a4) where a3 > 0: 8 input channels, exact fp32 (4 % of the backward's MACs)
+  c.in = g_a4; c.mask = a3; c.out = g3; c.woff = B.w4t;
+  if ((rc = launch_conv<8, 16, 3, false, false, true>(c, 1, s))) return rc;
+  absmax(g3, 16 * plane, 0);
+  DgradHArgs d{};
+  d.packed = packed_bwd; d.N = N;
+  // g2 = dgrad(conv 32->16)(g3) where a2 > 0
+  d.in = g3; d.in_absmax = scratch; d.skip = nullptr; d.mask = a2; d.out = g2; d.out_absmax = mx + 1; d.hoff = B.h3t;
+  if ((rc = launch_dgrad_h<16, false>(d, s))) return rc;
+  // gh = dgrad(ResConv block2)(g2) where h > 0
+  d.in = g2; d.in_absmax = scratch + 1; d.mask = h; d.out = gh; d.out_absmax = mx + 2; d.hoff = B.h2bt;
+  if ((rc = launch_dgrad_h<32, false>(d, s))) return rc;
+  // g1 = (g2 + dgrad(ResConv block1)(gh)) where a1 > 0
+  d.in = gh; d.in_absmax = scratch + 2; d.skip = g2; d.mask = a1; d.out = g1; d.out_absmax = nullptr; d.hoff = B.h2at;
+  rc = launch_dgrad_h<32, true>(d, s);
+  MMF_CHECK_LAUNCH();
+  return rc;
+}
+
 using WgradKernel = void (*)(const float*, const float*, float*, float*, int);
 
 static int launch_wgrad(WgradKernel k, const float* g, const float* act, float* partial, float* partial_b, int N,
@@ -945,6 +1012,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_finalize_kernel(const float* _
     for (int b = 0; b < n_blocks; ++b) s = __fadd_rn(s, partial_b[b * 32 + o]);
     db[o] = s;
   }
+}
+
+extern "C" int mmf_conv_weight_grads_h(const float* g, const float* act, const float* g_absmax, float* partial, float* partial_b,
+                                       int32_t* range_flag, int N, int co, int ci, int n_blocks, float* dw, float* db, void* stream) {
+  if (!g || !act || !g_absmax || !partial || !partial_b || N < 0 || n_blocks < 1) return MMF_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  void (*k)(const float*, const float*, float*, float*, int, const float*, int*) = nullptr;
+  if (co == 32 && ci == 32) k = conv_wgrad_h_kernel<32, 32>;
+  else if (co == 16 && ci == 32) k = conv_wgrad_h_kernel<16, 32>;
+  else if (co == 8 && ci == 16) k = conv_wgrad_h_kernel<8, 16>;
+  else return MMF_EINVAL;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(kLdsWgrad));
+  if (e != hipSuccess) return static_cast<int>(e);
+  k<<<n_blocks, 512, kLdsWgrad, s>>>(g, act, partial, partial_b, N, g_absmax, range_flag);
+  MMF_CHECK_LAUNCH();
+  if (!dw) return 0;
+  conv_wgrad_finalize_kernel<<<(9216 + co + 255) / 256, 256, 0, s>>>(partial, partial_b, n_blocks, co, ci, dw, db);
+  MMF_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int mmf_conv_weight_grads(const float* g, const float* act, float* partial, float* partial_b, int N, int co,

@@ -936,19 +936,32 @@ class ImageConvsFunction(torch.autograd.Function):
         g_a4 = g_a4.to(torch.float32).contiguous()
         g1, gh, g2 = torch.empty_like(a1), torch.empty_like(a1), torch.empty_like(a1)
         g3 = torch.empty_like(a3)
-        _abi.image_convs_train_backward(cached[1], a1, h, a2, a3, g_a4, g1, gh, g2, g3)
+        gmax = None   # f16x3 backward: max |g3|, |g2|, |gh|, |g_a4| as device scalars (the operand splits' scales)
+        if training_image_precision_code() != _abi.PREC_F32:   # round 6: the 32-output-channel layers on the f16 matrix pipe
+            gmax = torch.empty(4, dtype=torch.float32, device=img.device)
+            _abi.image_convs_train_backward_h(cached[1], a1, h, a2, a3, g_a4, g1, gh, g2, g3, gmax)
+        else:
+            _abi.image_convs_train_backward(cached[1], a1, h, a2, a3, g_a4, g1, gh, g2, g3)
         blocks = max(1, min(2 * N, 256))  # a workgroup walks half-images; one partial per workgroup
         partial = torch.empty((blocks, 9, 32, 32), dtype=torch.float32, device=img.device)
         partial_b = torch.empty((blocks, 32), dtype=torch.float32, device=img.device)
         E = lambda *shape: torch.empty(shape, dtype=torch.float32, device=img.device)
 
-        def wgrad(g, act, k=3):  # partial slots, then their sum in nn.Conv2d's layout: two launches per layer
+        # round 6: with a reduced precision selected for the training forward (f16x3 / bf16: training_image_precision_code) the
+        # 3x3 layers' weight gradients run on the f16 matrix pipe with three products per product (mmf_conv_weight_grads_h:
+        # 5x fewer matrix-pipe cycles than the exact-fp32 kernel); the 5x5 stem (25 taps of one channel) stays exact
+        reduced = training_image_precision_code() != _abi.PREC_F32
+
+        def wgrad(g, act, k=3, slot=None):  # partial slots, then their sum in nn.Conv2d's layout: two launches per layer
             co, ci = g.shape[1], act.shape[1]
             dw, db = E(co, ci, k, k), E(co)
-            _abi.conv_weight_grads(g, act, partial, partial_b, blocks, dw, db)
+            if reduced and k == 3:
+                _abi.conv_weight_grads_h(g, act, gmax[slot:slot + 1], partial, partial_b, range_flag(g.device), blocks, dw, db)
+            else:
+                _abi.conv_weight_grads(g, act, partial, partial_b, blocks, dw, db)
             return dw, db
 
-        (gw4, gb4), (gw3, gb3), (gw2b, gb2b), (gw2a, gb2a) = wgrad(g_a4, a3), wgrad(g3, a2), wgrad(g2, h), wgrad(gh, a1)
+        (gw4, gb4), (gw3, gb3), (gw2b, gb2b), (gw2a, gb2a) = wgrad(g_a4, a3, slot=3), wgrad(g3, a2, slot=0), wgrad(g2, h, slot=1), wgrad(gh, a1, slot=2)
         gw1, gb1 = wgrad(g1, img[:, None], 5)                                            # the 5x5 stem
         return (None, None, gw1, gw2a, gw2b, gw3, gw4, gb1, gb2a, gb2b, gb3, gb4)
 

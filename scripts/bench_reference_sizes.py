@@ -91,7 +91,7 @@ def train_regime(args, dev, backend):
         torch.manual_seed(0)
         fg = mmf.door_models.DoorCrossmodalParticleFilter().to(dev).train()
         fg.noise = mmf.NoiseSource(seed=5)
-        step = train.GraphedFilterStep(fg, torch.optim.Adam(fg.parameters(), lr=1e-4, capturable=True), initial_covariance=cov,
+        step = train.GraphedFilterStep(fg, torch.optim.Adam(fg.parameters(), lr=1e-4, capturable=True, fused=True), initial_covariance=cov,
                                        noise=fg.noise, eager_steps=2)
         gt, gl = [], []
         for it in range(args.train_iters + 4):
