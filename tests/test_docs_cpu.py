@@ -1,4 +1,4 @@
-"""DESIGN.md quotes measured numbers; the measurements live under ``profiles/r05`` (rocprofv3 CSVs, bench JSON
+"""DESIGN.md quotes measured numbers; the measurements live under ``profiles/r06`` (rocprofv3 CSVs, bench JSON
 lines, ``SUMMARY.md`` generated from them by ``scripts/profiles_summary.py``).  Round 2's verdict found three
 numbers in the docs that no committed file held.  These tests tie the headline figures of DESIGN.md section 5 to
 the committed files mechanically: a re-profile that is not followed by a doc update fails here."""
@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PROF = os.path.join(ROOT, "profiles", "r05")
+PROF = os.path.join(ROOT, "profiles", "r06")
 
 
 def _line(name):
@@ -74,8 +74,7 @@ def test_kernel_durations_in_design_are_the_committed_rocprof_averages():
     for csv_name, prefix in (("door_pf_kernel_stats.csv", "particle_net_kernel<3, 2, 1, 2, 1, 2, true>"),
                              ("door_pf_kernel_stats.csv", "particle_net_kernel<3, 3, 0, 2, 1, 2, true>"),
                              ("door_pf_kernel_stats.csv", "pf_resample_systematic_kernel<3, true>"),
-                             ("door_ekf_kernel_stats.csv", "conv2b_conv3_kernel<false, 2, true>"),
-                             ("door_ekf_kernel_stats.csv", "stem_conv2a_kernel<false>")):
+                             ("door_ekf_kernel_stats.csv", "image_encoder_resident_kernel<false>")):
         us = _avg_us(csv_name, prefix)
         assert f"{us:.1f}" in text, f"{prefix}: {us:.1f} us ({csv_name}) is not what DESIGN.md quotes"
     # the roofline fraction follows from the measurement kernel's average: 6.067e10 FLOP per launch
@@ -87,7 +86,36 @@ def test_kernel_durations_in_design_are_the_committed_rocprof_averages():
 def test_summary_is_what_the_script_generates_from_the_committed_files():
     with open(os.path.join(PROF, "SUMMARY.md")) as fh:
         committed = fh.read()
-    out = subprocess.run([sys.executable, os.path.join("scripts", "profiles_summary.py"), os.path.join("profiles", "r05"), "--stdout"],
+    out = subprocess.run([sys.executable, os.path.join("scripts", "profiles_summary.py"), os.path.join("profiles", "r06"), "--stdout"],
                          capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-1000:]
     assert out.stdout.strip() == committed.strip()
+
+
+def test_bench_traffic_is_the_newest_committed_profile():
+    """Round 5's verdict: ``roofline.traffic`` was read from an older round than the one the line was measured in.  The
+    bench now walks ``profiles/rNN`` newest first and names the file (``traffic_source``); this ties both to the files."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    newest = bench.profile_rounds()[0]
+    assert os.path.basename(newest) == os.path.basename(PROF)
+    with open(os.path.join(PROF, "pmc_hbm_traffic.json")) as fh:
+        k = json.load(fh)["kernels"]
+    want = next(v for name, v in k.items() if name.startswith("particle_net_kernel<3, 2, 1, 2, 1, 2, true>"))["hbm_bytes_corrected"]
+    got, src = bench.pmc_traffic("particle_net_kernel<3, 2, 1, 2, 1, 2, true>")
+    assert got == want and src == os.path.join("profiles", os.path.basename(PROF), "pmc_hbm_traffic.json")
+    with open(os.path.join(PROF, "pmc_hbm_traffic_ekf.json")) as fh:
+        k = json.load(fh)["kernels"]
+    want = sum(next(v for name, v in k.items() if name.startswith(prefix))["hbm_bytes_corrected"] for prefix in bench.K4_SEQUENCES[0])
+    got, src = bench.pmc_traffic_k4_ekf()
+    assert got == want and src == os.path.join("profiles", os.path.basename(PROF), "pmc_hbm_traffic_ekf.json")
+    # the committed lines of this round carry the same pair
+    for name, traffic in (("bench_door_pf_n1.json", bench.pmc_traffic("particle_net_kernel<3, 2, 1, 2, 1, 2, true>")),
+                          ("bench_door_ekf_n1.json", bench.pmc_traffic_k4_ekf())):
+        roof = _line(name)["roofline"]
+        assert "traffic_source" in roof, name
+        if roof["traffic_source"] == traffic[1]:
+            assert roof["traffic"] == traffic[0], name
+    # and a kernel no round profiled has no traffic rather than a stale one
+    assert bench.pmc_traffic("no_such_kernel") == (None, None)
