@@ -131,8 +131,7 @@ def pmc_traffic(kernel_key: str, files=("pmc_hbm_traffic.json", "pmc_hbm_traffic
 
 # the kernels of ONE image-encoder launch sequence, by generation of K4 (newest first): round 6's resident kernel keeps B in
 # LDS; rounds 3-5 ran stem_conv2a + conv2b_conv3 (conv 16->8 inside); both end in the split-K linear layer
-K4_SEQUENCES = (("image_encoder_resident_kernel<false", "fc_fused_f16x3_kernel"),
-                ("image_encoder_resident_kernel<false", "fc_partial_f16x3_kernel", "fc_tail_kernel<false"),
+K4_SEQUENCES = (("image_encoder_resident_kernel<false", "fc_partial_f16x3_kernel", "fc_tail_kernel<false"),
                 ("stem_conv2a_kernel<false", "conv2b_conv3_kernel<false", "fc_partial_f16x3_kernel", "fc_tail_kernel<false"))
 
 
@@ -1076,8 +1075,8 @@ def main():
             dom = ks["image_encoder"]
             ach = dom["flops_per_launch"] / (dom["avg_ms"] * 1e-3) / 1e12
             traffic, source = pmc_traffic_k4_ekf() if (B == 1024 and args.workload == "door_ekf") else (None, None)
-            out["roofline"] = {"kernel": "image encoder launch sequence (K4: image_encoder_resident_kernel, "
-                                         "fc_fused_f16x3_kernel) per chunk of images",
+            out["roofline"] = {"kernel": "image encoder launch sequence (K4: convolution stack, fc_partial_f16x3_kernel, "
+                                         "fc_tail_kernel) per chunk of images",
                                "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK["f16x3"], "unit": "TFLOP/s",
                                "frac": ach / MFMA_PEAK["f16x3"], "traffic": traffic, "traffic_source": source,
                                "note": "ALGORITHMIC fp32 FLOPs (26.12 MMAC per image per encoder); every product is 3 f16 MFMA "

@@ -478,158 +478,6 @@ __global__ __launch_bounds__(256) void fc_partial_f16x3_kernel(FcArgs a) {
   }
 }
 
-// Round 6: the split-K sums, their reduction and the tail in ONE launch.  A 1024-thread workgroup owns 32 images of one
-// encoder: wave w is K slice w of fc_partial_f16x3_kernel (same fragments, same product order), the 16 partial tiles meet
-// in LDS (128 KB, 16-byte units XOR-swizzled by image so that the accumulator-layout writes and the per-output reads are
-// both conflict-free) and wave w then runs the tail of images 2 w, 2 w + 1 -- the sums in fc_tail_kernel's order, so the
-// features are bit-identical to the two-launch form.  Saves the (nets, 16, N, 64) partial round trip through HBM (a quarter
-// of E's bytes again) and a launch.
-inline bool fc_two_launches() {  // A/B switch of scripts/debug/k4_fc_fused_ab.sh
-  static const bool v = getenv("MMF_K4_FC_TWO_LAUNCHES") && getenv("MMF_K4_FC_TWO_LAUNCHES")[0] == '1';
-  return v;
-}
-constexpr int kFcFusedThreads = 64 * kFcSplit;
-constexpr size_t kFcFusedLds = static_cast<size_t>(kFcSplit) * 32 * kFeat * sizeof(float);
-static_assert(kFcSplit == 16 && kFcFusedLds <= 160 * 1024, "one wave per K slice, all partial tiles in LDS");
-
-__device__ __forceinline__ float fc_res_linear(const float* blob, float h, int lane) {
-  constexpr Layout L = layout();
-  h = fmaxf(h, 0.f);
-  float t = blob[L.r1b + lane];
-#pragma unroll 8
-  for (int k = 0; k < kFeat; ++k) t = __builtin_fmaf(blob[L.r1t + k * kFeat + lane], __shfl(h, k), t);  // explicit chains: strict mode
-  t = fmaxf(t, 0.f);
-  float y = blob[L.r2b + lane] + h;
-#pragma unroll 8
-  for (int k = 0; k < kFeat; ++k) y = __builtin_fmaf(blob[L.r2t + k * kFeat + lane], __shfl(t, k), y);
-  return fmaxf(y, 0.f);
-}
-
-__global__ __launch_bounds__(kFcFusedThreads) void fc_fused_f16x3_kernel(FcArgs a) {
-  constexpr Layout L = layout();
-  constexpr int KSTEPS = kFcK / kFcSplit / 16;  // 32
-  extern __shared__ __attribute__((aligned(16))) float fc_part[];  // [split][image 32][16 units of 4 outputs, swizzled]
-  const int net = blockIdx.y;
-  const int lane = threadIdx.x & 63, split = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int j = lane & 31, h = lane >> 5;
-  const int img0 = blockIdx.x * 32;
-  const int img = min(img0 + j, a.N - 1);
-  const float* X = a.act + (static_cast<size_t>(net) * a.N + img) * kFcK + split * (kFcK / kFcSplit) + 8 * h;
-  const unsigned char* W = reinterpret_cast<const unsigned char*>(a.packed[net] + L.hfc) +
-                           static_cast<size_t>(split) * KSTEPS * 4096 + lane * 16;
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-  float amax = 0.f;
-  // rolling prefetch (the loop is fully unrolled: every buffer index is static): activations four k-steps ahead (HBM), weight
-  // fragments two ahead (L2) -- a wave keeps ~12 KB of requests in flight throughout instead of issuing four k-steps and
-  // draining them
-  f32x4 xb[4][2];
-  half8 wb[2][4];
-  auto load_x = [&](int ks, int b) {
-    xb[b][0] = *reinterpret_cast<const f32x4*>(X + 16 * ks);
-    xb[b][1] = *reinterpret_cast<const f32x4*>(X + 16 * ks + 4);
-  };
-  auto load_w = [&](int ks, int b) {
-    const unsigned char* wp = W + static_cast<size_t>(ks) * 4096;
-#pragma unroll
-    for (int f = 0; f < 4; ++f) wb[b][f] = *reinterpret_cast<const half8*>(wp + 1024 * f);  // tile 0 hi, lo, tile 1 hi, lo
-  };
-  load_x(0, 0);
-  load_w(0, 0);
-  load_x(1, 1);
-  load_w(1, 1);
-  load_x(2, 2);
-  load_x(3, 3);
-#pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks) {
-    const f32x4 x0 = xb[ks & 3][0], x1 = xb[ks & 3][1];
-    const float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-    u32x4 hv, lv;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const float v0 = xv[2 * p], v1 = xv[2 * p + 1];
-      amax = fmaxf(amax, fmaxf(fabsf(v0), fabsf(v1)));
-      const f32x2 xs = {v0, v1};
-      const half2v hh = __builtin_convertvector(xs, half2v);  // round to nearest even
-      const f32x2 hf = {static_cast<float>(hh[0]), static_cast<float>(hh[1])};
-      const f32x2 r = xs - hf;
-      const half2v ll = __builtin_convertvector(r, half2v);
-      hv[p] = __builtin_bit_cast(unsigned, hh);
-      lv[p] = __builtin_bit_cast(unsigned, ll);
-    }
-    if (ks + 4 < KSTEPS) load_x(ks + 4, ks & 3);
-    const half8 bhi = __builtin_bit_cast(half8, hv), blo = __builtin_bit_cast(half8, lv);
-    const half8 a0hi = wb[ks & 1][0], a0lo = wb[ks & 1][1], a1hi = wb[ks & 1][2], a1lo = wb[ks & 1][3];
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0hi, bhi, acc0, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0hi, blo, acc0, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0lo, bhi, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1hi, bhi, acc1, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1hi, blo, acc1, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1lo, bhi, acc1, 0, 0, 0);
-    if (ks + 2 < KSTEPS) load_w(ks + 2, ks & 1);
-    __builtin_amdgcn_sched_barrier(0);  // left alone the scheduler sinks every request to just before its use
-  }
-  if (a.range_flag != nullptr && !(amax < 65504.0f)) atomicOr(a.range_flag, 1);
-  {
-    // lane (image j, h), register r of tile t -> output 32 t + (r & 3) + 8 (r >> 2) + 4 h = unit 8 t + 2 g + h, element r & 3
-    float* p = fc_part + (split * 32 + j) * kFeat;
-    const int sw = j & 15;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 v0 = {acc0[4 * g] * kWInv, acc0[4 * g + 1] * kWInv, acc0[4 * g + 2] * kWInv, acc0[4 * g + 3] * kWInv};
-      const f32x4 v1 = {acc1[4 * g] * kWInv, acc1[4 * g + 1] * kWInv, acc1[4 * g + 2] * kWInv, acc1[4 * g + 3] * kWInv};
-      *reinterpret_cast<f32x4*>(p + 4 * ((2 * g + h) ^ sw)) = v0;
-      *reinterpret_cast<f32x4*>(p + 4 * ((8 + 2 * g + h) ^ sw)) = v1;
-    }
-  }
-  // tail of images 2 w, 2 w + 1: the two chains share every weight (column `lane` of each 64 x 64 matrix, requested as ONE
-  // batch of 64 loads -- the first before the barrier), same operations in the same order as fc_res_linear
-  const float* blob = a.packed[net];
-  auto bcast = [](float v, int k) {  // lane k's value in an SGPR (v_readlane_b32): what __shfl(v, k) returns, without the LDS crossbar
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k));
-  };
-  float w[kFeat];
-#pragma unroll
-  for (int k = 0; k < kFeat; ++k) w[k] = blob[L.r1t + k * kFeat + lane];
-  const float fcb = blob[L.fcb + lane], r1b = blob[L.r1b + lane], r2b = blob[L.r2b + lane];
-  __syncthreads();
-  const int li = 2 * split;  // wave-uniform
-  if (img0 + li >= a.N) return;
-  const bool two = img0 + li + 1 < a.N;
-  float h0 = fcb, h1 = fcb;
-  {
-    const float* p0 = fc_part + li * kFeat + 4 * ((lane >> 2) ^ (li & 15)) + (lane & 3);
-    const float* p1 = fc_part + (li + 1) * kFeat + 4 * ((lane >> 2) ^ ((li + 1) & 15)) + (lane & 3);
-#pragma unroll
-    for (int s = 0; s < kFcSplit; ++s) {
-      h0 += p0[s * 32 * kFeat];
-      h1 += p1[s * 32 * kFeat];
-    }
-  }
-  h0 = fmaxf(h0, 0.f);
-  h1 = fmaxf(h1, 0.f);
-  float t0 = r1b, t1 = r1b;
-#pragma unroll
-  for (int k = 0; k < kFeat; ++k) {
-    t0 = __builtin_fmaf(w[k], bcast(h0, k), t0);
-    t1 = __builtin_fmaf(w[k], bcast(h1, k), t1);
-  }
-#pragma unroll
-  for (int k = 0; k < kFeat; ++k) w[k] = blob[L.r2t + k * kFeat + lane];
-  t0 = fmaxf(t0, 0.f);
-  t1 = fmaxf(t1, 0.f);
-  float y0 = r2b + h0, y1 = r2b + h1;
-#pragma unroll
-  for (int k = 0; k < kFeat; ++k) {
-    y0 = __builtin_fmaf(w[k], bcast(t0, k), y0);
-    y1 = __builtin_fmaf(w[k], bcast(t1, k), y1);
-  }
-  float* o = a.feat + (static_cast<size_t>(net) * a.N + img0 + li) * kFeat + lane;
-  o[0] = fmaxf(y0, 0.f);
-  if (two) o[kFeat] = fmaxf(y1, 0.f);
-}
-
 // one wave per (image, net): bias + ReLU, then ResLinear(64).  SPAN: the linear layer's input is
 // the 64 values of the two spanning average pools over the 2-channel map in `act`
 // (push_models/layers.py:43-65: pool_h = mean over all rows x 2 columns -> [c][16], pool_w = mean
@@ -659,7 +507,15 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcArgs a) {
     for (int s = 0; s < kFcSplit; ++s)
       h += a.partial[((static_cast<size_t>(net) * kFcSplit + s) * a.N + img) * kFeat + lane];
   }
-  a.feat[(static_cast<size_t>(net) * a.N + img) * kFeat + lane] = fc_res_linear(blob, h, lane);
+  h = fmaxf(h, 0.f);
+  float t = blob[L.r1b + lane];
+#pragma unroll 8
+  for (int k = 0; k < kFeat; ++k) t = __builtin_fmaf(blob[L.r1t + k * kFeat + lane], __shfl(h, k), t);  // explicit chains: strict mode
+  t = fmaxf(t, 0.f);
+  float y = blob[L.r2b + lane] + h;
+#pragma unroll 8
+  for (int k = 0; k < kFeat; ++k) y = __builtin_fmaf(blob[L.r2t + k * kFeat + lane], __shfl(t, k), y);
+  a.feat[(static_cast<size_t>(net) * a.N + img) * kFeat + lane] = fmaxf(y, 0.f);
 }
 
 template <int CIN, int COUT, int KS, bool RELU, bool SKIP, bool MASK = false>
@@ -988,21 +844,11 @@ extern "C" int mmf_image_encoder(const float* const* packed, int n_nets, const f
   }
   if (precision == MMF_PREC_F16X3) {
     f.range_flag = range_flag;
-    if (fc_two_launches()) {
-      fc_partial_f16x3_kernel<<<dim3((N + 127) / 128, kFcSplit, n_nets), 256, 0, s>>>(f);
-      MMF_CHECK_LAUNCH();
-    } else {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fc_fused_f16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         static_cast<int>(kFcFusedLds));
-      if (e != hipSuccess) return static_cast<int>(e);
-      fc_fused_f16x3_kernel<<<dim3((N + 31) / 32, n_nets), kFcFusedThreads, kFcFusedLds, s>>>(f);
-      MMF_CHECK_LAUNCH();
-      return 0;
-    }
+    fc_partial_f16x3_kernel<<<dim3((N + 127) / 128, kFcSplit, n_nets), 256, 0, s>>>(f);
   } else {
     fc_partial_kernel<<<dim3((N + 15) / 16, kFcSplit, n_nets), 256, 0, s>>>(f);
-    MMF_CHECK_LAUNCH();
   }
+  MMF_CHECK_LAUNCH();
   fc_tail_kernel<false><<<dim3((N + 3) / 4, n_nets), 256, 0, s>>>(f);
   MMF_CHECK_LAUNCH();
   return 0;

@@ -15,7 +15,7 @@ import shutil
 import sys
 
 OURS = ("particle_net_kernel", "pf_reweight_resample_kernel", "pf_resample_systematic_kernel", "particle_net_train", "small_grads_kernel", "combine_", "dyn_epilogue", "philox_", "ekf_step_kernel", "conv_kernel",
-        "conv_f16x3_kernel", "fc_partial_kernel", "fc_partial_f16x3_kernel", "fc_fused_f16x3_kernel", "fc_tail_kernel", "weight_grad_kernel", "pf_init_particles_kernel", "fuse_sensors_kernel", "traj_program_kernel",
+        "conv_f16x3_kernel", "fc_partial_kernel", "fc_partial_f16x3_kernel", "fc_tail_kernel", "weight_grad_kernel", "pf_init_particles_kernel", "fuse_sensors_kernel", "traj_program_kernel",
         "pack_particle_net_kernel", "pack_encoder_kernel", "image_encoder_resident_kernel", "stem_conv2a_kernel", "conv2b_conv3_kernel", "conv4_kernel",
         "ukf_sigma_points_kernel", "ukf_moments_kernel", "ekf_")
 

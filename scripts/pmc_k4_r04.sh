@@ -17,7 +17,7 @@ cd $R
 python3 - "$P" "$OUT/$TAG.json" <<'PY'
 import collections, csv, glob, json, sys
 src, dst = sys.argv[1:3]
-want = {"resident": "image_encoder_resident_kernel<false>", "conv2b_conv3": "conv2b_conv3_kernel<false, 2, true>", "stem_conv2a": "stem_conv2a_kernel<false>", "fc_partial": "fc_partial_f16x3_kernel", "fc_fused": "fc_fused_f16x3_kernel", "jacobian": "particle_net_kernel<3, 3, 2",
+want = {"resident": "image_encoder_resident_kernel<false>", "conv2b_conv3": "conv2b_conv3_kernel<false, 2, true>", "stem_conv2a": "stem_conv2a_kernel<false>", "fc_partial": "fc_partial_f16x3_kernel", "jacobian": "particle_net_kernel<3, 3, 2",
         "traj_program": "traj_program_kernel"}
 dur = collections.defaultdict(list)
 for f in glob.glob(f"{src}/**/*kernel_trace.csv", recursive=True):
