@@ -410,7 +410,12 @@ def test_persistent_loop_that_gives_up_is_rerun_as_a_loop_of_launches():
     ("PushCrossmodalParticleFilter", 7, 300, 5, "f16x3", "philox"),     # d = 2, counter-based noise
     ("DoorUnimodalParticleFilter", 3, 1000, 4, "f16x3", "tensor"),      # two modalities, no weight model
     ("DoorParticleFilter", 5, 77, 5, "f16x3", "tensor"),                # ONE network; ragged tiles (77 = 2 x 32 + 13)
-    ("DoorCrossmodalParticleFilterSeq5", 6, 2048, 3, "f16x3", "philox"),  # the largest M; blacked-out frames (-inf modality weights)
+    ("DoorCrossmodalParticleFilterSeq5", 6, 2048, 3, "f16x3", "philox"),  # the largest single-chunk M of a 512-thread K1; blacked-out frames (-inf modality weights)
+    # round 6: several rounds of tiles per wave, and K1's 512 threads standing for the launch path's 1024 (two chunks)
+    # (eligible: <= 5 rounds per wave, and >= 24 trajectories once M > 2048 -- csrc/pf_persistent.inc, persistent_plan)
+    ("DoorCrossmodalParticleFilter", 32, 2048, 4, "f16x3", "tensor"),   # four rounds of tiles per wave and step
+    ("DoorCrossmodalParticleFilter", 24, 3000, 3, "f32", "philox"),     # K1: ragged second chunk (768-thread partition), bit-reproducible mode
+    ("PushCrossmodalParticleFilter", 24, 3328, 3, "f16x3", "philox"),   # d = 2; K1: 832-thread partition
 ])
 def test_persistent_step_loop_equals_loop_of_launches(cls, N, M, T, precision, noise):
     """``mmf_pf_forward_loop`` with ``MmfPfLoopArgs.persistent`` (ONE launch for all T steps: role-specialised
