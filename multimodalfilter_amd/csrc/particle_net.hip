@@ -328,23 +328,39 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
   constexpr int TILE = 32 * CT;
   static_assert(!JAC || D <= 3, "jacobian groups are 4 columns: primal + up to 3 tangents");
 
-  // stage this network's fragment-ordered weights in LDS once per workgroup
-  {
-    const float4* src = reinterpret_cast<const float4*>(a.packed);
-    float4* dst = reinterpret_cast<float4*>(lds);
-    mmf::stage_to_lds<blob_floats(NRES) / 4, kThreads>(src, dst, threadIdx.x);
-  }
-  __syncthreads();
-
-  // -1.0f in an SGPR, opaque to the optimiser (see split_pair); the asm emits no instruction
-  float neg_one = -1.0f;
-  asm volatile("" : "+s"(neg_one));
-
+  // stage this network's fragment-ordered weights in LDS once per workgroup.  ASYNC (round 6, the pipelined variant): only the
+  // first-layer / bias / head sections are copied through registers; the 64 x 64 layers (7 or 9 x 16 KB) travel by LDS-DMA
+  // (global_load_lds_dwordx4: no destination registers, 1 KB per wave-instruction, the LDS image is the blob's own order), layers
+  // 0 and 1 are waited for before the first tile, the rest lands UNDER that tile's first layer and a half and is waited
+  // for (one more barrier, in every wave's first tile) before layer 2's fragments are requested.  The copy was 4-7 us of
+  // every launch -- ~4 % of a 256 x 4096 launch, a quarter of a 32 x 4096 one.
+#ifdef MMF_K2_SYNC_STAGING   // scripts/debug/k2_async_staging_ab.sh builds the synchronous copy for the A/B
+  constexpr bool ASYNC_STAGE = false;
+#else
+  constexpr bool ASYNC_STAGE = PIPE && kThreads == 512;
+#endif
+  constexpr int NLAYERS = 3 + 2 * NRES;
   const int lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
   const int wave_global = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
   const int waves_total = gridDim.x * kWavesPerBlock;
   const int ntiles = (a.R + TILE - 1) / TILE;
+  if constexpr (!ASYNC_STAGE) {
+    const float4* src = reinterpret_cast<const float4*>(a.packed);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    mmf::stage_to_lds<blob_floats(NRES) / 4, kThreads>(src, dst, threadIdx.x);
+    __syncthreads();
+  } else {
+    const float4* src = reinterpret_cast<const float4*>(a.packed);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    static_assert(off_layers() % 256 == 0 && off_bias(NRES) % 4 == 0 && blob_floats(NRES) % 4 == 0, "16-byte sections, 1 KB pieces");
+    for (int i = threadIdx.x; i < off_layers() / 4; i += kThreads) dst[i] = src[i];
+    for (int i = off_bias(NRES) / 4 + threadIdx.x; i < blob_floats(NRES) / 4; i += kThreads) dst[i] = src[i];
+  }
+
+  // -1.0f in an SGPR, opaque to the optimiser (see split_pair); the asm emits no instruction
+  float neg_one = -1.0f;
+  asm volatile("" : "+s"(neg_one));
 
   // The inputs of a tile's first layer (the particle states: up to (D+2)/2 floats per lane and
   // column) are requested one tile ahead: a tile opens with a dependent HBM access otherwise
@@ -373,6 +389,45 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
   };
   float bnext[KS0][CT];
   if (wave_global < ntiles) first_layer_inputs(wave_global, bnext);
+  bool layers_pending = false;  // wave-uniform: layers 2 .. of the weights are still on their way
+  __shared__ int s_next_index;  // the tile claims' counter (below)
+  if constexpr (ASYNC_STAGE) {
+    if (threadIdx.x == 0) s_next_index = 2 * kWavesPerBlock;
+    // the first tile's inputs are WAITED FOR here, before the DMAs are issued: the memory counter retires in order, so a
+    // wait for an ordinary load issued after them would be a wait for all of them
+#pragma unroll
+    for (int s = 0; s < KS0; ++s)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) asm volatile("" : "+v"(bnext[s][c]));
+    const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds)) + off_layers() * 4;
+    const unsigned char* gsrc = reinterpret_cast<const unsigned char*>(a.packed + off_layers()) + lane * 16;
+    const int wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int l = 0; l < NLAYERS; ++l)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const unsigned piece = static_cast<unsigned>(l * 16 + wv * 2 + q) * 1024u;   // this wave's 2 KB of layer l
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + piece);
+        const unsigned char* sp = gsrc + piece;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(sp), "s"(dst) : "memory");
+      }
+    // layers 0 and 1 of every wave's share (the counter retires in order: all but the last 2 (NLAYERS - 2) DMAs), and the
+    // register-staged sections
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (NLAYERS - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    layers_pending = true;
+  }
+  auto await_layers = [&]() {  // every wave exactly once: in its first tile, or after the loop if it has none
+    if (layers_pending) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      layers_pending = false;
+    }
+  };
 
   // Tiles of a workgroup are CLAIMED, not dealt: the waves that share a SIMD do not advance at the same rate (the
   // arbiter favours one of two equally old waves), and with a fixed stride the favoured one runs out of tiles while its
@@ -381,11 +436,12 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
   // one ahead (the next tile's first-layer inputs are prefetched).  Which wave computes a tile does not change it.
   // (measured, same box, alternating: headline step 0.5581 -> 0.5542 ms; with one tile per wave -- 32 x 4096 -- there is
   // nothing to claim and the counter is not touched.)
-  __shared__ int s_next_index;
   const bool claims = ntiles > 2 * waves_total;  // wave-uniform
-  if (claims) {
-    if (threadIdx.x == 0) s_next_index = 2 * kWavesPerBlock;
-    __syncthreads();
+  if constexpr (!ASYNC_STAGE) {  // (ASYNC_STAGE: initialised ahead of the barrier that follows the DMAs' issue -- a
+    if (claims) {                //  __syncthreads() here would drain them)
+      if (threadIdx.x == 0) s_next_index = 2 * kWavesPerBlock;
+      __syncthreads();
+    }
   }
   auto tile_of = [&](int i) { return (i / kWavesPerBlock) * waves_total + blockIdx.x * kWavesPerBlock + i % kWavesPerBlock; };
   auto claim = [&](int after) {
@@ -516,6 +572,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
         vstage(I1{}, layer);
         pin_mfma_valu_interleave<5>();
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ASYNC_STAGE && l == 1) await_layers();  // the next stage requests layer 2's fragments
         mstage(I1{}, layer);
         if constexpr (l + 1 < NL) vstage(I0{}, std::integral_constant<int, l + 1>{});
         else relu_half<0>(H);
@@ -694,6 +751,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
     }
     tile = tile_next;
   }
+  if constexpr (ASYNC_STAGE) await_layers();
   K2_WG_STAMP(1);
 }
 
