@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 39
+#define MMF_ABI_VERSION 40
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -853,9 +853,24 @@ typedef struct MmfEkfLoopArgs {
   const int32_t* feedback_gate; /* (T) device words or null: step t writes the fused belief back (feedback) only where
                                 gate[t] != 0 -- the reference's batch-global blackout branch
                                 (door_models/crossmodal_kf.py:59-62) decided on the device, no host read per step  */
+  int32_t persistent;        /* ABI 40. != 0: the whole loop as ONE persistent launch (mmf_ekf_persistent_plan > 0);
+                                mu_pred and A are not touched; same bits as the loop of launches                  */
+  int32_t n_sync_words;      /* 4-byte words of sync_words (>= mmf_ekf_persistent_sync_words(N, K, d))            */
+  uint32_t* sync_words;      /* persistent: device workspace of the in-launch hand-offs between the K sub-filters'
+                                workgroups (tagged 8-byte granules), zeroed by the call; range_flag bit 2 = "a
+                                hand-off timed out: discard this loop and run it as launches"                     */
 } MmfEkfLoopArgs;            /* host struct holding device pointers                            */
 
 int mmf_ekf_forward_loop(const MmfEkfLoopArgs* args /* host */, void* stream);
+
+/* The persistent form of the EKF step loop (MmfEkfLoopArgs.persistent; csrc/ekf_persistent.inc): a wave owns 8
+ * trajectories of ONE sub-filter for all T steps -- belief in registers, the dynamics network's weights in LDS, per step
+ * the forward-mode Jacobian tile and the d x d algebra; K > 1 sub-filters meet once per step and trajectory through L2.
+ * Replaces the 2 T launches of mmf_ekf_forward_loop (crossmodal_kf.py:88-151, unimodal_kf.py:162-250).
+ *   mmf_ekf_persistent_plan: number of workgroups it would use (0: not eligible -- more than two rounds of tiles per wave,
+ *   or a device with too few CUs to keep every workgroup resident).  d must be 2 or 3, n_res_dyn 3. */
+int mmf_ekf_persistent_plan(int N, int K);
+size_t mmf_ekf_persistent_sync_words(int N, int K, int d);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 39
+ABI_VERSION = 40
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16, PREC_F16X3_DUAL = 0, 1, 2, 3
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
@@ -124,7 +124,8 @@ class MmfEkfLoopArgs(Structure):
                 ("dyn_packed", _FP * LOOP_MAX_MEAS), ("dyn_bias", _FP * LOOP_MAX_MEAS),
                 ("q_tril", _FP), ("z", _FP), ("r_tril", _FP), ("fuse_w", _FP),
                 ("mu", _FP), ("Sigma", _FP), ("mu_pred", _FP), ("A", _FP), ("Sigma_f", _FP),
-                ("estimates", _FP), ("feedback_gate", _FP)]
+                ("estimates", _FP), ("feedback_gate", _FP),
+                ("persistent", c_int32), ("n_sync_words", c_int32), ("sync_words", _FP)]
 
 
 class MmfImageEncoderDesc(Structure):
@@ -172,6 +173,8 @@ SIGNATURES = {
     "mmf_fc64_train_backward": (c_int, [_FP, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_void_p]),
     "mmf_fuse_virtual_sensors": (c_int, [_FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_int, c_void_p]),
     "mmf_ekf_forward_loop": (c_int, [POINTER(MmfEkfLoopArgs), c_void_p]),
+    "mmf_ekf_persistent_plan": (c_int, [c_int, c_int]),
+    "mmf_ekf_persistent_sync_words": (c_size_t, [c_int, c_int, c_int]),
     "mmf_dynamics_jacobian_multi": (c_int, [POINTER(c_void_p), c_int, c_int, _FP, POINTER(c_void_p), _FP, _FP, _FP,
                                             c_int, c_int, c_int, c_void_p]),
     "mmf_particle_net_train_forward": (c_int, [_FP, c_int, c_int, _FP, _FP, _FP, _FP, _FP, c_int, c_int, c_int, c_void_p]),
@@ -351,6 +354,15 @@ def pf_persistent_plan(N: int, M: int, n_meas: int) -> int:
 
 def pf_persistent_sync_words(N: int, M: int, d: int, n_meas: int) -> int:
     return int(load().mmf_pf_persistent_sync_words(N, M, d, n_meas))
+
+
+def ekf_persistent_plan(N: int, K: int) -> int:
+    """Workgroups the persistent EKF step loop would use for this problem; <= 0: not eligible (include/mmf.h)."""
+    return int(load().mmf_ekf_persistent_plan(N, K))
+
+
+def ekf_persistent_sync_words(N: int, K: int, d: int) -> int:
+    return int(load().mmf_ekf_persistent_sync_words(N, K, d))
 
 
 def pf_argmax_estimate(loglik, logw_in, states, estimate):

@@ -384,7 +384,7 @@ class _FusedKalmanFilters(base.Filter, _EnabledModels):
         a.mu, a.Sigma, a.mu_pred, a.A, a.Sigma_f, a.estimates = P(mu), P(Sigma), P(mu_pred), P(A), P(Sigma_f), P(est)
         if gate is not None:
             a.feedback_gate = ctypes.c_void_p(_abi.ptr(gate, dtype=torch.int32))
-        _abi.ekf_forward_loop(a, mu)
+        engine.run_ekf_loop(a, mu, Sigma)
         for k, f in enumerate(live):
             f._belief_mean, f._belief_covariance = mu[k], Sigma[k]
         return est, (Sigma_f if fusion else None)

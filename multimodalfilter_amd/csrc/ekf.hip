@@ -8,109 +8,12 @@
 //   /root/reference/crossmodal/base_models/unimodal_kf.py:204-242    (information-form fusion)
 // HBM bytes per trajectory-step (K=2, d=3): 2*(A 36 + mu- 12 + z 12 + T 36 + w 12 + Sigma 36 r/w 72
 // + mu 12) + fused 48 = 432 B for ~1.5 kFLOP: launch-latency-bound in isolation.
-#include "mmf_common.h"
+#include "ekf_algebra.h"
 
 namespace {
 
-template <int D>
-struct Mat {
-  float a[D][D];
-};
+using namespace mmf_ekf;
 
-template <int D>
-__device__ __forceinline__ Mat<D> load_mat(const float* p) {
-  Mat<D> m;
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int j = 0; j < D; ++j) m.a[i][j] = p[i * D + j];
-  return m;
-}
-
-template <int D>
-__device__ __forceinline__ void store_mat(float* p, const Mat<D>& m) {
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int j = 0; j < D; ++j) p[i * D + j] = m.a[i][j];
-}
-
-template <int D>
-__device__ __forceinline__ Mat<D> matmul(const Mat<D>& x, const Mat<D>& y) {
-  Mat<D> r;
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      float s = 0.f;
-#pragma unroll
-      for (int k = 0; k < D; ++k) s += x.a[i][k] * y.a[k][j];
-      r.a[i][j] = s;
-    }
-  return r;
-}
-
-template <int D>
-__device__ __forceinline__ Mat<D> matmul_nt(const Mat<D>& x, const Mat<D>& y) {  // x y^T
-  Mat<D> r;
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      float s = 0.f;
-#pragma unroll
-      for (int k = 0; k < D; ++k) s += x.a[i][k] * y.a[j][k];
-      r.a[i][j] = s;
-    }
-  return r;
-}
-
-// Gauss-Jordan with partial pivoting (the pivot order LU-based torch.inverse uses); row
-// swaps are branch-free selects so every index stays compile-time and the matrix stays in
-// registers.
-template <int D>
-__device__ __forceinline__ Mat<D> inverse(Mat<D> m) {
-  Mat<D> inv;
-#pragma unroll
-  for (int i = 0; i < D; ++i)
-#pragma unroll
-    for (int j = 0; j < D; ++j) inv.a[i][j] = (i == j) ? 1.f : 0.f;
-#pragma unroll
-  for (int c = 0; c < D; ++c) {
-#pragma unroll
-    for (int r = c + 1; r < D; ++r) {
-      const bool sw = fabsf(m.a[r][c]) > fabsf(m.a[c][c]);
-#pragma unroll
-      for (int j = 0; j < D; ++j) {
-        const float t0 = m.a[c][j], t1 = m.a[r][j];
-        m.a[c][j] = sw ? t1 : t0;
-        m.a[r][j] = sw ? t0 : t1;
-        const float u0 = inv.a[c][j], u1 = inv.a[r][j];
-        inv.a[c][j] = sw ? u1 : u0;
-        inv.a[r][j] = sw ? u0 : u1;
-      }
-    }
-    const float piv = 1.0f / m.a[c][c];
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      m.a[c][j] *= piv;
-      inv.a[c][j] *= piv;
-    }
-#pragma unroll
-    for (int r = 0; r < D; ++r) {
-      if (r == c) continue;
-      const float f = m.a[r][c];
-#pragma unroll
-      for (int j = 0; j < D; ++j) {
-        m.a[r][j] -= f * m.a[c][j];
-        inv.a[r][j] -= f * inv.a[c][j];
-      }
-    }
-  }
-  return inv;
-}
-
-constexpr int kMaxK = 4;
 
 template <int D>
 __global__ __launch_bounds__(256) void ekf_step_kernel(
@@ -124,7 +27,7 @@ __global__ __launch_bounds__(256) void ekf_step_kernel(
   // frame in the batch -> the branch that skips the write-back) as a device word: no host round trip per step
   if (feedback_gate != nullptr && *feedback_gate == 0) feedback = 0;
 
-  float mus[kMaxK][D];
+  float mus[kMaxK][D], w[kMaxK][D];
   Mat<D> Ss[kMaxK];
 #pragma unroll
   for (int k = 0; k < kMaxK; ++k) {
@@ -134,116 +37,22 @@ __global__ __launch_bounds__(256) void ekf_step_kernel(
     const Mat<D> S0 = load_mat<D>(Sigma + row * D * D);
     const Mat<D> L = load_mat<D>(q_tril + static_cast<size_t>(k) * D * D);
     const Mat<D> T = load_mat<D>(r_tril + row * D * D);
-    // predict: S- = A S A^T + L L^T
-    const Mat<D> AS = matmul<D>(Ak, S0);
-    Mat<D> Sp = matmul_nt<D>(AS, Ak);
-    const Mat<D> Q = matmul_nt<D>(L, L);
-    const Mat<D> Rm = matmul_nt<D>(T, T);
-    Mat<D> Sinn;
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-      for (int j = 0; j < D; ++j) {
-        Sp.a[i][j] += Q.a[i][j];
-        Sinn.a[i][j] = Sp.a[i][j] + Rm.a[i][j];
-      }
-    // correct (C = I): K = S- (S- + R)^-1; mu = mu- + K (z - mu-); S = (I - K) S-
-    const Mat<D> G = matmul<D>(Sp, inverse<D>(Sinn));
-    float mp[D], innov[D];
+    float mp[D], zk[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       mp[i] = mu_pred[row * D + i];
-      innov[i] = z[row * D + i] - mp[i];
+      zk[i] = z[row * D + i];
     }
-    Mat<D> ImG;
+    predict_correct<D>(Ak, S0, L, T, mp, zk, mus[k], Ss[k]);
+    if (fusion == 1) {
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < D; ++j) {
-        s += G.a[i][j] * innov[j];
-        ImG.a[i][j] = ((i == j) ? 1.f : 0.f) - G.a[i][j];
-      }
-      mus[k][i] = mp[i] + s;
+      for (int i = 0; i < D; ++i) w[k][i] = fuse_w[row * D + i];
     }
-    Ss[k] = matmul<D>(ImG, Sp);
   }
 
   float mf[D];
   Mat<D> Sf;
-  if (fusion == 1) {
-    // mu_f = sum_k (w_k / (sum_k w_k + 1e-9)) mu_k ; Sigma_f = sum_k (w_k w_k^T) (.) Sigma_k
-    float w[kMaxK][D], wsum[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) wsum[i] = 0.f;
-#pragma unroll
-    for (int k = 0; k < kMaxK; ++k) {
-      if (k >= K) break;
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
-        w[k][i] = fuse_w[(static_cast<size_t>(k) * N + n) * D + i];
-        wsum[i] += w[k][i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-      mf[i] = 0.f;
-#pragma unroll
-      for (int j = 0; j < D; ++j) Sf.a[i][j] = 0.f;
-    }
-#pragma unroll
-    for (int k = 0; k < kMaxK; ++k) {
-      if (k >= K) break;
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
-        mf[i] += (w[k][i] / (wsum[i] + 1e-9f)) * mus[k][i];
-#pragma unroll
-        for (int j = 0; j < D; ++j) Sf.a[i][j] += (w[k][i] * w[k][j]) * Ss[k].a[i][j];
-      }
-    }
-  } else if (fusion == 2) {
-    // P_k = (Sigma_k + 1e-9)^-1 ; Sigma_f = (sum_k P_k + 1e-9)^-1 ; mu_f = Sigma_f sum_k P_k mu_k
-    Mat<D> Psum;
-    float info[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-      info[i] = 0.f;
-#pragma unroll
-      for (int j = 0; j < D; ++j) Psum.a[i][j] = 0.f;
-    }
-#pragma unroll
-    for (int k = 0; k < kMaxK; ++k) {
-      if (k >= K) break;
-      Mat<D> t = Ss[k];
-#pragma unroll
-      for (int i = 0; i < D; ++i)
-#pragma unroll
-        for (int j = 0; j < D; ++j) t.a[i][j] += 1e-9f;
-      const Mat<D> P = inverse<D>(t);
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-          s += P.a[i][j] * mus[k][j];
-          Psum.a[i][j] += P.a[i][j];
-        }
-        info[i] += s;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-      for (int j = 0; j < D; ++j) Psum.a[i][j] += 1e-9f;
-    Sf = inverse<D>(Psum);
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < D; ++j) s += Sf.a[i][j] * info[j];
-      mf[i] = s;
-    }
-  }
+  fuse<D>(K, fusion, w, mus, Ss, mf, Sf);
 
   if (fusion != 0) {
 #pragma unroll

@@ -17,6 +17,11 @@ extern "C" int mmf_ekf_forward_loop(const MmfEkfLoopArgs* a, void* stream) {
   if (a->fusion != 0 && (!a->Sigma_f)) return MMF_EINVAL;
   for (int k = 0; k < a->K; ++k)
     if (!a->dyn_packed[k] || !a->dyn_bias[k]) return MMF_EINVAL;
+  if (a->persistent && a->T > 0) {  // ONE launch for all T steps (ekf_persistent.inc); same bits
+    const int rc = mmf_internal_ekf_persistent(a, stream);
+    if (rc != MMF_INTERNAL_NOT_RESIDENT) return rc;
+    // this device cannot hold the persistent grid, or the problem is not eligible: the loop of launches
+  }
   const size_t N = static_cast<size_t>(a->N), d = static_cast<size_t>(a->d), K = static_cast<size_t>(a->K);
   hipStream_t hs = static_cast<hipStream_t>(stream);
   for (int t = 0; t < a->T; ++t) {

@@ -16,6 +16,7 @@
 // the persistent small-problem step loop (pf_persistent.inc, compiled with particle_net.hip); reached through
 // mmf_pf_forward_loop when MmfPfLoopArgs.persistent is set
 int mmf_internal_pf_persistent(const MmfPfLoopArgs* args, void* stream);
+int mmf_internal_ekf_persistent(const MmfEkfLoopArgs* args, void* stream);  /* ekf_persistent.inc */
 #define MMF_INTERNAL_NOT_RESIDENT (-1000)  /* its grid would not be co-resident on this device: take the launch path */
 
 // the exact-fp32 three-pass backward of the native training recursion over f16 recompute buffers (particle_net_train.inc)

@@ -738,12 +738,12 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
         if (role == 0) {
 #pragma unroll
           for (int i = 0; i < D; ++i)
-            a.states_out[traj * D + i] = a.states_in[traj * D + i] + dirp[i] * sg;
+            a.states_out[traj * D + i] = jac_primal(a.states_in[traj * D + i], dirp[i], sg);
         } else if (role <= D) {
           const float dgate = mine[D];  // tangent columns carry no bias
 #pragma unroll
           for (int i = 0; i < D; ++i) {
-            const float dv = mine[i] * sg + dirp[i] * (sg * (1.0f - sg)) * dgate + ((i == role - 1) ? 1.f : 0.f);
+            const float dv = jac_tangent(mine[i], sg, dirp[i], dgate, (i == role - 1) ? 1.f : 0.f);
             a.jac[(static_cast<size_t>(traj) * D + i) * D + (role - 1)] = dv;
           }
         }
@@ -987,3 +987,4 @@ extern "C" int mmf_dynamics_jacobian_multi(const float* const* packed, int n_res
 
 #include "particle_net_train.inc"
 #include "pf_persistent.inc"
+#include "ekf_persistent.inc"

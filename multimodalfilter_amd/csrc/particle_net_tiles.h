@@ -68,6 +68,19 @@ __device__ __forceinline__ float quad_first(float x) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x00, 0xf, 0xf, true));
 }
 
+// The epilogue of a Jacobian column group, spelled out (explicit fused multiply-adds, no implicit contraction): the launch
+// kernel and the persistent EKF loop (ekf_persistent.inc) must produce the same bits whatever surrounds these statements.
+// x' = x + dir sigmoid(gate);  d x'_i / d x_c = d dir_i s + dir_i s (1 - s) d gate + [i == c]
+__device__ __forceinline__ float jac_primal(float x, float dir, float sg) {
+#pragma clang fp contract(off)
+  return __builtin_fmaf(dir, sg, x);
+}
+__device__ __forceinline__ float jac_tangent(float ddir, float sg, float dir, float dgate, float delta) {
+#pragma clang fp contract(off)
+  const float u = (dir * (sg * (1.0f - sg))) * dgate;
+  return __builtin_fmaf(ddir, sg, u) + delta;
+}
+
 template <int CT>
 __device__ __forceinline__ void mfma_layer(const float* __restrict__ Wl, const Act<CT>& in,
                                            Act<CT>& acc, int lane) {

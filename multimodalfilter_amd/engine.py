@@ -148,6 +148,9 @@ def training_image_precision_code() -> int:
 # launch per forward_loop: role-specialised workgroups keep one network's weights in LDS for all T steps and hand the
 # particles over through L2 (csrc/pf_persistent.inc); bit-identical to the launch-per-step loop.  "0": A/B, off.
 PF_PERSISTENT = os.environ.get("MMF_PF_PERSISTENT", "1") not in ("", "0")
+# The EKF step loop likewise (mmf_ekf_persistent_plan > 0; csrc/ekf_persistent.inc): a wave owns 8 trajectories of one
+# sub-filter for all T steps, K > 1 sub-filters meet once per step through L2; bit-identical to the 2 T launches.
+EKF_PERSISTENT = os.environ.get("MMF_EKF_PERSISTENT", "1") not in ("", "0")
 
 
 # Training is opt-in: nothing switches paths silently, and eval() always means the forward-only HIP
@@ -198,7 +201,7 @@ def persistent_loop_gave_up(device) -> bool:
     out because a workgroup of the launch was not resident, e.g. another process shares the GPU)?  Clears the bit,
     switches the persistent form off for the rest of the process and warns once; the caller re-runs the loop as a
     loop of launches.  One 4-byte device->host read."""
-    global PF_PERSISTENT, _PERSISTENT_WARNED
+    global PF_PERSISTENT, EKF_PERSISTENT, _PERSISTENT_WARNED
     flag = _RANGE_FLAGS.get(str(device))
     if flag is None:
         return False
@@ -206,14 +209,38 @@ def persistent_loop_gave_up(device) -> bool:
     if not bits & 4:
         return False
     flag.bitwise_and_(~4)
-    PF_PERSISTENT = False
+    PF_PERSISTENT = EKF_PERSISTENT = False
     if not _PERSISTENT_WARNED:
         _PERSISTENT_WARNED = True
         import warnings
-        warnings.warn("the persistent particle-filter loop gave up waiting for a hand-off (a workgroup of its launch was not "
+        warnings.warn("a persistent filter loop gave up waiting for a hand-off (a workgroup of its launch was not "
                       "resident -- is another process using this GPU?); this forward_loop is re-run as a loop of launches and the "
-                      "persistent form is switched off for this process (MMF_PF_PERSISTENT=0 does so from the start)")
+                      "persistent forms are switched off for this process (MMF_PF_PERSISTENT=0 MMF_EKF_PERSISTENT=0 do so from the start)")
     return True
+
+
+def run_ekf_loop(a, mu: torch.Tensor, Sigma: torch.Tensor):
+    """``mmf_ekf_forward_loop`` on filled ``MmfEkfLoopArgs`` (``mu`` / ``Sigma``: its in / out belief tensors): as ONE
+    persistent launch where the problem is eligible (``EKF_PERSISTENT``), with the loop of launches as the fallback if a
+    hand-off of that launch timed out (the belief is restored first)."""
+    import ctypes
+
+    dev = mu.device
+    keep = None
+    if (EKF_PERSISTENT and not CAPTURING and a.T > 0 and a.d in (2, 3) and a.n_res_dyn == 3
+            and _abi.ekf_persistent_plan(a.N, a.K) > 0):
+        n_words = _abi.ekf_persistent_sync_words(a.N, a.K, a.d)
+        sync = torch.empty(n_words, dtype=torch.int32, device=dev)  # tagged granules of the hand-offs (zeroed by the call)
+        keep = (sync, mu.clone(), Sigma.clone())
+        a.persistent, a.n_sync_words = 1, n_words
+        a.sync_words = ctypes.c_void_p(_abi.ptr(sync, dtype=torch.int32))
+        a.range_flag = ctypes.c_void_p(_abi.ptr(range_flag(dev), dtype=torch.int32))  # bit 2: "a hand-off timed out"
+    _abi.ekf_forward_loop(a, mu)
+    if a.persistent and a.K > 1 and persistent_loop_gave_up(dev):
+        mu.copy_(keep[1])
+        Sigma.copy_(keep[2])
+        a.persistent = 0
+        _abi.ekf_forward_loop(a, mu)
 
 
 # While a training step is being captured into a hipGraph (train.GraphedFilterStep) nothing may read the device: the checks

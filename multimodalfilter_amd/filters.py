@@ -609,7 +609,7 @@ class VirtualSensorExtendedKalmanFilter(base.Filter):
         a.dyn_packed[0], a.dyn_bias[0] = P(blob), P(ctrl_all["bias"])
         a.q_tril, a.z, a.r_tril = P(q), P(z), P(r)
         a.mu, a.Sigma, a.mu_pred, a.A, a.estimates = P(mu), P(Sigma), P(mu_pred), P(A), P(est)
-        _abi.ekf_forward_loop(a, mu)
+        engine.run_ekf_loop(a, mu, Sigma)
         self._belief_mean, self._belief_covariance = mu[0], Sigma[0]
         return est
 

@@ -541,6 +541,73 @@ def test_native_ekf_loop_equals_stepwise(cls, kw, masked):
         assert torch.equal(f.weighted_covariances, wc)
 
 
+@pytest.mark.parametrize("cls,kw,N,T,precision", [
+    ("DoorCrossmodalKalmanFilter", {}, 37, 6, "f16x3"),                                   # K = 2, ragged last tile (37 = 4 x 8 + 5)
+    ("DoorCrossmodalKalmanFilter", {"know_image_blackout": True, "feedback": "belief"}, 1027, 5, "f16x3"),  # many workgroups per role; the gate
+    ("DoorCrossmodalKalmanFilter", {"feedback": "belief", "fix_weight_layout": True}, 64, 4, "f32"),        # the bit-reproducible mode
+    ("PushCrossmodalKalmanFilter", {}, 200, 4, "f16x3"),                                  # d = 2
+    ("DoorUnimodalKalmanFilter", {}, 32, 7, "f16x3"),                                     # BASELINE config 1's shape: information-form fusion
+    ("DoorKalmanFilter", {}, 100, 5, "f16x3"),                                            # K = 1, no fusion, no hand-offs
+    ("DoorCrossmodalKalmanFilter", {}, 4096 + 5, 3, "f16x3"),                             # two tiles per wave, one after the other
+])
+def test_persistent_ekf_loop_equals_loop_of_launches(cls, kw, N, T, precision):
+    """``mmf_ekf_forward_loop`` with ``MmfEkfLoopArgs.persistent`` (ONE launch for all T steps: a wave owns 8 trajectories
+    of one sub-filter, the sub-filters' workgroups meet once per step through L2 -- csrc/ekf_persistent.inc) against the
+    same loop as 2 T launches: estimates, every sub-filter's belief and the fused covariance are identical BITS, twice in a
+    row (the hand-off words are re-initialised per call)."""
+    _need_gpu()
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import _abi, engine
+
+    dev = torch.device("cuda:0")
+    tname = "door" if cls.startswith("Door") else "push"
+    d = om.TASKS[tname].state_dim
+    old_prec, old_persist = engine.DEFAULT_PRECISION, engine.EKF_PERSISTENT
+    engine.set_default_precision(precision)
+    try:
+        torch.manual_seed(5)
+        g = torch.Generator().manual_seed(41)
+        obs = {"image": (torch.randn((T, N, 32, 32), generator=g) * 0.5).clamp(-1, 1).to(dev),
+               "gripper_pos": torch.randn((T, N, 3), generator=g).to(dev),
+               "gripper_sensors": torch.randn((T, N, 7), generator=g).to(dev)}
+        ctrl = torch.randn((T, N, 7), generator=g).to(dev)
+        x0 = torch.randn((N, d), generator=g).to(dev)
+        cov = (torch.eye(d) * 0.1)[None].expand(N, d, d).to(dev)
+        if kw.get("know_image_blackout"):
+            obs["image"][1, 2] = 0.0
+            obs["image"][3, N - 1] = 0.0
+        f = mmf.model_types(tname)[cls](**kw).to(dev).eval()
+
+        def run(persistent):
+            engine.EKF_PERSISTENT = persistent
+            taken = []
+            real = _abi.ekf_forward_loop
+            _abi.ekf_forward_loop = lambda a, *r, **k: (taken.append(int(a.persistent)), real(a, *r, **k))[1]
+            try:
+                f.initialize_beliefs(mean=x0, covariance=cov)
+                a = f.forward_loop(observations=obs, controls=ctrl)
+                b = f.forward_loop(observations={k: v[:2] for k, v in obs.items()}, controls=ctrl[:2])  # again, from the belief it left
+                subs = list(f.filter_models) if hasattr(f, "filter_models") else [f]
+                beliefs = [(m._belief_mean.clone(), m._belief_covariance.clone()) for m in subs if m._initialized]
+                wc = getattr(f, "weighted_covariances", None)
+                return taken, a, b, beliefs, (None if wc is None else wc.clone())
+            finally:
+                _abi.ekf_forward_loop = real
+
+        ref = run(False)
+        got = run(True)
+        assert ref[0] == [0, 0] and got[0] == [1, 1], (ref[0], got[0])
+        assert torch.equal(ref[1], got[1]) and torch.equal(ref[2], got[2])
+        assert bool(torch.isfinite(got[1]).all())
+        for (m0, s0), (m1, s1) in zip(ref[3], got[3]):
+            assert torch.equal(m0, m1) and torch.equal(s0, s1)
+        if ref[4] is not None:
+            assert torch.equal(ref[4], got[4])
+    finally:
+        engine.set_default_precision(old_prec)
+        engine.EKF_PERSISTENT = old_persist
+
+
 @pytest.mark.parametrize("tname", ["door", "push"])
 def test_dynamics_forward_loop_native_rollout(tname):
     """``DynamicsModel.forward_loop`` (``/root/reference/crossmodal/eval_helpers.py:135-137``): the native

@@ -40,7 +40,9 @@ def test_stacked_noise_checks_shapes():
 def test_loop_argument_structs_match_the_header():
     """Field order / sizes of the host structs handed to the native step loops."""
     P, I = ctypes.sizeof(ctypes.c_void_p), 4
-    assert ctypes.sizeof(_abi.MmfEkfLoopArgs) == 8 * I + (2 * _abi.LOOP_MAX_MEAS + 12) * P  # + feedback_gate (ABI 33)
+    # + feedback_gate (ABI 33); + persistent, n_sync_words (two int32 = one pointer slot), sync_words (ABI 40)
+    assert ctypes.sizeof(_abi.MmfEkfLoopArgs) == 8 * I + (2 * _abi.LOOP_MAX_MEAS + 12) * P + 2 * I + P
+    assert _abi.MmfEkfLoopArgs.sync_words.offset == _abi.MmfEkfLoopArgs.persistent.offset + 2 * I
     pf = _abi.MmfPfLoopArgs
     assert pf.T.offset == 0 and pf.dyn_packed.offset == 10 * I
     assert pf.event_stride.offset + I <= ctypes.sizeof(pf)
