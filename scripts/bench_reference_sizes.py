@@ -63,6 +63,43 @@ def eval_regime(args, dev):
     return out
 
 
+def eval_ekf_regime(args, dev, cls):
+    """The extended Kalman filters at the reference's evaluation size (BASELINE config 1: 32 trajectories; sequences of
+    hundreds of steps, eval_helpers.py:139-142): whole ``forward_loop`` per step, the recursion as ONE persistent launch
+    (csrc/ekf_persistent.inc) against two launches per step."""
+    import bench
+    import multimodalfilter_amd as mmf
+    from multimodalfilter_amd import engine, synthetic
+
+    N, T, d = 32, args.eval_steps, 3
+    torch.manual_seed(0)
+    f = mmf.model_types("door")[cls]().to(dev).eval()
+    traj = bench.to_device(synthetic.make_trajectories(state_dim=d, T=T + 1, N=N, seed=5), dev)
+    obs = {k: traj[k][1:] for k in ("image", "gripper_pos", "gripper_sensors")}
+    cov = (torch.eye(d, device=dev) * 0.1)[None].expand(N, d, d)
+    out = {"regime": "eval_ekf", "filter": cls, "batch": N, "steps": T}
+    old = engine.EKF_PERSISTENT
+    try:
+        for persistent in (True, False):
+            engine.EKF_PERSISTENT = persistent
+            times = []
+            for it in range(args.eval_repeats + 1):
+                f.initialize_beliefs(mean=traj["states"][0], covariance=cov)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                est = f.forward_loop(observations=obs, controls=traj["controls"][1:])
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            key = "persistent" if persistent else "two_launches_per_step"
+            out[key] = {"ms_per_step": 1e3 * min(times[1:]) / T, "trajectory_steps_per_s": N * T / min(times[1:])}
+            out.setdefault("estimates", est.clone())
+            out["same_bits"] = bool(torch.equal(out["estimates"], est))
+    finally:
+        engine.EKF_PERSISTENT = old
+    del out["estimates"]
+    return out
+
+
 def train_regime(args, dev, backend):
     import multimodalfilter_amd as mmf
     from multimodalfilter_amd import engine, synthetic, train
@@ -144,12 +181,15 @@ def main():
     ap.add_argument("--eval-repeats", type=int, default=3)
     ap.add_argument("--train-iters", type=int, default=10)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--only", default="eval,train")
+    ap.add_argument("--only", default="eval,ekf,train")
     ap.add_argument("--backends", default="hip,autograd")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if "eval" in args.only:
         print(json.dumps(eval_regime(args, dev)), flush=True)
+    if "ekf" in args.only:
+        for cls in ("DoorCrossmodalKalmanFilter", "DoorUnimodalKalmanFilter", "DoorKalmanFilter"):
+            print(json.dumps(eval_ekf_regime(args, dev, cls)), flush=True)
     if "train" in args.only:
         for backend in args.backends.split(","):
             print(json.dumps(train_regime(args, dev, backend)), flush=True)
