@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MMF_ABI_VERSION 41
+#define MMF_ABI_VERSION 40
 
 #define MMF_EINVAL (-1)      /* bad argument (null pointer, d out of range, ...) */
 #define MMF_ETOOLARGE (-2)   /* size beyond what the kernel supports (see each call) */
@@ -431,13 +431,6 @@ typedef struct MmfPfLoopArgs {
   int32_t n_sync_words;      /* 4-byte words of sync_words (>= mmf_pf_persistent_sync_words(N, M, d, n_meas))              */
   uint32_t* sync_words;      /* persistent: device workspace of the in-launch hand-offs -- tagged 8-byte granules of the   */
                              /* particle rows and log-likelihoods --, zeroed by the call; an allocation of its own         */
-  int32_t fuse_k1;           /* ABI 41. != 0 (plain systematic resampling, weighted-average estimates): K1 runs in the TAIL  */
-                             /* of each step's last measurement launch -- tiles count themselves on their trajectory's      */
-                             /* counter, a workgroup that has run out of tiles resamples trajectories in the LDS the        */
-                             /* weights no longer need -- where the launch is eligible (M a multiple of the tile, <= 4096;  */
-                             /* every workgroup resident); same bits; steps timed through `events` keep two launches        */
-  int32_t reserved0;
-  uint32_t* k1_counters;     /* fuse_k1: (N) device words, ZERO on entry (monotonic tile counts of the loop)                */
 } MmfPfLoopArgs;             /* host struct holding device pointers                           */
 
 int mmf_pf_forward_loop(const MmfPfLoopArgs* args /* host */, void* stream);

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MMF_LIB_PATH") or os.path.join(_HERE, "libmmf_hip.so"
 MMF_UNITS = 64
 MMF_MAX_RES = 3
 MMF_MAX_STATE_DIM = 4
-ABI_VERSION = 41
+ABI_VERSION = 40
 KIND_DYNAMICS, KIND_MEASURE, KIND_JACOBIAN = 0, 1, 2  # particle-network kinds (csrc/particle_net.hip)
 PREC_F32, PREC_F16X3, PREC_BF16, PREC_F16X3_DUAL = 0, 1, 2, 3
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}                          # per-particle networks (K2)
@@ -88,8 +88,7 @@ class MmfPfLoopArgs(Structure):
                 ("noise_seed", ctypes.c_uint64), ("noise_step0", ctypes.c_uint32), ("noise_traj0", ctypes.c_uint32),
                 ("noise_mode", c_int32),
                 ("soft_alpha", ctypes.c_float), ("estimate_argmax", c_int32), ("estimate_scratch", _FP),
-                ("persistent", c_int32), ("n_sync_words", c_int32), ("sync_words", _FP),
-                ("fuse_k1", c_int32), ("reserved0", c_int32), ("k1_counters", _FP)]
+                ("persistent", c_int32), ("n_sync_words", c_int32), ("sync_words", _FP)]
 
 
 class MmfTrainNet(Structure):

@@ -17,13 +17,6 @@
 // mmf_pf_forward_loop when MmfPfLoopArgs.persistent is set
 int mmf_internal_pf_persistent(const MmfPfLoopArgs* args, void* stream);
 int mmf_internal_ekf_persistent(const MmfEkfLoopArgs* args, void* stream);  /* ekf_persistent.inc */
-/* mmf_pf_measure with K1 (plain systematic resampling of the same step) in the launch's tail (particle_net.hip, K1Tail);
-   MMF_INTERNAL_NOT_RESIDENT: not eligible here -- launch the two separately */
-int mmf_internal_pf_measure_k1(const float* packed, int n_res, int precision, const float* states, const float* traj_bias,
-                               const float* modality_logw, int logw_stride, float* loglik, int combine, int* range_flag,
-                               int N, int M, int d, const float* logw_in, const float* u, float* estimate, float* states_out,
-                               float* logw_out, int32_t* indices_out, unsigned* counters, unsigned launch_index /* fused launches of this loop so far */,
-                               void* stream);
 #define MMF_INTERNAL_NOT_RESIDENT (-1000)  /* its grid would not be co-resident on this device: take the launch path */
 
 // the exact-fp32 three-pass backward of the native training recursion over f16 recompute buffers (particle_net_train.inc)

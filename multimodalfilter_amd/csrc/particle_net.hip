@@ -34,7 +34,6 @@
 #include "../../include/mmf_philox.h"
 
 #include "particle_net_tiles.h"
-#include "pf_resample_systematic.inc"  // K1's body: the measurement kernel can run it in its tail (K1Tail)
 
 namespace {
 
@@ -311,29 +310,8 @@ __device__ int g_k2_xcc[512];
 
 // blockIdx.y selects one of up to MMF_LOOP_MAX_MEAS independent problems of the same shape (the
 // sub-filters of a fused EKF evaluate their Jacobians in one launch).
-// Round 6: K1 in the TAIL of the step's last measurement launch (pf_loop.hip, MmfPfLoopArgs.fuse_k1).  Every tile announces
-// itself on its trajectory's counter once its log-likelihoods are written; when a workgroup has run out of tiles it takes
-// trajectories blockIdx.x, blockIdx.x + gridDim.x, .. , waits for their counters (all workgroups of the grid are resident:
-// one per CU, grid <= CUs -- checked by the launcher; the wait is bounded all the same) and runs
-// mmf::resample_systematic_trajectory in the LDS the weights no longer need: the launch of K1, its queue gap and its
-// first dependent loads are gone.  512 threads reproduce the 1024-thread partition of the float sums (`virt`), so the
-// bits are those of pf_resample_systematic_kernel.
-struct K1Tail {
-  int enabled, N;
-  const float* logw_in;    // (N, M) or null (uniform)
-  const float* u;          // (N)
-  float* estimate;         // (N, D)
-  float* states_out;       // (N, M, D)
-  float* logw_out;         // (N, M) or null
-  int32_t* indices_out;    // (N, M) or null
-  unsigned* counters;      // (N) monotonic: tiles of the trajectory delivered since the loop began
-  unsigned expect;         // the value every counter reaches with this launch
-  float lw_uniform, log_uniform;
-};
-
 struct NetArgsMulti {
   NetArgs a[MMF_LOOP_MAX_MEAS];
-  K1Tail k1;
 };
 
 template <int D, int NRES, int KIND, int CT, int PREC, int WPS, bool PIPE = false>
@@ -474,15 +452,6 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
   };
   int i_next = (threadIdx.x >> 6) + kWavesPerBlock;  // the second round is still dealt: its inputs are requested below
 
-  const bool k1_tail = KIND == kMeasure && multi.k1.enabled != 0;  // grid-uniform
-  int k1_pending = -1;
-  // A tile's log-likelihoods leave as agent-scope WRITE-THROUGH stores (below); once they are acknowledged (vmcnt) the count
-  // may follow -- no fence: a release fence at agent scope writes the XCD's L2 back and invalidates the CU's L1, per tile
-  // (measured: the step 40 % longer, profiles/r06/bench_pf_onelaunch_ab.txt)
-  auto k1_announce = [&](int traj) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(multi.k1.counters + traj, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
   for (int tile = wave_global; tile < ntiles;) {
     const int tile_next = tile_of(i_next);
     const int base = tile * TILE;
@@ -710,11 +679,6 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
     const float* bh = lds + off_bhead(NRES);
 
     if (KIND == kMeasure) {
-      if (k1_tail) {
-        // the PREVIOUS tile's stores have long landed: its announcement costs no wait here, ahead of this tile's stores
-        if (k1_pending >= 0) k1_announce(k1_pending);
-        k1_pending = base / a.M;  // (the launcher checked M % TILE == 0: a tile lies in one trajectory)
-      }
       if (active) {
         const int traj = my_row / a.M;
         float ll = mine[0] + bh[0];
@@ -729,8 +693,7 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
             ll = (m == -INFINITY) ? m : m + logf(expf(prev - m) + expf(ll - m));
           }
         }
-        if (k1_tail) __hip_atomic_store(a.loglik + my_row, ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else a.loglik[my_row] = ll;
+        a.loglik[my_row] = ll;
       }
     } else if (KIND == kDynamics) {
       if (active) {
@@ -789,41 +752,6 @@ __global__ __launch_bounds__(WPS * 256, WPS) void particle_net_kernel(NetArgsMul
     tile = tile_next;
   }
   if constexpr (ASYNC_STAGE) await_layers();
-  if constexpr (KIND == kMeasure && D <= 3) {
-    if (k1_tail) {
-      const K1Tail& k1 = multi.k1;
-      if (k1_pending >= 0) k1_announce(k1_pending);
-      __shared__ int s_k1_gave_up;
-      if (threadIdx.x == 0) s_k1_gave_up = 0;
-      __syncthreads();  // every wave of this workgroup is done with the weights: their LDS is K1's now
-      for (int n = blockIdx.x; n < k1.N; n += gridDim.x) {
-        if (threadIdx.x == 0) {
-          unsigned spins = 0;
-          while (__hip_atomic_load(k1.counters + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k1.expect) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 16)) { s_k1_gave_up = 1; break; }  // ~30 ms: a workgroup of this grid is not running
-          }
-        }
-        __syncthreads();
-        if (s_k1_gave_up) {  // workgroup-uniform: the host discards the loop and re-runs it with K1 as its own launch
-          if (threadIdx.x == 0 && a.range_flag != nullptr) atomicOr(a.range_flag, 4);
-          return;
-        }
-        mmf::K1Trajectory tr{};
-        tr.ll[0] = a.loglik + static_cast<size_t>(n) * a.M;
-        tr.n_ll = 1;
-        tr.lw = k1.logw_in ? k1.logw_in + static_cast<size_t>(n) * a.M : nullptr;
-        tr.xs = a.states_in + static_cast<size_t>(n) * a.M * D;
-        tr.u = k1.u[n];
-        tr.estimate = k1.estimate + static_cast<size_t>(n) * D;
-        tr.so = k1.states_out + static_cast<size_t>(n) * a.M * D;
-        tr.lo = k1.logw_out ? k1.logw_out + static_cast<size_t>(n) * a.M : nullptr;
-        tr.io = k1.indices_out ? k1.indices_out + static_cast<size_t>(n) * a.M : nullptr;
-        mmf::resample_systematic_trajectory<D, true, false, false, true>(reinterpret_cast<unsigned char*>(lds), tr, a.M, a.M, k1.lw_uniform, k1.log_uniform);
-        __syncthreads();  // the LDS of this trajectory is free again
-      }
-    }
-  }
   K2_WG_STAMP(1);
 }
 
@@ -1001,47 +929,6 @@ extern "C" int mmf_pf_measure(const float* packed, int n_res, int precision, con
   a.logw_stride = logw_stride; a.loglik = loglik; a.combine = combine; a.R = N * M; a.M = M;
   a.range_flag = range_flag;
   return launch<kMeasure>(a, d, n_res, precision, static_cast<hipStream_t>(stream));
-}
-
-int mmf_internal_pf_measure_k1(const float* packed, int n_res, int precision, const float* states, const float* traj_bias,
-                               const float* modality_logw, int logw_stride, float* loglik, int combine, int* range_flag,
-                               int N, int M, int d, const float* logw_in, const float* u, float* estimate, float* states_out,
-                               float* logw_out, int32_t* indices_out, unsigned* counters, unsigned launch_index, void* stream) {
-  if (!packed || !states || !traj_bias || !loglik || !u || !estimate || !states_out || !counters) return MMF_EINVAL;
-  if (N < 1 || M < 1) return MMF_EINVAL;
-  if (static_cast<long long>(N) * M > 0x7fffffffLL / 8) return MMF_ETOOLARGE;
-  // eligibility: a tile lies in one trajectory; K1's 512 threads can stand for the launch path's partition (M <= 4096); K1's
-  // LDS (CDF slots + marks + staged states) fits what the weights occupied; the timeout can be reported; every workgroup of
-  // the grid is resident (one per CU: the weights' LDS)
-  if (range_flag == nullptr || (d != 2 && d != 3) || n_res != 2 || M > 4 * mmf::kK1Block) return MMF_INTERNAL_NOT_RESIDENT;
-  const bool big = static_cast<long long>(N) * M >= 256LL * 8 * 64;
-  const int tile = big ? 64 : 32;
-  if (M % tile != 0) return MMF_INTERNAL_NOT_RESIDENT;
-  const size_t slots = (static_cast<size_t>(M) * 8 + 15) & ~static_cast<size_t>(15);
-  const size_t sc_sz = (sizeof(mmf::K1Scratch) + 15) & ~static_cast<size_t>(15);
-  const size_t marks_sz = ((static_cast<size_t>(M) + 4) * 4 + 15) & ~static_cast<size_t>(15);
-  if (slots + sc_sz + marks_sz + static_cast<size_t>(M) * d * sizeof(float) > static_cast<size_t>(blob_floats(2)) * sizeof(float))
-    return MMF_INTERNAL_NOT_RESIDENT;
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return n;
-  }();
-  const int ntiles = (N * M + tile - 1) / tile;
-  int grid = (ntiles + 7) / 8;
-  if (grid > 256) grid = 256;
-  if (grid > cus) return MMF_INTERNAL_NOT_RESIDENT;
-  NetArgsMulti m{};
-  NetArgs& a = m.a[0];
-  a.packed = packed; a.states_in = states; a.traj_bias = traj_bias; a.mod_logw = modality_logw;
-  a.logw_stride = logw_stride; a.loglik = loglik; a.combine = combine; a.R = N * M; a.M = M;
-  a.range_flag = range_flag;
-  m.k1.enabled = 1; m.k1.N = N; m.k1.logw_in = logw_in; m.k1.u = u; m.k1.estimate = estimate; m.k1.states_out = states_out;
-  m.k1.logw_out = logw_out; m.k1.indices_out = indices_out; m.k1.counters = counters;
-  m.k1.expect = (launch_index + 1u) * static_cast<unsigned>(M / tile);  // the counters are never reset inside a loop
-  m.k1.lw_uniform = static_cast<float>(-std::log(static_cast<double>(M)));
-  m.k1.log_uniform = m.k1.lw_uniform;  // M_out == M
-  return launch_multi<kMeasure>(m, 1, d, n_res, precision, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mmf_pf_measure_multi(const float* const* packed, int count, int n_res, int precision, const float* states,

@@ -28,8 +28,6 @@ static int pf_enqueue_steps(const MmfPfLoopArgs* a, void* stream, bool with_even
   int ev = 0;  // optional timing events: [sample][dynamics, measure x n_meas, resample][start, end]
   const int stride = a->event_stride > 1 ? a->event_stride : 1;
   bool sampled = false;  // an event record costs a barrier packet: long loops sample every stride-th step
-  bool fuse_k1 = a->fuse_k1 && a->k1_counters && a->resample_mode == 1 && !soft && !a->estimate_argmax;
-  unsigned k1_launches = 0;
   auto mark = [&]() {
     if (sampled && with_events) {
       hipError_t e = hipEventRecord(static_cast<hipEvent_t>(a->events[ev++]), hs);
@@ -54,28 +52,10 @@ static int pf_enqueue_steps(const MmfPfLoopArgs* a, void* stream, bool with_even
     // parity certificates keep every step's log-likelihoods and ancestors (null on the timed path)
     float* ll = a->loglik_steps ? a->loglik_steps + t * nm : a->loglik;
     int32_t* anc = a->indices_steps ? a->indices_steps + t * nm : nullptr;
-    float* est = a->estimates + t * row * a->d;
-    bool k1_done = false;  // K1 ran in the tail of the last measurement launch
     {
       for (int k = 0; k < a->n_meas; ++k) {
         const float* lw = a->meas_logw[k] ? a->meas_logw[k] + t * row * a->logw_stride : nullptr;
         if ((rc = mark())) return rc;
-        // plain systematic resampling: K1 in the tail of the step's last measurement launch (MmfPfLoopArgs.fuse_k1) --
-        // except on the steps whose launches are timed one by one
-        if (fuse_k1 && k == a->n_meas - 1 && !sampled) {
-          const float* u = a->uniforms + t * row;
-          rc = mmf_internal_pf_measure_k1(a->meas_packed[k], a->n_res_meas, a->precision, other,
-                                          a->meas_bias[k] + t * row * MMF_UNITS, lw, a->logw_stride, ll, k > 0, a->range_flag,
-                                          a->N, a->M, a->d, t == 0 ? lw_cur : nullptr, u, est, cur,
-                                          t == a->T - 1 ? lw_other : nullptr, anc, a->k1_counters, k1_launches, stream);
-          if (rc == 0) {
-            k1_done = true;
-            ++k1_launches;
-            continue;
-          }
-          if (rc != MMF_INTERNAL_NOT_RESIDENT) return rc;
-          fuse_k1 = false;  // not eligible on this device / for this shape: two launches, for the rest of the loop
-        }
         rc = mmf_pf_measure(a->meas_packed[k], a->n_res_meas, a->precision, other,
                             a->meas_bias[k] + t * row * MMF_UNITS, lw, a->logw_stride, ll, k > 0,
                             a->range_flag, a->N, a->M, a->d, stream);
@@ -83,6 +63,7 @@ static int pf_enqueue_steps(const MmfPfLoopArgs* a, void* stream, bool with_even
         if ((rc = mark())) return rc;
       }
     }
+    float* est = a->estimates + t * row * a->d;
     if (a->estimate_argmax) {
       // the particle with the largest pre-resampling weight; K1's weighted mean goes to the scratch.  In the plain
       // resampling loop the incoming weights are uniform from the second step on (see below)
@@ -103,8 +84,6 @@ static int pf_enqueue_steps(const MmfPfLoopArgs* a, void* stream, bool with_even
                                     a->M, a->M, a->d, 0, stream);
       if (rc) return rc;
       float* s = cur; cur = other; other = s;  // propagated particles are the new belief
-    } else if (k1_done) {
-      // resampled particles already landed in `cur`
     } else {
       const float* u = a->uniforms + t * (a->resample_mode == 1 ? row : nm);
       // every step of this loop resamples, so from the second step on the incoming weights are the

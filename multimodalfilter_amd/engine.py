@@ -148,9 +148,6 @@ def training_image_precision_code() -> int:
 # launch per forward_loop: role-specialised workgroups keep one network's weights in LDS for all T steps and hand the
 # particles over through L2 (csrc/pf_persistent.inc); bit-identical to the launch-per-step loop.  "0": A/B, off.
 PF_PERSISTENT = os.environ.get("MMF_PF_PERSISTENT", "1") not in ("", "0")
-# Larger particle-filter loops with plain systematic resampling: K1 in the TAIL of every step's last measurement launch
-# (csrc/particle_net.hip, K1Tail) instead of a launch of its own; bit-identical.  "0": A/B, off.
-PF_FUSE_K1 = os.environ.get("MMF_PF_FUSE_K1", "1") not in ("", "0")
 # The EKF step loop likewise (mmf_ekf_persistent_plan > 0; csrc/ekf_persistent.inc): a wave owns 8 trajectories of one
 # sub-filter for all T steps, K > 1 sub-filters meet once per step through L2; bit-identical to the 2 T launches.
 EKF_PERSISTENT = os.environ.get("MMF_EKF_PERSISTENT", "1") not in ("", "0")
@@ -204,7 +201,7 @@ def persistent_loop_gave_up(device) -> bool:
     out because a workgroup of the launch was not resident, e.g. another process shares the GPU)?  Clears the bit,
     switches the persistent form off for the rest of the process and warns once; the caller re-runs the loop as a
     loop of launches.  One 4-byte device->host read."""
-    global PF_PERSISTENT, EKF_PERSISTENT, PF_FUSE_K1, _PERSISTENT_WARNED
+    global PF_PERSISTENT, EKF_PERSISTENT, _PERSISTENT_WARNED
     flag = _RANGE_FLAGS.get(str(device))
     if flag is None:
         return False
@@ -212,7 +209,7 @@ def persistent_loop_gave_up(device) -> bool:
     if not bits & 4:
         return False
     flag.bitwise_and_(~4)
-    PF_PERSISTENT = EKF_PERSISTENT = PF_FUSE_K1 = False
+    PF_PERSISTENT = EKF_PERSISTENT = False
     if not _PERSISTENT_WARNED:
         _PERSISTENT_WARNED = True
         import warnings

@@ -353,15 +353,6 @@ class ParticleFilter(base.Filter):
             # the persistent launch needs ALL its workgroups resident; if it gives up (another process on this GPU),
             # the loop is re-run from this copy of the belief as a loop of launches -- see below
             belief_backup = (states_a.clone(), logw_a.clone())
-        elif (engine.PF_FUSE_K1 and mode == 1 and a.soft_alpha == 0.0 and not a.estimate_argmax and d in (2, 3) and M % 32 == 0
-              and M <= 4096 and all(net.n_res == 2 for net, _b, _l in nets)):
-            # K1 in the tail of every step's last measurement launch (csrc/particle_net.hip, K1Tail; the C side decides per
-            # device whether the launch is eligible): its workgroups wait for each other, so the same fallback applies
-            counters = torch.zeros(N, dtype=torch.int32, device=dev)
-            keep.append(counters)
-            a.fuse_k1 = 1
-            a.k1_counters = ctypes.c_void_p(_abi.ptr(counters, dtype=torch.int32))
-            belief_backup = (states_a.clone(), logw_a.clone())
         events = None
         names = ["particle_net_dynamics"] + ["particle_net_measure"] * len(nets) + ["pf_reweight_resample"]
         stride = 1
@@ -369,13 +360,12 @@ class ParticleFilter(base.Filter):
             stride = max(1, int(timer.loop_stride))
             events = timer.loop_events(2 * len(names) * len(range(stride // 2, T, stride)))  # pf_loop.hip samples t % stride == stride // 2
         loc = _abi.pf_forward_loop(a, like, events, stride)
-        if (a.persistent or a.fuse_k1) and engine.persistent_loop_gave_up(dev):
+        if a.persistent and engine.persistent_loop_gave_up(dev):
             # bounded spins ran out (a workgroup of the launch was not resident): nothing of this call can be used.
             # Restore the belief, take the launch-per-step path for this call and for the rest of the process.
             states_a.copy_(belief_backup[0])
             logw_a.copy_(belief_backup[1])
             a.persistent = 0
-            a.fuse_k1 = 0
             loc = _abi.pf_forward_loop(a, like, events, stride)
         if timer is not None:
             R = N * M

@@ -476,75 +476,6 @@ def test_persistent_step_loop_equals_loop_of_launches(cls, N, M, T, precision, n
         engine.PF_PERSISTENT = old_persist
 
 
-@pytest.mark.parametrize("cls,N,M,T,precision,noise", [
-    ("DoorCrossmodalParticleFilter", 32, 4096, 5, "f16x3", "tensor"),    # 64-particle tiles; K1's 512 threads stand for 1024
-    ("DoorCrossmodalParticleFilter", 256, 1024, 4, "f16x3", "philox"),   # BASELINE config 2: every workgroup resamples one trajectory
-    ("DoorCrossmodalParticleFilter", 300, 512, 3, "f16x3", "tensor"),    # more trajectories than workgroups
-    ("PushCrossmodalParticleFilter", 7, 2048, 4, "f16x3", "tensor"),     # d = 2; 32-particle tiles (small problem)
-    ("DoorUnimodalParticleFilter", 9, 3072, 3, "f32", "philox"),         # the bit-reproducible mode; 768-thread partition
-    ("DoorParticleFilter", 40, 4096, 3, "f16x3", "tensor"),              # ONE measurement network (no fold)
-])
-def test_k1_in_the_measurement_tail_equals_its_own_launch(cls, N, M, T, precision, noise):
-    """``MmfPfLoopArgs.fuse_k1``: K1 in the tail of every step's last measurement launch (tiles count themselves on their
-    trajectory's counter; a workgroup out of tiles resamples trajectories in the LDS the weights no longer need --
-    csrc/particle_net.hip, K1Tail) against K1 as its own launch: estimates, ancestors of every step and the final belief are
-    identical BITS, from a non-uniform incoming belief, twice in a row."""
-    _need_gpu()
-    import multimodalfilter_amd as mmf
-    from multimodalfilter_amd import _abi, engine, synthetic
-
-    dev = torch.device("cuda:0")
-    tname = "door" if cls.startswith("Door") else "push"
-    d = om.TASKS[tname].state_dim
-    old = engine.DEFAULT_PRECISION, engine.PF_PERSISTENT, engine.PF_FUSE_K1
-    engine.set_default_precision(precision)
-    engine.PF_PERSISTENT = False
-    try:
-        torch.manual_seed(3)
-        f = mmf.model_types(tname)[cls]().to(dev).eval()
-        f.num_particles = M
-        traj = {k: v.to(dev) for k, v in synthetic.make_trajectories(state_dim=d, T=T + 1, N=N, seed=17).items()}
-        obs = {k: traj[k][1:] for k in ("image", "gripper_pos", "gripper_sensors")}
-        ctrl = traj["controls"][1:]
-        cov = (torch.eye(d, device=dev) * 0.1)[None].expand(N, d, d)
-        g = torch.Generator(device=dev).manual_seed(5)
-        eps0 = torch.randn((N, M, d), generator=g, device=dev)
-        eps = torch.randn((T + 3, N, M, d), generator=g, device=dev)
-        us = torch.rand((T + 3, N), generator=g, device=dev)
-
-        def run(fuse):
-            engine.PF_FUSE_K1 = fuse
-            taken = []
-            real = _abi.pf_forward_loop
-            _abi.pf_forward_loop = lambda a, *r, **k: (taken.append(int(a.fuse_k1)), real(a, *r, **k))[1]
-            try:
-                f.noise = mmf.CounterNoise(99) if noise == "philox" else mmf.StackedNoise(eps0, eps, us)
-                f.initialize_beliefs(mean=traj["states"][0], covariance=cov)
-                f.resample = False   # one step WITHOUT resampling first: the loop then starts from non-uniform log-weights
-                first = f.forward_loop(observations={k: v[:1] for k, v in obs.items()}, controls=ctrl[:1])
-                f.resample = None
-                f.record_indices = True
-                a = f.forward_loop(observations={k: v[1:] for k, v in obs.items()}, controls=ctrl[1:])
-                anc = f.last_resample_indices.clone()
-                f.record_indices = False
-                s1, w1 = f.particle_states.clone(), f.particle_log_weights.clone()
-                b = f.forward_loop(observations={k: v[1:3] for k, v in obs.items()}, controls=ctrl[1:3])
-                return taken, first, a, anc, s1, w1, b, f.particle_states.clone(), f.particle_log_weights.clone()
-            finally:
-                _abi.pf_forward_loop = real
-                f.record_indices = False
-
-        ref = run(False)
-        got = run(True)
-        assert ref[0] == [0, 0, 0] and got[0] == [0, 1, 1], (ref[0], got[0])
-        for x, y in zip(ref[1:], got[1:]):
-            assert torch.equal(x, y)
-        assert bool(torch.isfinite(got[2]).all())
-    finally:
-        engine.set_default_precision(old[0])
-        engine.PF_PERSISTENT, engine.PF_FUSE_K1 = old[1], old[2]
-
-
 @pytest.mark.parametrize("cls,kw,masked", [
     ("DoorKalmanFilter", {}, False),
     ("PushKalmanFilter", {}, False),
