@@ -231,7 +231,7 @@ def run_ekf_loop(a, mu: torch.Tensor, Sigma: torch.Tensor):
             and _abi.ekf_persistent_plan(a.N, a.K) > 0):
         n_words = _abi.ekf_persistent_sync_words(a.N, a.K, a.d)
         sync = torch.empty(n_words, dtype=torch.int32, device=dev)  # tagged granules of the hand-offs (zeroed by the call)
-        keep = (sync, mu.clone(), Sigma.clone())
+        keep = (sync, mu.clone(), Sigma.clone()) if a.K > 1 else (sync, None, None)  # (one sub-filter: no hand-offs, nothing can time out)
         a.persistent, a.n_sync_words = 1, n_words
         a.sync_words = ctypes.c_void_p(_abi.ptr(sync, dtype=torch.int32))
         a.range_flag = ctypes.c_void_p(_abi.ptr(range_flag(dev), dtype=torch.int32))  # bit 2: "a hand-off timed out"

@@ -59,6 +59,9 @@ python scripts/gpu_busy.py $(find $P/stats_ref -name "*kernel_trace.csv" | head 
 python scripts/gpu_busy.py $(find $P/stats_ekf -name "*kernel_trace.csv" | head -1) --top 3 --kernels 12 > $OUT/door_ekf_gpu_busy.txt 2>&1
 python scripts/gpu_busy.py $(find $P/stats -name "*kernel_trace.csv" | head -1) --top 3 --kernels 8 > $OUT/door_pf_gpu_busy.txt 2>&1
 python scripts/collect_profiles.py $P $OUT/collected > $OUT/collect.log 2>&1
+# the bench lines below quote `roofline.traffic` from the newest committed profile: make that THIS run's counter passes (the
+# box's copy of the repo; the same files go into profiles/r06 afterwards), so that a line and the file it names agree to the bit
+mkdir -p $R/profiles/r06 && cp $OUT/collected/pmc_hbm_traffic*.json $R/profiles/r06/
 # K2: SQ counters + effective clock of the shipped (column-half) pipeline
 bash scripts/pmc_k2_r04.sh shipped > /dev/null 2>&1
 cp gpurun_out/pmc_k2_r04/shipped.json $OUT/pmc_k2_sq_counters.json
