@@ -8,7 +8,7 @@ import json,sys
 l=[json.loads(x) for x in sys.stdin if x.startswith('{')][-1]
 print('  %4d x %5d persistent=$3: %.4e particle-steps/s  %.2f us/step' % ($1, $2, l['value'], 1e3*l['ms_per_step']))"
 }
-for shape in ${SHAPES:-32x4096 64x4096 128x4096 256x4096 32x2048 64x1024 128x1024 256x1024 48x2048}; do
+for shape in ${SHAPES:-16x4096 8x4096 32x2048 24x3000 64x1024 40x1500 32x4096 64x4096}; do
   set -- ${shape%x*} ${shape#*x}
   run $1 $2 1
   run $1 $2 0

@@ -416,11 +416,6 @@ def test_persistent_loop_that_gives_up_is_rerun_as_a_loop_of_launches():
     ("DoorCrossmodalParticleFilter", 32, 2048, 4, "f16x3", "tensor"),   # four rounds of tiles per wave and step
     ("DoorCrossmodalParticleFilter", 24, 3000, 3, "f32", "philox"),     # K1: ragged second chunk (768-thread partition), bit-reproducible mode
     ("PushCrossmodalParticleFilter", 24, 3328, 3, "f16x3", "philox"),   # d = 2; K1: 832-thread partition
-    # 64-particle pipelined tiles inside the persistent roles (f16x3, M % 64 == 0, several rounds per wave)
-    ("DoorCrossmodalParticleFilter", 32, 4096, 4, "f16x3", "tensor"),   # SURVEY's small-batch point
-    ("DoorCrossmodalParticleFilterSeq5", 40, 1536, 3, "f16x3", "philox"),  # blacked-out frames (-inf modality weights)
-    ("PushCrossmodalParticleFilter", 48, 2048, 3, "f16x3", "tensor"),   # d = 2
-    ("DoorCrossmodalParticleFilter", 32, 4096, 3, "f32", "tensor"),     # f32 mode at the same shape: not eligible -> launches (same call path)
 ])
 def test_persistent_step_loop_equals_loop_of_launches(cls, N, M, T, precision, noise):
     """``mmf_pf_forward_loop`` with ``MmfPfLoopArgs.persistent`` (ONE launch for all T steps: role-specialised
