@@ -799,6 +799,10 @@ def run_configs(args, device, headline_filter, d, K, W):
     share = None
     if args.workload == "door_pf":
         share = {k: v.detach().clone() for k, v in headline_filter.state_dict().items()}
+    # BASELINE config 1 is the reference's own CPU-runnable case (door unimodal EKF, 32 trajectories): here on the GPU, its
+    # recursion as ONE persistent launch (csrc/ekf_persistent.inc), with the CPU oracle timed at the same batch beside it
+    c1 = dict(task="door", cls="DoorUnimodalKalmanFilter", kind="ekf", batch=32, particles=1, desc="door unimodal EKF")
+    guarded("C1_door_unimodal_ekf_32", lambda: leg_ekf("C1", c1, K=4 * Kl, W=W, device=device, cpu_batch=32, cpu_steps=200))
     c2 = dict(WORKLOADS["door_pf"], batch=256, particles=1024)
     guarded("C2_door_crossmodal_pf_256x1024", lambda: leg_pf("C2", c2, K=Kl, W=W, device=device, share_state=share)[0])
     c3 = dict(WORKLOADS["push_pf"], batch=1024, particles=4096)
@@ -1186,7 +1190,7 @@ def main():
         if out.get("roofline") is not None:
             out["roofline"]["f32_mode"] = {"value": f32m["value"], "ms_per_step": f32m["ms_per_step"],
                                            "frac": (f32m.get("roofline") or {}).get("frac"), "peak": MFMA_PEAK["f32"]}
-    for key, short in (("C2_door_crossmodal_pf_256x1024", "c2"), ("C3_push_crossmodal_pf_1024x4096", "c3"),
+    for key, short in (("C1_door_unimodal_ekf_32", "c1"), ("C2_door_crossmodal_pf_256x1024", "c2"), ("C3_push_crossmodal_pf_1024x4096", "c3"),
                        ("C4_door_crossmodal_ekf_1024_per_gpu_share_of_8192", "c4"), ("C5_push_unimodal_pf_train_32x8192x16", "c5")):
         leg = (out.get("configs") or {}).get(key) or {}
         if "ms_per_step" in leg:
