@@ -40,6 +40,19 @@ def test_size_queries_need_no_gpu():
     assert lib.mmf_pf_reweight_resample_lds_bytes(4096, 0) >= 4096 * 4
 
 
+def test_persistent_loop_sizing_needs_no_gpu():
+    """The persistent loops' host-side sizing: workspace words follow the documented layout; without a device no problem is
+    eligible (the plan asks the runtime for the CU count) and nothing crashes; nonsense arguments are refused."""
+    from multimodalfilter_amd import _abi
+
+    assert _abi.pf_persistent_sync_words(32, 300, 3, 2) == 4 + 2 * (2 * 32 * 300 * 3 + 2 * 32 * 300)
+    assert _abi.ekf_persistent_sync_words(32, 2, 3) == 4 + 2 * (2 * 2 * 32 * (3 + 9))
+    assert _abi.ekf_persistent_sync_words(0, 2, 3) == 0
+    if not torch.cuda.is_available():
+        assert _abi.pf_persistent_plan(32, 300, 2) == 0 and _abi.ekf_persistent_plan(32, 2) == 0
+    assert _abi.ekf_persistent_plan(0, 2) < 0 and _abi.ekf_persistent_plan(32, 9) < 0  # MMF_EINVAL
+
+
 def test_descriptor_layout_matches_header():
     from multimodalfilter_amd import _abi
 
