@@ -435,10 +435,29 @@ __global__ __launch_bounds__(256) void fc_partial_f16x3_kernel(FcArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
   float amax = 0.f;
-#pragma unroll 4
+  // rolling requests (the loop is fully unrolled: every buffer index is static): activations four k-steps ahead (HBM), weight
+  // fragments two ahead (L2).  Left to the compiler the fragments were requested right before their MFMAs: an L2 round
+  // trip on every k-step of every wave.
+  f32x4 xb[4][2];
+  half8 wb[2][4];
+  auto load_x = [&](int ks, int b) {
+    xb[b][0] = *reinterpret_cast<const f32x4*>(X + 16 * ks);
+    xb[b][1] = *reinterpret_cast<const f32x4*>(X + 16 * ks + 4);
+  };
+  auto load_w = [&](int ks, int b) {
+    const unsigned char* wp = W + static_cast<size_t>(ks) * 4096;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) wb[b][f] = *reinterpret_cast<const half8*>(wp + 1024 * f);  // tile 0 hi, lo, tile 1 hi, lo
+  };
+  load_x(0, 0);
+  load_w(0, 0);
+  load_x(1, 1);
+  load_w(1, 1);
+  load_x(2, 2);
+  load_x(3, 3);
+#pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(X + 16 * ks);
-    const f32x4 x1 = *reinterpret_cast<const f32x4*>(X + 16 * ks + 4);
+    const f32x4 x0 = xb[ks & 3][0], x1 = xb[ks & 3][1];
     const float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
     u32x4 hv, lv;
 #pragma unroll
@@ -453,16 +472,17 @@ __global__ __launch_bounds__(256) void fc_partial_f16x3_kernel(FcArgs a) {
       hv[p] = __builtin_bit_cast(unsigned, hh);
       lv[p] = __builtin_bit_cast(unsigned, ll);
     }
+    if (ks + 4 < KSTEPS) load_x(ks + 4, ks & 3);
     const half8 bhi = __builtin_bit_cast(half8, hv), blo = __builtin_bit_cast(half8, lv);
-    const unsigned char* wp = W + static_cast<size_t>(ks) * 4096;
-    const half8 a0hi = *reinterpret_cast<const half8*>(wp), a0lo = *reinterpret_cast<const half8*>(wp + 1024);
-    const half8 a1hi = *reinterpret_cast<const half8*>(wp + 2048), a1lo = *reinterpret_cast<const half8*>(wp + 3072);
+    const half8 a0hi = wb[ks & 1][0], a0lo = wb[ks & 1][1], a1hi = wb[ks & 1][2], a1lo = wb[ks & 1][3];
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0hi, bhi, acc0, 0, 0, 0);
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0hi, blo, acc0, 0, 0, 0);
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0lo, bhi, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1hi, bhi, acc1, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1hi, blo, acc1, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1lo, bhi, acc1, 0, 0, 0);
+    if (ks + 2 < KSTEPS) load_w(ks + 2, ks & 1);
+    __builtin_amdgcn_sched_barrier(0);  // left alone the scheduler sinks every request to just before its use
   }
   if (a.range_flag != nullptr && !(amax < 65504.0f)) atomicOr(a.range_flag, 1);
   if (img0 + j < a.N) {
