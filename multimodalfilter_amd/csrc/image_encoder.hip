@@ -524,17 +524,30 @@ __global__ __launch_bounds__(256) void fc_tail_kernel(FcArgs a) {
 #pragma unroll 8
     for (int k = 0; k < kFeat; ++k) h += blob[L.fcw + lane * kFeat + k] * __shfl(pooled, k);
   } else {
-    for (int s = 0; s < kFcSplit; ++s)
-      h += a.partial[((static_cast<size_t>(net) * kFcSplit + s) * a.N + img) * kFeat + lane];
+    float ps[kFcSplit];  // the 16 partial sums are requested together and added in slice order
+#pragma unroll
+    for (int s = 0; s < kFcSplit; ++s) ps[s] = a.partial[((static_cast<size_t>(net) * kFcSplit + s) * a.N + img) * kFeat + lane];
+#pragma unroll
+    for (int s = 0; s < kFcSplit; ++s) h += ps[s];
   }
+  // ResLinear(64): this lane's column of each 64 x 64 matrix is requested as ONE batch of 64 loads (eight at a time, each
+  // batch a dependent L2 round trip on the chain, was most of this kernel's 19 us), lane k's value travels by v_readlane
+  // (what __shfl(v, k) returns, without the LDS crossbar); same fused multiply-adds in the same order
+  auto bcast = [](float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); };
+  float w[kFeat];
+#pragma unroll
+  for (int k = 0; k < kFeat; ++k) w[k] = blob[L.r1t + k * kFeat + lane];
+  const float r1b = blob[L.r1b + lane], r2b = blob[L.r2b + lane];
   h = fmaxf(h, 0.f);
-  float t = blob[L.r1b + lane];
-#pragma unroll 8
-  for (int k = 0; k < kFeat; ++k) t = __builtin_fmaf(blob[L.r1t + k * kFeat + lane], __shfl(h, k), t);  // explicit chains: strict mode
+  float t = r1b;
+#pragma unroll
+  for (int k = 0; k < kFeat; ++k) t = __builtin_fmaf(w[k], bcast(h, k), t);  // explicit chains: strict mode
+#pragma unroll
+  for (int k = 0; k < kFeat; ++k) w[k] = blob[L.r2t + k * kFeat + lane];
   t = fmaxf(t, 0.f);
-  float y = blob[L.r2b + lane] + h;
-#pragma unroll 8
-  for (int k = 0; k < kFeat; ++k) y = __builtin_fmaf(blob[L.r2t + k * kFeat + lane], __shfl(t, k), y);
+  float y = r2b + h;
+#pragma unroll
+  for (int k = 0; k < kFeat; ++k) y = __builtin_fmaf(w[k], bcast(t, k), y);
   a.feat[(static_cast<size_t>(net) * a.N + img) * kFeat + lane] = fmaxf(y, 0.f);
 }
 
